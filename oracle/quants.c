@@ -1,0 +1,328 @@
+// TEST INFRASTRUCTURE — see oracle.h.  Block formats, activation quantisers, dequantisers and the quantised
+// dot products of the reference CPU path, restated in plain scalar C with the AVX2 arm's lane structure.
+#include "oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+// ---- fp16 <-> fp32: IEEE binary16, round-to-nearest-even, as F16C's _cvtss_sh(x,0)/_cvtsh_ss (ggml-impl.h:88-92)
+float o_fp16_to_fp32(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000u) << 16;
+    const uint32_t exp  = (h >> 10) & 0x1f;
+    uint32_t mant = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (mant == 0) {
+            bits = sign;
+        } else {                       // subnormal: normalise
+            int e = -1;
+            do { e++; mant <<= 1; } while (!(mant & 0x400u));
+            bits = sign | (uint32_t) (112 - e) << 23 | (mant & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | mant << 13;
+    } else {
+        bits = sign | (exp + 112) << 23 | mant << 13;
+    }
+    float f; memcpy(&f, &bits, 4);
+    return f;
+}
+
+uint16_t o_fp32_to_fp16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t) ((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t) (sign | 0x7e00u | ((x >> 13) & 0x3ffu));   // NaN
+    if (x >= 0x47800000u) return (uint16_t) (sign | 0x7c00u);                          // >= 65536 or inf
+    const uint32_t exp  = x >> 23;
+    const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+    if (exp < 113) {                                                                   // result is subnormal/zero
+        if (exp < 102) return sign;
+        const int shift = 126 - (int) exp;                                             // 14..24
+        uint32_t q = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (q & 1))) q++;
+        return (uint16_t) (sign | q);
+    }
+    uint32_t h = (exp - 112) << 10 | (mant & 0x7fffffu) >> 13;
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;                             // carry may roll into inf: correct
+    return (uint16_t) (sign | h);
+}
+
+int o_blck_size(int type) {
+    switch (type) {
+        case OT_F32: case OT_F16: return 1;
+        case OT_Q4_0: case OT_Q8_0: return OQK;
+        case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: case OT_Q8_K: return OQK_K;
+    }
+    return 0;
+}
+
+int o_type_size(int type) {
+    switch (type) {
+        case OT_F32: return 4; case OT_F16: return 2;
+        case OT_Q4_0: return sizeof(oblk_q4_0); case OT_Q8_0: return sizeof(oblk_q8_0);
+        case OT_Q4_K: return sizeof(oblk_q4_K); case OT_Q5_K: return sizeof(oblk_q5_K);
+        case OT_Q6_K: return sizeof(oblk_q6_K); case OT_Q8_K: return sizeof(oblk_q8_K);
+    }
+    return 0;
+}
+
+size_t o_row_size(int type, int64_t n) { return (size_t) (n / o_blck_size(type)) * o_type_size(type); }
+
+// ggml.c:415-600 type_traits[].vec_dot_type
+int o_vec_dot_type(int type) {
+    switch (type) {
+        case OT_F32: return OT_F32; case OT_F16: return OT_F16;
+        case OT_Q4_0: case OT_Q8_0: return OT_Q8_0;
+        case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: return OT_Q8_K;
+    }
+    return -1;
+}
+
+// ggml-quants.c:1191-1196 — round-half-even through the 1.5*2^23 magic constant
+static inline int nearest_int(float fval) {
+    float val = fval + 12582912.f;
+    int i; memcpy(&i, &val, sizeof(int));
+    return (i & 0x007fffff) - 0x00400000;
+}
+
+// ggml-quants.c:2329-2364 (quantize_row_q8_K_reference; there is no SIMD variant)
+void o_quantize_row_q8_K(const float * x, void * vy, int k) {
+    oblk_q8_K * y = vy;
+    const int nb = k / OQK_K;
+    for (int i = 0; i < nb; i++, x += OQK_K) {
+        float max = 0, amax = 0;
+        for (int j = 0; j < OQK_K; ++j) {
+            const float ax = fabsf(x[j]);
+            if (ax > amax) { amax = ax; max = x[j]; }
+        }
+        if (!amax) {
+            // (the reference leaves bsums untouched here; activations are never all-zero in practice. We zero them.)
+            y[i].d = 0; memset(y[i].qs, 0, OQK_K); memset(y[i].bsums, 0, sizeof y[i].bsums);
+            continue;
+        }
+        const float iscale = -128.f / max;
+        for (int j = 0; j < OQK_K; ++j) {
+            const int v = nearest_int(iscale * x[j]);
+            y[i].qs[j] = (int8_t) (v < 127 ? v : 127);
+        }
+        for (int j = 0; j < OQK_K / 16; ++j) {
+            int sum = 0;
+            for (int ii = 0; ii < 16; ++ii) sum += y[i].qs[j * 16 + ii];
+            y[i].bsums[j] = (int16_t) sum;
+        }
+        y[i].d = 1 / iscale;
+    }
+}
+
+// ggml-quants.c:702-760 — the AVX/AVX2 arm of quantize_row_q8_0: d = amax/127 (stored f16), id = 127/amax,
+// round-half-even (_mm256_round_ps NEAREST).  (The scalar arm :607-630 uses 1/d and roundf; we follow AVX.)
+void o_quantize_row_q8_0(const float * x, void * vy, int k) {
+    oblk_q8_0 * y = vy;
+    const int nb = k / OQK;
+    for (int i = 0; i < nb; i++, x += OQK) {
+        float amax = 0.0f;
+        for (int j = 0; j < OQK; j++) { const float a = fabsf(x[j]); if (a > amax) amax = a; }
+        const float d  = amax / 127.f;
+        y[i].d = o_fp32_to_fp16(d);
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        for (int j = 0; j < OQK; ++j) {
+            int v = (int) nearbyintf(x[j] * id);
+            if (v > 127) v = 127; else if (v < -128) v = -128;       // packs_epi32/epi16 saturate
+            y[i].qs[j] = (int8_t) v;
+        }
+    }
+}
+
+void o_quantize_act(int vec_dot_type, const float * x, void * y, int k) {
+    if (vec_dot_type == OT_Q8_K) o_quantize_row_q8_K(x, y, k); else o_quantize_row_q8_0(x, y, k);
+}
+
+// ggml-quants.c:1446-1453
+static inline void scale_min_k4(int j, const uint8_t * q, uint8_t * d, uint8_t * m) {
+    if (j < 4) { *d = q[j] & 63; *m = q[j + 4] & 63; }
+    else       { *d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); *m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+
+// element e (0..255) of a Q4_K / Q5_K / Q6_K super-block as the integer the dot product multiplies
+static inline int q4k_at(const oblk_q4_K * b, int e) { const int j = e >> 6, h = (e >> 5) & 1, l = e & 31; const uint8_t q = b->qs[32 * j + l]; return h ? q >> 4 : q & 0xF; }
+static inline int q5k_at(const oblk_q5_K * b, int e) {
+    const int j = e >> 6, h = (e >> 5) & 1, l = e & 31; const uint8_t q = b->qs[32 * j + l];
+    return (h ? q >> 4 : q & 0xF) + (((b->qh[l] >> (2 * j + h)) & 1) << 4);
+}
+static inline int q6k_at(const oblk_q6_K * b, int e) {                        // 0..63 (before the -32)
+    const int n = e >> 7, g = (e >> 5) & 3, l = e & 31;
+    const uint8_t lo = b->ql[64 * n + 32 * (g & 1) + l];
+    return ((g & 2) ? lo >> 4 : lo & 0xF) | (((b->qh[32 * n + l] >> (2 * g)) & 3) << 4);
+}
+
+// ggml-quants.c:1074-1092, 1168-1182, 1917-1954, 2117-2160, 2263-2308
+void o_dequantize_row(int type, const void * vx, float * y, int k) {
+    switch (type) {
+        case OT_F32: memcpy(y, vx, (size_t) 4 * k); break;
+        case OT_F16: { const uint16_t * x = vx; for (int i = 0; i < k; i++) y[i] = o_fp16_to_fp32(x[i]); } break;
+        case OT_Q4_0: {
+            const oblk_q4_0 * x = vx;
+            for (int i = 0; i < k / OQK; i++) {
+                const float d = o_fp16_to_fp32(x[i].d);
+                for (int j = 0; j < 16; ++j) {
+                    y[i * OQK + j]      = ((x[i].qs[j] & 0x0F) - 8) * d;
+                    y[i * OQK + j + 16] = ((x[i].qs[j] >> 4) - 8) * d;
+                }
+            }
+        } break;
+        case OT_Q8_0: {
+            const oblk_q8_0 * x = vx;
+            for (int i = 0; i < k / OQK; i++) {
+                const float d = o_fp16_to_fp32(x[i].d);
+                for (int j = 0; j < OQK; ++j) y[i * OQK + j] = x[i].qs[j] * d;
+            }
+        } break;
+        case OT_Q4_K: {
+            const oblk_q4_K * x = vx;
+            for (int i = 0; i < k / OQK_K; i++) {
+                const float d = o_fp16_to_fp32(x[i].d), min = o_fp16_to_fp32(x[i].dmin);
+                for (int s = 0; s < 8; s++) {
+                    uint8_t sc, m; scale_min_k4(s, x[i].scales, &sc, &m);
+                    const float d1 = d * sc, m1 = min * m;
+                    for (int l = 0; l < 32; ++l) *y++ = d1 * q4k_at(&x[i], 32 * s + l) - m1;
+                }
+            }
+        } break;
+        case OT_Q5_K: {
+            const oblk_q5_K * x = vx;
+            for (int i = 0; i < k / OQK_K; i++) {
+                const float d = o_fp16_to_fp32(x[i].d), min = o_fp16_to_fp32(x[i].dmin);
+                for (int s = 0; s < 8; s++) {
+                    uint8_t sc, m; scale_min_k4(s, x[i].scales, &sc, &m);
+                    const float d1 = d * sc, m1 = min * m;
+                    for (int l = 0; l < 32; ++l) *y++ = d1 * q5k_at(&x[i], 32 * s + l) - m1;
+                }
+            }
+        } break;
+        case OT_Q6_K: {
+            const oblk_q6_K * x = vx;
+            for (int i = 0; i < k / OQK_K; i++) {
+                const float d = o_fp16_to_fp32(x[i].d);
+                for (int e = 0; e < OQK_K; e++) {
+                    const int8_t q = (int8_t) q6k_at(&x[i], e) - 32;
+                    *y++ = d * x[i].scales[e >> 4] * q;
+                }
+            }
+        } break;
+    }
+}
+
+// hsum_float_8 (ggml-quants.c:67-73): (a4+a0, a5+a1, a6+a2, a7+a3) -> (r0+r2, r1+r3) -> sum
+static inline float hsum8(const float a[8]) {
+    const float r0 = a[4] + a[0], r1 = a[5] + a[1], r2 = a[6] + a[2], r3 = a[7] + a[3];
+    const float s0 = r0 + r2, s1 = r1 + r3;
+    return s0 + s1;
+}
+
+// per-lane integer sums of one block: lane k (0..7) covers bytes 4k..4k+3 of every 32-element group,
+// the grouping _mm256_maddubs_epi16 + _mm256_madd_epi16 produce.
+void o_block_isums(int type, const void * xb, const void * yb, int32_t * isum, int32_t * msum) {
+    for (int k = 0; k < 8; k++) isum[k] = 0;
+    *msum = 0;
+    if (type == OT_Q4_0 || type == OT_Q8_0) {
+        const oblk_q8_0 * y = yb;
+        for (int b = 0; b < 32; b++) {
+            int xv;
+            if (type == OT_Q4_0) { const oblk_q4_0 * x = xb; xv = (b < 16 ? x->qs[b] & 0xF : x->qs[b - 16] >> 4) - 8; }
+            else                 { const oblk_q8_0 * x = xb; xv = x->qs[b]; }
+            isum[b >> 2] += xv * y->qs[b];
+        }
+        return;
+    }
+    const oblk_q8_K * y = yb;
+    if (type == OT_Q6_K) {
+        const oblk_q6_K * x = xb;
+        for (int e = 0; e < OQK_K; e++) isum[(e & 31) >> 2] += x->scales[e >> 4] * (q6k_at(x, e) - 32) * y->qs[e];
+        return;
+    }
+    const uint8_t * scales = type == OT_Q4_K ? ((const oblk_q4_K *) xb)->scales : ((const oblk_q5_K *) xb)->scales;
+    for (int s = 0; s < 8; s++) {
+        uint8_t sc, m; scale_min_k4(s, scales, &sc, &m);
+        for (int l = 0; l < 32; l++) {
+            const int e = 32 * s + l;
+            const int q = type == OT_Q4_K ? q4k_at(xb, e) : q5k_at(xb, e);
+            isum[l >> 2] += sc * q * y->qs[e];
+        }
+        *msum += m * (y->bsums[2 * s] + y->bsums[2 * s + 1]);
+    }
+}
+
+// ggml_vec_dot_q4_K_q8_K AVX2 arm (ggml-quants.c:5318-5381), q5_K (:5967-6050), q6_K (:6741-6810),
+// q4_0 (:2500-2523), q8_0 (:3584-3605)
+float o_vec_dot(int type, int n, const void * vx, const void * vy) {
+    float acc[8] = { 0 };
+    if (type == OT_F16) return 0.0f; // see ops.c o_vec_dot_f16
+    if (type == OT_F32) { // ggml_vec_dot_f32 AVX arm (ggml.c:1157-1191): 4 accumulators x 8 lanes
+        const float * x = vx, * y = vy;
+        float sum[4][8] = { { 0 } };
+        const int np = n & ~31;
+        for (int i = 0; i < np; i += 32)
+            for (int j = 0; j < 4; j++)
+                for (int l = 0; l < 8; l++) sum[j][l] = fmaf(x[i + 8 * j + l], y[i + 8 * j + l], sum[j][l]);
+        for (int l = 0; l < 8; l++) { sum[0][l] += sum[2][l]; sum[1][l] += sum[3][l]; }
+        for (int l = 0; l < 8; l++) sum[0][l] += sum[1][l];
+        float t[4]; for (int l = 0; l < 4; l++) t[l] = sum[0][l] + sum[0][l + 4];
+        float sumf = (t[0] + t[1]) + (t[2] + t[3]);
+        for (int i = np; i < n; ++i) sumf += x[i] * y[i];
+        return sumf;
+    }
+    if (type == OT_Q4_0 || type == OT_Q8_0) {
+        const int nb = n / OQK;
+        const oblk_q8_0 * y = vy;
+        for (int i = 0; i < nb; i++) {
+            int32_t is[8], ms;
+            const void * xb = type == OT_Q4_0 ? (const void *) ((const oblk_q4_0 *) vx + i) : (const void *) ((const oblk_q8_0 *) vx + i);
+            const uint16_t xd = type == OT_Q4_0 ? ((const oblk_q4_0 *) vx)[i].d : ((const oblk_q8_0 *) vx)[i].d;
+            o_block_isums(type, xb, &y[i], is, &ms);
+            const float d = o_fp16_to_fp32(xd) * o_fp16_to_fp32(y[i].d);
+            for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+        }
+        return hsum8(acc);
+    }
+    const int nb = n / OQK_K;
+    const oblk_q8_K * y = vy;
+    if (type == OT_Q6_K) {
+        const oblk_q6_K * x = vx;
+        for (int i = 0; i < nb; i++) {
+            int32_t is[8], ms;
+            o_block_isums(type, &x[i], &y[i], is, &ms);
+            const float d = y[i].d * o_fp16_to_fp32(x[i].d);
+            for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+        }
+        return hsum8(acc);
+    }
+    float acc_m[4] = { 0 };
+    float summs = 0.0f;
+    for (int i = 0; i < nb; i++) {
+        const uint8_t * scales; uint16_t xd, xdmin; const void * xb;
+        if (type == OT_Q4_K) { const oblk_q4_K * x = (const oblk_q4_K *) vx + i; scales = x->scales; xd = x->d; xdmin = x->dmin; xb = x; }
+        else                 { const oblk_q5_K * x = (const oblk_q5_K *) vx + i; scales = x->scales; xd = x->d; xdmin = x->dmin; xb = x; }
+        const float d    =  y[i].d * o_fp16_to_fp32(xd);
+        const float dmin = -y[i].d * o_fp16_to_fp32(xdmin);
+        int32_t prod[4];
+        for (int k = 0; k < 4; k++) {
+            uint8_t sc, m0, m1;
+            scale_min_k4(2 * k, scales, &sc, &m0); scale_min_k4(2 * k + 1, scales, &sc, &m1);
+            const int16_t s0 = (int16_t) (y[i].bsums[4 * k] + y[i].bsums[4 * k + 1]), s1 = (int16_t) (y[i].bsums[4 * k + 2] + y[i].bsums[4 * k + 3]);
+            prod[k] = m0 * s0 + m1 * s1;
+        }
+        if (type == OT_Q4_K) for (int k = 0; k < 4; k++) acc_m[k] = fmaf(dmin, (float) prod[k], acc_m[k]);
+        else                 summs += dmin * (float) (prod[0] + prod[1] + prod[2] + prod[3]);
+        int32_t is[8], ms;
+        o_block_isums(type, xb, &y[i], is, &ms);
+        for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+    }
+    if (type == OT_Q4_K) {
+        const float a0 = acc_m[0] + acc_m[2], a1 = acc_m[1] + acc_m[3];
+        return hsum8(acc) + (a0 + a1);
+    }
+    return hsum8(acc) + summs;
+}

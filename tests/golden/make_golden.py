@@ -1,0 +1,136 @@
+"""Generates the committed fixtures under tests/golden/.  Runs ONLY in the build container (needs oracle/_ref, i.e. the
+real reference library compiled from /root/reference).  Outputs are data: tiny quantised GGUF models (weights quantised
+by the reference's own quantize_row_*_reference) and the reference kernels' outputs on seeded inputs.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from pipeinfer_amd.tools import synth  # noqa: E402
+from tests import oracle_lib as O  # noqa: E402
+from tests import scenarios as S  # noqa: E402
+
+MODELS = [  # (file stem, spec, ftype, seed)
+    ("tiny_llama_q4_k_m", "tiny-llama", "q4_k_m", 11),
+    ("tiny_llama_q4_0", "tiny-llama", "q4_0", 12),
+    ("tiny_llama_b_q4_k_m", "tiny-llama-b", "q4_k_m", 13),     # "draft"-vs-"target" pair partner, MHA
+    ("tiny_falcon_q4_0", "tiny-falcon", "q4_0", 14),           # 7B-style: MQA, single norm, Q8_0 head
+    ("tiny_falcon40_q4_k_m", "tiny-falcon40", "q4_k_m", 15),   # 40B-style: GQA, two norms, Q5_K qkv
+]
+
+
+def ref_quantizer():
+    r = O.ref()
+
+    def q(ttype, x):
+        x = np.ascontiguousarray(x, np.float32)
+        if ttype == 0:
+            return x.view(np.uint8).reshape(-1)
+        out = np.zeros(O.row_size(ttype, x.size), np.uint8)
+        r.ref_quantize_reference(ttype, O._ptr(x), O._ptr(out), x.size)
+        return out
+    return q
+
+
+def synth_signal(n, seed):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n, dtype=np.float32)
+    return (0.1 + 2.0 * np.cos(i + seed)).astype(np.float32) + rng.standard_normal(n).astype(np.float32) * 0.5
+
+
+def kernel_vectors():
+    """K1/K2 of SURVEY 8c: per-type quant blocks + activations + reference outputs; elementwise op outputs"""
+    r = O.Impl("ref")
+    q = ref_quantizer()
+    out = {}
+    k = 1024
+    for t in (O.Q4_0, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K):
+        rng = np.random.default_rng(100 + t)
+        w = (rng.standard_normal((6, k)) * 0.05).astype(np.float32)
+        blocks = q(t, w).reshape(6, -1)
+        act = np.stack([synth_signal(k, s + t) for s in range(3)])
+        vdt = O.VEC_DOT_TYPE[t]
+        qa = np.stack([r.quantize_act(vdt, a) for a in act])
+        dots = np.array([[r.vec_dot(t, k, blocks[i], qa[j]) for i in range(6)] for j in range(3)], np.float32)
+        name = O.TYPE_NAMES[t]
+        out[f"{name}_blocks"] = blocks
+        out[f"{name}_act"] = act
+        out[f"{name}_qact"] = qa
+        out[f"{name}_dots"] = dots
+        out[f"{name}_deq"] = np.stack([r.dequantize(t, b, k) for b in blocks])
+    x = np.stack([synth_signal(512, s) for s in range(3)])
+    out["norm_x"] = x
+    out["rms_norm_y"] = r.rms_norm(x, 1e-5)
+    out["layer_norm_y"] = r.norm(x, 1e-5)
+    rng = np.random.default_rng(7)
+    rx = rng.standard_normal((5, 3, 64)).astype(np.float32)
+    pos = np.array([0, 1, 9, 300, 1023], np.int32)
+    out["rope_x"] = rx
+    out["rope_pos"] = pos
+    out["rope_mode0"] = r.rope(rx, pos, 0)
+    out["rope_mode2"] = r.rope(rx, pos, 2)
+    sx = (rng.standard_normal((6, 77)) * 3).astype(np.float32)
+    sx[:, 60:] = -np.inf
+    sx[2, :5] = -np.inf
+    out["softmax_x"] = sx
+    out["softmax_y"] = r.soft_max(sx)
+    ux = (rng.standard_normal(4096) * 3).astype(np.float32)
+    out["unary_x"] = ux
+    out["silu_y"] = r.silu(ux)
+    out["gelu_y"] = r.gelu(ux)
+    fx = (rng.standard_normal(4096) * np.float32(10.0) ** rng.integers(-8, 5, 4096)).astype(np.float32)
+    out["f16_x"] = fx
+    h = np.zeros(fx.size, np.uint16)
+    O.ref().ref_fp32_to_fp16_row(O._ptr(fx), O._ptr(h), fx.size)
+    out["f16_bits"] = h
+    # the three fp16 tables are NOT committed; a 256-entry strided sample pins the formula
+    idx = np.arange(0, 65536, 257, dtype=np.int64)
+    tx = idx.astype(np.uint16).view(np.float16).astype(np.float32)
+    fin = np.isfinite(tx)
+    out["table_idx"] = idx[fin].astype(np.int32)
+    out["table_silu"] = O.f32_to_f16_bits(r.silu(tx[fin]))
+    out["table_gelu"] = O.f32_to_f16_bits(r.gelu(tx[fin]))
+    np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
+
+
+def model_vectors():
+    q = ref_quantizer()
+    for stem, spec, ftype, seed in MODELS:
+        path = os.path.join(HERE, stem + ".gguf")
+        synth.write_model(path, spec, ftype, seed=seed, std=0.08, quantizer=q)
+        n_vocab = synth.SPECS[spec][6]
+        res = {}
+        m = O.RefModel(path, n_ctx=128, max_seq=8)
+        ops = S.scenario_spec_like(n_vocab, seed=seed)
+        for i, lg in enumerate(S.run_scenario(ops, m)):
+            res[f"spec_like_{i}"] = lg
+        m.close()
+        # greedy continuation: prompt batched, then token by token (the lossless-speculation ground truth)
+        prompt, n_gen = S.scenario_greedy(n_vocab, seed=seed)
+        m = O.RefModel(path, n_ctx=128, max_seq=8)
+        lg = m.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
+        res["greedy_prompt_logits"] = lg
+        toks = []
+        cur = int(np.argmax(lg[-1]))
+        for i in range(n_gen):
+            toks.append(cur)
+            lg = m.decode([cur], [len(prompt) + i], [[0]])
+            cur = int(np.argmax(lg[0]))
+        res["greedy_tokens"] = np.array(toks, np.int32)
+        res["greedy_last_logits"] = lg
+        m.close()
+        np.savez_compressed(os.path.join(HERE, stem + ".npz"), **res)
+        print(stem, os.path.getsize(path), "bytes; greedy:", toks[:8])
+
+
+if __name__ == "__main__":
+    assert O.ref() is not None, "needs oracle/_ref (make -C oracle ref)"
+    kernel_vectors()
+    model_vectors()

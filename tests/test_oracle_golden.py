@@ -1,0 +1,82 @@
+"""CPU tests (-m "not gpu"): the oracle against the committed golden vectors (generated from the real reference by
+tests/golden/make_golden.py).  These run everywhere, including where oracle/_ref does not exist."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from tests import scenarios as S
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+K = np.load(os.path.join(GOLD, "kernels.npz"))
+MODELS = ["tiny_llama_q4_k_m", "tiny_llama_q4_0", "tiny_llama_b_q4_k_m", "tiny_falcon_q4_0", "tiny_falcon40_q4_k_m"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K])
+def test_quant_golden(t):
+    o = O.Impl("oracle")
+    name = O.TYPE_NAMES[t]
+    blocks, act, qact, dots, deq = (K[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
+    k = act.shape[1]
+    for j in range(act.shape[0]):
+        assert np.array_equal(o.quantize_act(O.VEC_DOT_TYPE[t], act[j]), qact[j])          # bytes identical
+        for i in range(blocks.shape[0]):
+            assert np.float32(o.vec_dot(t, k, blocks[i], qact[j])).view(np.uint32) == dots[j, i].view(np.uint32)
+    for i in range(blocks.shape[0]):
+        assert np.array_equal(bits(o.dequantize(t, blocks[i], k)), bits(deq[i]))
+    # error bounds of tests/test-quantize-fns.cpp:16-20: |vec_dot - fp dot| / n < 0.02
+    for j in range(act.shape[0]):
+        for i in range(blocks.shape[0]):
+            assert abs(float(dots[j, i]) - float(np.dot(deq[i].astype(np.float64), act[j].astype(np.float64)))) / k < 0.02
+
+
+def test_elementwise_golden():
+    o = O.Impl("oracle")
+    assert np.array_equal(bits(o.rms_norm(K["norm_x"], 1e-5)), bits(K["rms_norm_y"]))
+    assert np.array_equal(bits(o.norm(K["norm_x"], 1e-5)), bits(K["layer_norm_y"]))
+    assert np.allclose(o.rope(K["rope_x"], K["rope_pos"], 0), K["rope_mode0"], rtol=0, atol=1e-6)
+    assert np.allclose(o.rope(K["rope_x"], K["rope_pos"], 2), K["rope_mode2"], rtol=0, atol=1e-6)
+    assert np.allclose(o.soft_max(K["softmax_x"]), K["softmax_y"], rtol=1e-6, atol=0)
+    assert np.allclose(o.silu(K["unary_x"]), K["silu_y"], rtol=1e-6, atol=0)
+    assert np.allclose(o.gelu(K["unary_x"]), K["gelu_y"], rtol=1e-6, atol=0)
+    lib = O.oracle()
+    assert np.array_equal(np.array([lib.o_fp32_to_fp16(float(v)) for v in K["f16_x"]], np.uint16), K["f16_bits"])
+
+
+def test_fp16_tables_formula_sample():
+    import ctypes as C
+    lib = O.oracle()
+    idx = K["table_idx"]
+    for name, gold in (("o_table_silu_f16", K["table_silu"]), ("o_table_gelu_f16", K["table_gelu"])):
+        tab = np.ctypeslib.as_array(C.cast(getattr(lib, name)(), C.POINTER(C.c_uint16)), shape=(65536,))
+        assert np.array_equal(tab[idx], gold)
+
+
+@pytest.mark.parametrize("stem", MODELS)
+def test_model_scenarios_golden(stem):
+    """whole-path oracle (cell placement + mask + forward) vs logits of the reference kernels, every decode of the
+    PipeInfer-style KV script; then the greedy continuation (the lossless-speculation ground truth)"""
+    g = np.load(os.path.join(GOLD, stem + ".npz"))
+    path = os.path.join(GOLD, stem + ".gguf")
+    m = O.OracleModel(path, n_ctx=128, max_seq=8)
+    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15}[stem]
+    outs = S.run_scenario(S.scenario_spec_like(m.n_vocab, seed=seed), m)
+    for i, lg in enumerate(outs):
+        assert np.allclose(lg, g[f"spec_like_{i}"], rtol=0, atol=1e-5), (stem, i, np.abs(lg - g[f"spec_like_{i}"]).max())
+    m.close()
+    prompt, n_gen = S.scenario_greedy(512, seed=seed)
+    m = O.OracleModel(path, n_ctx=128, max_seq=8)
+    lg = m.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
+    assert np.allclose(lg, g["greedy_prompt_logits"], rtol=0, atol=1e-5)
+    toks, cur = [], int(np.argmax(lg[-1]))
+    for i in range(n_gen):
+        toks.append(cur)
+        lg = m.decode([cur], [len(prompt) + i], [[0]])
+        cur = int(np.argmax(lg[0]))
+    assert toks == list(g["greedy_tokens"])
+    m.close()
