@@ -1,0 +1,86 @@
+/* pipeinfer_ops.h — C ABI of the MI355X hot-path operators (libpipeinfer_amd.so).
+ *
+ * One entry point per reference operator on the per-token path.  Every pointer named *_dev is a device
+ * (HBM) pointer; `stream` is a hipStream_t passed as void* (NULL = the default stream).  All functions return 0 on
+ * success and a negative value on error (pi_last_error() has the text).  There is NO CPU fallback: without a GPU the
+ * compute entry points fail loudly.
+ *
+ * Reference interface each one replaces (file:line under the reference tree):
+ *   pi_weight_upload        ggml tensor data as laid out by the GGUF loader             llama.cpp:1805-2134, ggml-quants.h:10-166
+ *   pi_op_get_rows          ggml_compute_forward_get_rows_q                             ggml.c:10161-10188
+ *   pi_op_norm              ggml_compute_forward_rms_norm_f32 / _norm_f32 + ggml_mul/add ggml.c:9028-9074, 8959-9008; llama.cpp:3579-3609
+ *   pi_op_quantize          quantize_row_q8_K / quantize_row_q8_0 (mul_mat INIT phase)   ggml-quants.c:2329-2364, 702-760; ggml.c:9493-9506
+ *   pi_op_mul_mat           ggml_compute_forward_mul_mat + ggml_vec_dot_{q4_0,q8_0,q4_K,q5_K,q6_K}_q8_*  ggml.c:9388-9597; ggml-quants.c:2426,3521,5216,5864,6594
+ *   pi_op_rope_kv_store     ggml_compute_forward_rope_f32 + llm_build_kv_store           ggml.c:11006-11168; llama.cpp:3546-3577
+ *   pi_op_attention         llm_build_kqv (KQ, scale, mask, soft_max, KQV)               llama.cpp:3698-3764; ggml.c:10551-10620, 1193-1228
+ *   pi_op_silu_mul/_gelu/_add  ggml_silu / ggml_gelu / ggml_mul / ggml_add               ggml.c:1418-1498, 7583, 6803
+ *   pi_op_topk              llama_sample_softmax / llama_sample_token_greedy             llama.cpp:7019-7046, 7496-7510
+ */
+#ifndef PIPEINFER_OPS_H
+#define PIPEINFER_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PI_API __attribute__((visibility("default")))
+
+/* ggml tensor type ids (ggml.h enum ggml_type) */
+enum pi_type { PI_F32 = 0, PI_F16 = 1, PI_Q4_0 = 2, PI_Q8_0 = 8, PI_Q4_K = 12, PI_Q5_K = 13, PI_Q6_K = 14, PI_Q8_K = 15 };
+
+typedef struct pi_weight pi_weight;    /* a weight matrix resident in HBM in the kernel-friendly layout */
+
+PI_API const char * pi_last_error(void);
+PI_API int     pi_device_count(void);
+PI_API int     pi_device_init(int device);            /* selects the GPU, builds + uploads the fp16 lookup tables */
+
+PI_API void *  pi_malloc(size_t bytes);
+PI_API void    pi_free(void * p_dev);
+PI_API int     pi_memcpy_h2d(void * dst_dev, const void * src, size_t bytes, void * stream);
+PI_API int     pi_memcpy_d2h(void * dst, const void * src_dev, size_t bytes, void * stream);
+PI_API int     pi_memset(void * dst_dev, int value, size_t bytes, void * stream);
+PI_API int     pi_stream_sync(void * stream);
+
+/* host_blocks: ne1 rows of ne0 elements in the GGUF/ggml block format of `type` (row-major, rows contiguous) */
+PI_API pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host_blocks, void * stream);
+PI_API void    pi_weight_free(pi_weight * w);
+PI_API size_t  pi_weight_nbytes(const pi_weight * w);  /* HBM bytes == ggml_nbytes of the tensor */
+PI_API int     pi_weight_type(const pi_weight * w);
+
+/* type the activations must be quantised to for this weight type (type_traits[].vec_dot_type, ggml.c:415-600) */
+PI_API int     pi_vec_dot_type(int weight_type);
+/* bytes of the device activation buffer for n_tok rows of k values quantised to vdt (PI_Q8_K or PI_Q8_0) */
+PI_API size_t  pi_q8_nbytes(int vdt, int64_t k, int n_tok);
+/* byte offsets of the planes inside that buffer: qs (int8 [n_tok][k]), d (f32 [n_tok][k/256] | f16 [n_tok][k/32]), bsums (int16 [n_tok][k/16], Q8_K only) */
+PI_API void    pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size_t * off_d, size_t * off_bsums);
+
+PI_API int pi_op_get_rows(const pi_weight * w, const int32_t * tokens_dev, int n_tok, float * out_dev, void * stream);
+PI_API int pi_op_norm(const float * x_dev, const float * w_dev, const float * b_dev, float * y_dev, int n, int n_tok, float eps, int rms, void * stream);
+PI_API int pi_op_quantize(int vdt, const float * x_dev, int64_t k, int n_tok, void * q8_dev, void * stream);
+/* out[t][row] = (residual ? residual[t][row] : 0) + W[row] . act[t]      out/residual: f32 [n_tok][ne1] */
+PI_API int pi_op_mul_mat(const pi_weight * w, const void * q8_dev, int n_tok, float * out_dev, const float * residual_dev, void * stream);
+
+/* RoPE tables as the reference iterates them: cos/sin [n_pos][head_dim/2] f32, built on the host (theta *= theta_scale) */
+PI_API void *  pi_rope_table_create(int n_pos, int head_dim, float freq_base, float freq_scale, int neox);
+PI_API void    pi_rope_table_free(void * table);
+/* q/k/v: f32 [n_tok][n_head*hd] / [n_tok][n_head_kv*hd]; writes roped Q as f16 [n_tok][n_head*hd]; K and V as f16 rows of
+ * the layer's cache at cells kv_head.. (k_cache/v_cache: [n_ctx][n_head_kv*hd] f16 each) */
+PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const float * v_dev, const int32_t * pos_dev, const void * rope_table,
+                               int neox, int head_dim, int n_head, int n_head_kv, int n_tok, int kv_head,
+                               uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, void * stream);
+/* mask_dev: uint32 bitmap [n_tok][ceil(n_kv/32)], bit i set <=> cell i visible to the token; out f32 [n_tok][n_head*hd] */
+PI_API int pi_op_attention(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
+                           int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, void * stream);
+PI_API int pi_op_silu_mul(const float * gate_dev, const float * up_dev, float * out_dev, int64_t n, void * stream);
+PI_API int pi_op_gelu(const float * x_dev, float * out_dev, int64_t n, void * stream);
+PI_API int pi_op_add(const float * a_dev, const float * b_dev, float * out_dev, int64_t n, void * stream);
+/* per token: ids/logits of the k largest (logit desc, id asc), max logit and sum_i expf(l_i - max) over the full vocab */
+PI_API int pi_op_topk(const float * logits_dev, int n_vocab, int n_tok, int k, int32_t * ids_dev, float * vals_dev, float * sumexp_dev, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,326 @@
+// Small per-token operators: embedding gather, norms, activation quantisers, RoPE + KV store, activations, top-k.
+// Every rounding point follows the reference CPU path (see include/pipeinfer_ops.h for file:line); this file is
+// compiled with -ffp-contract=off so a*b+c is never fused where the reference rounds twice.
+#include "ops_common.h"
+
+#include <cmath>
+#include <vector>
+
+// =================================================================================================================
+// get_rows: dequantise n_tok embedding rows (ggml.c:10161-10188; dequantize_row_* ggml-quants.c:1074,1168,1917,2117,2263)
+// =================================================================================================================
+static __device__ __forceinline__ void k4_scale_min(int j, const uint8_t * q, int & sc, int & m) {
+    if (j < 4) { sc = q[j] & 63; m = q[j + 4] & 63; }
+    else       { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+
+__global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, float * __restrict__ out) {
+    const int t = blockIdx.y;
+    const int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= w.ne0) return;
+    const int64_t row = tokens[t];
+    float y = 0.0f;
+    switch (w.type) {
+        case PI_F32: y = ((const float *) w.p0)[row * w.ne0 + e]; break;
+        case PI_F16: y = pi_h2f(((const uint16_t *) w.p0)[row * w.ne0 + e]); break;
+        case PI_Q4_0: {
+            const int64_t b = row * w.nb + (e >> 5); const int l = (int) (e & 31);
+            const uint8_t q = w.p0[b * 16 + (l & 15)];
+            const int x = (l < 16 ? (q & 0xF) : (q >> 4)) - 8;
+            y = x * pi_h2f(((const uint16_t *) w.p1)[b]);
+        } break;
+        case PI_Q8_0: {
+            const int64_t b = row * w.nb + (e >> 5);
+            y = (int) ((const int8_t *) w.p0)[b * 32 + (e & 31)] * pi_h2f(((const uint16_t *) w.p1)[b]);
+        } break;
+        case PI_Q4_K: case PI_Q5_K: {
+            const int ts = w.type == PI_Q4_K ? 144 : 176;
+            const uint8_t * blk = w.p0 + (row * w.nb + (e >> 8)) * ts;
+            const int ee = (int) (e & 255), s = ee >> 5, l = ee & 31, j = s >> 1, h = s & 1;
+            const float d = pi_h2f(blk[0] | (blk[1] << 8)), mn = pi_h2f(blk[2] | (blk[3] << 8));
+            int sc, m; k4_scale_min(s, blk + 4, sc, m);
+            const uint8_t * qs = blk + (w.type == PI_Q4_K ? 16 : 48);
+            int q = h ? qs[32 * j + l] >> 4 : qs[32 * j + l] & 0xF;
+            if (w.type == PI_Q5_K) q += ((blk[16 + l] >> (2 * j + h)) & 1) << 4;
+            const float d1 = d * sc, m1 = mn * m;
+            y = d1 * q - m1;
+        } break;
+        case PI_Q6_K: {
+            const int64_t b = row * w.nb + (e >> 8);
+            const int ee = (int) (e & 255), n = ee >> 7, g = (ee >> 5) & 3, l = ee & 31;
+            const uint8_t lo = w.p0[b * 128 + 64 * n + 32 * (g & 1) + l];
+            const int q6 = ((g & 2) ? lo >> 4 : lo & 0xF) | (((w.p1[b * 64 + 32 * n + l] >> (2 * g)) & 3) << 4);
+            const int8_t q = (int8_t) (q6 - 32);
+            const float d = pi_h2f(((const uint16_t *) w.p3)[b]);
+            y = d * (float) ((const int8_t *) w.p2)[b * 16 + (ee >> 4)] * (float) q;
+        } break;
+    }
+    out[(int64_t) t * w.ne0 + e] = y;
+}
+
+extern "C" int pi_op_get_rows(const pi_weight * w, const int32_t * tokens, int n_tok, float * out, void * stream) {
+    if (n_tok <= 0) return 0;
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) ((w->ne0 + 255) / 256), n_tok), dim3(256), 0, (hipStream_t) stream, *w, tokens, out);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================================
+// norms (ggml.c:9028-9074 rms, 8959-9008 layer norm) followed by ggml_mul(weight) and ggml_add(bias) (llama.cpp:3579-3609)
+// one 256-thread workgroup per token row; sums in double like the reference
+// =================================================================================================================
+static __device__ __forceinline__ double block_sum_f64(double v, double * sh) {
+    v = pi_wave_sum_f64(v);
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[wv] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; i++) s += sh[i];
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_norm(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b,
+                                              float * __restrict__ y, int n, float eps, int rms) {
+    __shared__ double sh[8];
+    const float * xr = x + (int64_t) blockIdx.x * n;
+    float * yr = y + (int64_t) blockIdx.x * n;
+    float mean = 0.0f;
+    double acc = 0.0;
+    if (rms) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i]; acc += (double) (v * v); }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double) xr[i];
+        mean = (float) (block_sum_f64(acc, sh) / n);
+        acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const float v = xr[i] - mean; acc += (double) (v * v); }
+    }
+    const float var = (float) (block_sum_f64(acc, sh) / n);
+    const float scale = 1.0f / sqrtf(var + eps);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = (xr[i] - mean) * scale;      // rms: mean == 0 exactly, x - 0 == x
+        if (w) v = v * w[i];
+        if (b) v = v + b[i];
+        yr[i] = v;
+    }
+}
+
+extern "C" int pi_op_norm(const float * x, const float * w, const float * b, float * y, int n, int n_tok, float eps, int rms, void * stream) {
+    if (n_tok <= 0) return 0;
+    hipLaunchKernelGGL(k_norm, dim3(n_tok), dim3(256), 0, (hipStream_t) stream, x, w, b, y, n, eps, rms);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================================
+// activation quantisers.  One wave per 256 values, 4 consecutive values per lane.
+//   Q8_K (ggml-quants.c:2329-2364): max = signed value of the FIRST largest |x|; iscale = -128/max; q = min(127, rne(iscale*x));
+//                                   d = 1/iscale (f32); bsums over groups of 16.
+//   Q8_0 (ggml-quants.c:702-760, AVX arm): d = amax/127 (stored f16); id = 127/amax; q = rne(x*id).
+// Output planes: see pi_q8_layout.
+// =================================================================================================================
+__global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums) {
+    const int t = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
+    const int64_t nb = k >> 8;
+    const float4 v = *(const float4 *) (x + (int64_t) t * k + (int64_t) blk * 256 + lane * 4);
+    const float xs[4] = { v.x, v.y, v.z, v.w };
+    float amax = 0.0f, mx = 0.0f; int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
+    }
+    int q[4] = { 0, 0, 0, 0 };
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.f / mx;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int r = __float2int_rn(iscale * xs[i]); q[i] = r < 127 ? r : 127; }
+        d = 1 / iscale;
+    }
+    const uint32_t packed = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
+    *(uint32_t *) (qs + (int64_t) t * k + (int64_t) blk * 256 + lane * 4) = packed;
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    if ((lane & 3) == 0) bsums[((int64_t) t * nb + blk) * 16 + (lane >> 2)] = (int16_t) s;
+    if (lane == 0) dd[(int64_t) t * nb + blk] = d;
+}
+
+__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, uint16_t * __restrict__ dd) {
+    const int t = blockIdx.y, lane = threadIdx.x;
+    const int64_t e0 = (int64_t) blockIdx.x * 256 + lane * 4;
+    if (e0 >= k) return;                    // k is a multiple of 32, so whole 8-lane groups drop out together
+    const float4 v = *(const float4 *) (x + (int64_t) t * k + e0);
+    const float xs[4] = { v.x, v.y, v.z, v.w };
+    float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.f;
+    const float id = amax != 0.0f ? 127.f / amax : 0.0f;
+    int q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { int r = __float2int_rn(xs[i] * id); q[i] = r > 127 ? 127 : (r < -128 ? -128 : r); }
+    *(uint32_t *) (qs + (int64_t) t * k + e0) = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
+    if ((lane & 7) == 0) dd[(int64_t) t * (k >> 5) + (e0 >> 5)] = pi_f2h(d);
+}
+
+extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, void * q8, void * stream) {
+    if (n_tok <= 0) return 0;
+    size_t oq, od, ob;
+    pi_q8_layout(vdt, k, n_tok, &oq, &od, &ob);
+    uint8_t * base = (uint8_t *) q8;
+    if (vdt == PI_Q8_K) {
+        if (k % 256) { pi_set_error("pi_op_quantize: Q8_K needs k %% 256 == 0 (k=%lld)", (long long) k); return -1; }
+        hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob));
+    } else if (vdt == PI_Q8_0) {
+        if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 needs k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
+        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((k + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (uint16_t *) (base + od));
+    } else { pi_set_error("pi_op_quantize: unsupported activation type %d", vdt); return -1; }
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================================
+// RoPE (ggml.c:11006-11168) + KV store as f16 (llama.cpp:3546-3577).  cos/sin come from a host-built table so that
+// theta (iterated `theta *= theta_scale` in fp32) and libm cosf/sinf are exactly the reference's.
+// =================================================================================================================
+struct pi_rope_table { float * cs; int n_pos; int head_dim; };   // cs: [n_pos][head_dim/2][2] = (cos, sin)
+
+extern "C" void * pi_rope_table_create(int n_pos, int head_dim, float freq_base, float freq_scale, int neox) {
+    std::vector<float> h((size_t) n_pos * head_dim);
+    const float theta_scale = powf(freq_base, -2.0f / head_dim);
+    for (int p = 0; p < n_pos; p++) {
+        float theta_base = (float) p;
+        if (neox) theta_base *= freq_scale;                           // ggml.c:11136
+        for (int i = 0; i < head_dim / 2; i++) {
+            const float theta = freq_scale * theta_base;              // rope_yarn with ext_factor == 0 (ggml.c:10979-10989)
+            h[((size_t) p * (head_dim / 2) + i) * 2 + 0] = cosf(theta) * 1.0f;
+            h[((size_t) p * (head_dim / 2) + i) * 2 + 1] = sinf(theta) * 1.0f;
+            theta_base *= theta_scale;
+        }
+    }
+    pi_rope_table * t = new pi_rope_table{ nullptr, n_pos, head_dim };
+    if (hipMalloc((void **) &t->cs, h.size() * 4) != hipSuccess || hipMemcpy(t->cs, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        pi_set_error("pi_rope_table_create: device allocation/copy failed"); delete t; return nullptr;
+    }
+    return t;
+}
+extern "C" void pi_rope_table_free(void * t_) { pi_rope_table * t = (pi_rope_table *) t_; if (t) { (void) hipFree(t->cs); delete t; } }
+
+// grid (n_tok, n_head + 2*n_head_kv) — one workgroup of hd/2 threads per head vector
+__global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict__ k, const float * __restrict__ v, const int32_t * __restrict__ pos,
+                          const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head,
+                          uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc) {
+    const int t = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;           // i: pair index
+    const int n_embd = n_head * hd, n_gqa = n_head_kv * hd;
+    if (hh >= n_head + n_head_kv) {                                         // V: plain f32 -> f16 copy into the cache row
+        const int h = hh - n_head - n_head_kv;
+        const float * src = v + (int64_t) t * n_gqa + h * hd;
+        uint16_t * dst = vc + (int64_t) (kv_head + t) * n_gqa + h * hd;
+        dst[2 * i] = pi_f2h(src[2 * i]); dst[2 * i + 1] = pi_f2h(src[2 * i + 1]);
+        return;
+    }
+    const bool is_q = hh < n_head;
+    const int h = is_q ? hh : hh - n_head;
+    const float * src = is_q ? q + (int64_t) t * n_embd + h * hd : k + (int64_t) t * n_gqa + h * hd;
+    uint16_t * dst = is_q ? q16 + (int64_t) t * n_embd + h * hd : kc + (int64_t) (kv_head + t) * n_gqa + h * hd;
+    const float2 c = *(const float2 *) (cs + ((int64_t) pos[t] * (hd / 2) + i) * 2);
+    const int i0 = neox ? i : 2 * i, i1 = neox ? i + hd / 2 : 2 * i + 1;
+    const float x0 = src[i0], x1 = src[i1];
+    dst[i0] = pi_f2h(x0 * c.x - x1 * c.y);
+    dst[i1] = pi_f2h(x0 * c.y + x1 * c.x);
+}
+
+extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float * v, const int32_t * pos, const void * table_, int neox,
+                                   int hd, int n_head, int n_head_kv, int n_tok, int kv_head, uint16_t * q16, uint16_t * kc, uint16_t * vc, void * stream) {
+    if (n_tok <= 0) return 0;
+    const pi_rope_table * t = (const pi_rope_table *) table_;
+    if (t->head_dim != hd) { pi_set_error("pi_op_rope_kv_store: table head_dim %d != %d", t->head_dim, hd); return -1; }
+    hipLaunchKernelGGL(k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
+                       q, k, v, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
+// =================================================================================================================
+// activations through the fp16 tables (ggml.c:1433-1441, 1490-1498), ggml_mul, ggml_add
+// =================================================================================================================
+__global__ void k_silu_mul(const float * __restrict__ g, const float * __restrict__ u, float * __restrict__ o, int64_t n, const uint16_t * __restrict__ tab) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = pi_h2f(tab[pi_f2h(g[i])]) * u[i];
+}
+__global__ void k_gelu(const float * __restrict__ x, float * __restrict__ o, int64_t n, const uint16_t * __restrict__ tab) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = pi_h2f(tab[pi_f2h(x[i])]);
+}
+__global__ void k_add(const float * __restrict__ a, const float * __restrict__ b, float * __restrict__ o, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+extern "C" int pi_op_silu_mul(const float * g, const float * u, float * o, int64_t n, void * stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, g, u, o, n, pi_get_tables().silu_f16);
+    PI_CHECK_LAUNCH(); return 0;
+}
+extern "C" int pi_op_gelu(const float * x, float * o, int64_t n, void * stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gelu, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, o, n, pi_get_tables().gelu_f16);
+    PI_CHECK_LAUNCH(); return 0;
+}
+extern "C" int pi_op_add(const float * a, const float * b, float * o, int64_t n, void * stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_add, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a, b, o, n);
+    PI_CHECK_LAUNCH(); return 0;
+}
+
+// =================================================================================================================
+// top-k per token over the vocabulary: ordering (logit desc, id asc) == std::max_element's first-max rule for k = 1
+// (llama.cpp:7496-7510) and a stable version of the std::sort in llama_sample_softmax (llama.cpp:7019-7046);
+// plus max and sum_i expf(l_i - max) so p_j = expf(l_j - max) / sum on the host.
+// =================================================================================================================
+__global__ void __launch_bounds__(1024) k_topk(const float * __restrict__ logits, int n_vocab, int k, int32_t * __restrict__ ids, float * __restrict__ vals, float * __restrict__ sumexp) {
+    __shared__ float sv[16]; __shared__ int si[16]; __shared__ float sb[2]; __shared__ int sbi;
+    const float * l = logits + (int64_t) blockIdx.x * n_vocab;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float prev_v = INFINITY; int prev_i = -1;
+    for (int r = 0; r < k; r++) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < n_vocab; i += 1024) {
+            const float v = l[i];
+            const bool after = v < prev_v || (v == prev_v && i > prev_i);       // strictly behind the previous winner
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { sv[wv] = bv; si[wv] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; w++) if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+            sb[0] = bv; sbi = bi;
+            ids[blockIdx.x * k + r] = bi; vals[blockIdx.x * k + r] = bv;
+        }
+        __syncthreads();
+        prev_v = sb[0]; prev_i = sbi;
+        if (r == 0) sb[1] = prev_v;
+    }
+    __syncthreads();
+    const float mx = sb[1];
+    float s = 0.0f;
+    for (int i = tid; i < n_vocab; i += 1024) s += expf(l[i] - mx);
+    s = pi_lanes_sum<64>(s);
+    __syncthreads();
+    if (lane == 0) sv[wv] = s;
+    __syncthreads();
+    if (tid == 0) { float tot = 0.0f; for (int w = 0; w < 16; w++) tot += sv[w]; sumexp[blockIdx.x] = tot; }
+}
+
+extern "C" int pi_op_topk(const float * logits, int n_vocab, int n_tok, int k, int32_t * ids, float * vals, float * sumexp, void * stream) {
+    if (n_tok <= 0) return 0;
+    hipLaunchKernelGGL(k_topk, dim3(n_tok), dim3(1024), 0, (hipStream_t) stream, logits, n_vocab, k, ids, vals, sumexp);
+    PI_CHECK_LAUNCH(); return 0;
+}

@@ -1,0 +1,198 @@
+// Device runtime glue: error text, fp16 tables, memory helpers, weight upload + one-time re-layout.
+#include "ops_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void pi_set_error(const char * fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char * pi_last_error(void) { return g_err; }
+
+extern "C" int pi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- fp16 lookup tables (ggml.c:2190-2201; formulas ggml.c:1418-1421, 1479-1481) ---------------------------------
+// Built on the host with the host libm so that they are the very tables the reference CPU path uses on this machine.
+static uint16_t host_f32_to_f16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t) ((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t) (sign | 0x7e00u | ((x >> 13) & 0x3ffu));
+    if (x >= 0x47800000u) return (uint16_t) (sign | 0x7c00u);
+    const uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u;
+    if (e < 113) {
+        if (e < 102) return sign;
+        const int sh = 126 - (int) e;
+        uint32_t q = m >> sh;
+        const uint32_t rem = m & ((1u << sh) - 1), half = 1u << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) q++;
+        return (uint16_t) (sign | q);
+    }
+    uint32_t h = (e - 112) << 10 | (m & 0x7fffffu) >> 13;
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (uint16_t) (sign | h);
+}
+
+static float host_f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000u) << 16, e = (h >> 10) & 0x1f;
+    uint32_t m = h & 0x3ffu, bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else { int s = -1; do { s++; m <<= 1; } while (!(m & 0x400u)); bits = sign | (uint32_t) (112 - s) << 23 | (m & 0x3ffu) << 13; }
+    } else if (e == 31) bits = sign | 0x7f800000u | m << 13;
+    else bits = sign | (e + 112) << 23 | m << 13;
+    float f; memcpy(&f, &bits, 4);
+    return f;
+}
+
+static pi_tables g_tables = { nullptr, nullptr, nullptr };
+static int g_device = -1;
+
+const pi_tables & pi_get_tables() { return g_tables; }
+
+extern "C" int pi_device_init(int device) {
+    if (pi_device_count() <= 0) { pi_set_error("pi_device_init: no HIP device visible (the MI355X path has no CPU fallback)"); return -1; }
+    PI_CHECK_HIP(hipSetDevice(device));
+    if (g_tables.exp_f16 && g_device == device) return 0;
+    g_device = device;
+    std::vector<uint16_t> t(3u << 16);
+    for (int i = 0; i < (1 << 16); i++) {
+        const float f = host_f16_to_f32((uint16_t) i);
+        t[i]             = host_f32_to_f16(expf(f));
+        t[(1 << 16) + i] = host_f32_to_f16(f / (1.0f + expf(-f)));
+        const float inner = 0.79788456080286535587989211986876f * f * (1.0f + 0.044715f * f * f);
+        t[(2 << 16) + i] = host_f32_to_f16(0.5f * f * (1.0f + tanhf(inner)));
+    }
+    uint16_t * dev = nullptr;
+    PI_CHECK_HIP(hipMalloc((void **) &dev, t.size() * 2));
+    PI_CHECK_HIP(hipMemcpy(dev, t.data(), t.size() * 2, hipMemcpyHostToDevice));
+    g_tables.exp_f16 = dev; g_tables.silu_f16 = dev + (1 << 16); g_tables.gelu_f16 = dev + (2 << 16);
+    return 0;
+}
+
+// ---- memory helpers ---------------------------------------------------------------------------------------------
+extern "C" void * pi_malloc(size_t bytes) {
+    void * p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { pi_set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void pi_free(void * p) { if (p) (void) hipFree(p); }
+extern "C" int pi_memcpy_h2d(void * dst, const void * src, size_t n, void * stream) {
+    PI_CHECK_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t) stream));
+    return 0;
+}
+extern "C" int pi_memcpy_d2h(void * dst, const void * src, size_t n, void * stream) {
+    PI_CHECK_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t) stream));
+    PI_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream));
+    return 0;
+}
+extern "C" int pi_memset(void * dst, int v, size_t n, void * stream) { PI_CHECK_HIP(hipMemsetAsync(dst, v, n, (hipStream_t) stream)); return 0; }
+extern "C" int pi_stream_sync(void * stream) { PI_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream)); return 0; }
+
+// ---- weight upload + re-layout ------------------------------------------------------------------------------------
+// one thread per block: split the GGUF block into the planes (bytes are only moved, never changed)
+__global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * ql, uint8_t * qh, uint8_t * sc, uint16_t * d, int64_t nblocks) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint8_t * b = src + i * 210;
+    for (int k = 0; k < 128; k++) ql[i * 128 + k] = b[k];
+    for (int k = 0; k < 64; k++)  qh[i * 64 + k]  = b[128 + k];
+    for (int k = 0; k < 16; k++)  sc[i * 16 + k]  = b[192 + k];
+    d[i] = (uint16_t) (b[208] | (b[209] << 8));
+}
+__global__ void k_repack_q4_0(const uint8_t * __restrict__ src, uint8_t * qs, uint16_t * d, int64_t nblocks) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint8_t * b = src + i * 18;
+    d[i] = (uint16_t) (b[0] | (b[1] << 8));
+    for (int k = 0; k < 16; k++) qs[i * 16 + k] = b[2 + k];
+}
+__global__ void k_repack_q8_0(const uint8_t * __restrict__ src, uint8_t * qs, uint16_t * d, int64_t nblocks) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint8_t * b = src + i * 34;
+    d[i] = (uint16_t) (b[0] | (b[1] << 8));
+    for (int k = 0; k < 32; k++) qs[i * 32 + k] = b[2 + k];
+}
+
+extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host, void * stream_) {
+    hipStream_t stream = (hipStream_t) stream_;
+    const int blck = pi_type_blck(type), tsz = pi_type_size(type);
+    if (!tsz || type == PI_Q8_K) { pi_set_error("pi_weight_upload: unsupported tensor type %d", type); return nullptr; }
+    if (ne0 % blck) { pi_set_error("pi_weight_upload: ne0=%lld not a multiple of the block size %d", (long long) ne0, blck); return nullptr; }
+    pi_weight * w = new pi_weight();
+    w->type = type; w->ne0 = ne0; w->ne1 = ne1; w->nb = ne0 / blck;
+    const int64_t nblocks = w->nb * ne1;
+    w->nbytes = (size_t) nblocks * tsz;
+    if (hipMalloc(&w->base, w->nbytes + 256) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", w->nbytes); delete w; return nullptr; }
+    uint8_t * base = (uint8_t *) w->base;
+    w->p0 = base; w->p1 = w->p2 = w->p3 = nullptr;
+    const bool planar = type == PI_Q6_K || type == PI_Q4_0 || type == PI_Q8_0;
+    if (!planar) {
+        if (hipMemcpyAsync(base, host, w->nbytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            pi_set_error("pi_weight_upload: H2D copy failed"); (void) hipFree(w->base); delete w; return nullptr;
+        }
+        return w;
+    }
+    uint8_t * staging = nullptr;
+    if (hipMalloc((void **) &staging, w->nbytes) != hipSuccess) { pi_set_error("pi_weight_upload: staging hipMalloc failed"); (void) hipFree(w->base); delete w; return nullptr; }
+    (void) hipMemcpyAsync(staging, host, w->nbytes, hipMemcpyHostToDevice, stream);
+    const int threads = 256;
+    const unsigned grid = (unsigned) ((nblocks + threads - 1) / threads);
+    if (type == PI_Q6_K) {
+        w->p1 = base + nblocks * 128; w->p2 = w->p1 + nblocks * 64; w->p3 = w->p2 + nblocks * 16;
+        hipLaunchKernelGGL(k_repack_q6_K, dim3(grid), dim3(threads), 0, stream, staging, base, (uint8_t *) w->p1, (uint8_t *) w->p2, (uint16_t *) w->p3, nblocks);
+    } else if (type == PI_Q4_0) {
+        w->p1 = base + nblocks * 16;
+        hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, base, (uint16_t *) w->p1, nblocks);
+    } else {
+        w->p1 = base + nblocks * 32;
+        hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, base, (uint16_t *) w->p1, nblocks);
+    }
+    const hipError_t e = hipStreamSynchronize(stream);
+    (void) hipFree(staging);
+    if (e != hipSuccess) { pi_set_error("pi_weight_upload: repack failed: %s", hipGetErrorString(e)); (void) hipFree(w->base); delete w; return nullptr; }
+    return w;
+}
+
+extern "C" void pi_weight_free(pi_weight * w) { if (w) { (void) hipFree(w->base); delete w; } }
+extern "C" size_t pi_weight_nbytes(const pi_weight * w) { return w->nbytes; }
+extern "C" int pi_weight_type(const pi_weight * w) { return w->type; }
+
+extern "C" int pi_vec_dot_type(int t) {
+    switch (t) {
+        case PI_Q4_0: case PI_Q8_0: return PI_Q8_0;
+        case PI_Q4_K: case PI_Q5_K: case PI_Q6_K: return PI_Q8_K;
+        case PI_F16: return PI_F16; case PI_F32: return PI_F32;
+    }
+    return -1;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t) 255; }
+
+extern "C" void pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size_t * off_d, size_t * off_bsums) {
+    const size_t qs = align256((size_t) n_tok * k);
+    const size_t d  = vdt == PI_Q8_K ? align256((size_t) n_tok * (k / 256) * 4) : align256((size_t) n_tok * (k / 32) * 2);
+    if (off_qs) *off_qs = 0;
+    if (off_d) *off_d = qs;
+    if (off_bsums) *off_bsums = qs + d;
+}
+
+extern "C" size_t pi_q8_nbytes(int vdt, int64_t k, int n_tok) {
+    size_t oq, od, ob;
+    pi_q8_layout(vdt, k, n_tok, &oq, &od, &ob);
+    return ob + (vdt == PI_Q8_K ? align256((size_t) n_tok * (k / 16) * 2) : 0);
+}

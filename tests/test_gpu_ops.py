@@ -1,0 +1,298 @@
+"""-m gpu: every hot-path HIP operator, called through the C ABI (include/pipeinfer_ops.h), against the oracle on the same
+seeded inputs and against the committed golden vectors.  Integer/byte results must be identical; fp32 results within the
+tolerance written at each assert (BASELINE.json: logits within 1e-3; the per-operator bounds here are far tighter)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from pipeinfer_amd.tools import gguf as G
+from pipeinfer_amd.tools import synth
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+QTYPES = [O.Q4_0, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from tests import gpu_util as U
+    lib = U.init()
+    return lib, U
+
+
+def signal(n, seed):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n, dtype=np.float32)
+    return (0.1 + 2.0 * np.cos(i + seed)).astype(np.float32) + rng.standard_normal(n).astype(np.float32) * 0.5
+
+
+def upload_weight(lib, t, rows, k, blocks):
+    blocks = np.ascontiguousarray(blocks)
+    w = lib.pi_weight_upload(t, k, rows, blocks.ctypes.data_as(C.c_void_p), None)
+    assert w, lib.pi_last_error()
+    assert lib.pi_weight_nbytes(w) == rows * O.row_size(t, k)          # HBM bytes == ggml_nbytes (roofline accounting)
+    return w
+
+
+def gpu_quantize(lib, U, vdt, x):
+    n_tok, k = x.shape
+    xd = U.Dev(x.astype(np.float32))
+    q8 = U.Dev(nbytes=lib.pi_q8_nbytes(vdt, k, n_tok))
+    from pipeinfer_amd import lib as L
+    L.check(lib.pi_op_quantize(vdt, xd.ptr, k, n_tok, q8.ptr, None), "quantize")
+    return q8
+
+
+def gpu_mul_mat(lib, U, t, w, k, rows, act, residual=None):
+    from pipeinfer_amd import lib as L
+    n_tok = act.shape[0]
+    q8 = gpu_quantize(lib, U, O.VEC_DOT_TYPE[t], act)
+    out = U.Dev(nbytes=4 * n_tok * rows)
+    res = U.Dev(residual.astype(np.float32)) if residual is not None else None
+    L.check(lib.pi_op_mul_mat(w, q8.ptr, n_tok, out.ptr, res.ptr if res else None, None), "mul_mat")
+    return out.get(np.float32, (n_tok, rows))
+
+
+@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0])
+def test_activation_quantiser_bytes_identical(gpu, vdt):
+    lib, U = gpu
+    o = O.Impl("oracle")
+    for k in (256, 1024, 4096, 11008 // 256 * 256) + ((4544, 18176) if vdt == O.Q8_0 else ()):
+        x = np.stack([signal(k, s) * (0.01 if s % 2 else 3.0) for s in range(5)])
+        x[4, :256] = 0.0                              # all-zero block
+        x[3, 10] = 2.5; x[3, 11] = -2.5               # equal |x| with opposite signs: first one fixes the sign of the scale
+        q8 = gpu_quantize(lib, U, vdt, x)
+        got = U.q8_as_ref_blocks(vdt, *U.q8_planes(lib, vdt, k, 5, q8))
+        for t in range(5):
+            assert np.array_equal(got[t], o.quantize_act(vdt, x[t])), (k, t)
+
+
+@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0])
+def test_activation_quantiser_golden(gpu, vdt):
+    lib, U = gpu
+    K = np.load(os.path.join(GOLD, "kernels.npz"))
+    for t in ([O.Q4_K, O.Q5_K, O.Q6_K] if vdt == O.Q8_K else [O.Q4_0, O.Q8_0]):
+        name = O.TYPE_NAMES[t]
+        act, qact = K[f"{name}_act"], K[f"{name}_qact"]
+        q8 = gpu_quantize(lib, U, vdt, act)
+        got = U.q8_as_ref_blocks(vdt, *U.q8_planes(lib, vdt, act.shape[1], act.shape[0], q8))
+        assert np.array_equal(got, qact)
+
+
+@pytest.mark.parametrize("t", QTYPES)
+def test_mul_mat_golden_blocks(gpu, t):
+    """weights quantised by the reference's own quantiser + reference vec_dot results (tests/golden/kernels.npz)"""
+    lib, U = gpu
+    K = np.load(os.path.join(GOLD, "kernels.npz"))
+    name = O.TYPE_NAMES[t]
+    blocks, act, dots = K[f"{name}_blocks"], K[f"{name}_act"], K[f"{name}_dots"]
+    rows, k = blocks.shape[0], act.shape[1]
+    w = upload_weight(lib, t, rows, k, blocks)
+    got = gpu_mul_mat(lib, U, t, w, k, rows, act)
+    scale = np.abs(dots).max()
+    assert np.abs(got - dots).max() <= 1e-5 * scale, np.abs(got - dots).max() / scale
+    lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("t", QTYPES)
+@pytest.mark.parametrize("k,rows", [(256, 37), (768, 64), (1024, 100), (2048, 256), (4096, 515), (11008, 96), (28672, 40)])
+@pytest.mark.parametrize("n_tok", [1, 2, 3, 5, 8, 11])
+def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
+    if (k, rows, n_tok) not in {(256, 37, 3), (768, 64, 1), (1024, 100, 8), (2048, 256, 2), (4096, 515, 1), (4096, 515, 5), (11008, 96, 11), (28672, 40, 8), (11008, 96, 1)}:
+        pytest.skip("sampled grid")
+    lib, U = gpu
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(k + rows + n_tok)
+    blocks = synth.random_blocks(t, rows * k, rng, 0.05).reshape(rows, -1)
+    act = np.stack([signal(k, s + n_tok) for s in range(n_tok)])
+    res = rng.standard_normal((n_tok, rows)).astype(np.float32)
+    w = upload_weight(lib, t, rows, k, blocks)
+    want = o.mul_mat(t, blocks, k, rows, act)
+    got = gpu_mul_mat(lib, U, t, w, k, rows, act)
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max() / scale
+    assert err <= 2e-5, err                                    # fp32 summation-order spread only
+    got_r = gpu_mul_mat(lib, U, t, w, k, rows, act, residual=res)
+    assert np.abs(got_r - (res + want)).max() / scale <= 2e-5
+    lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("t", QTYPES)
+def test_mul_mat_integer_sums_exact(gpu, t):
+    """Scales forced to powers of two and integer activations small enough that every partial sum is an integer < 2^24:
+    any fp32 summation order then gives the same bits, so equality with the oracle proves the int8 dot products exact."""
+    lib, U = gpu
+    o = O.Impl("oracle")
+    k, rows, n_tok = 1024, 64, 4
+    rng = np.random.default_rng(99 + t)
+    blocks = synth.random_blocks(t, rows * k, rng, 0.05).reshape(rows * (k // O.BLCK[t]), O.TSIZE[t]).copy()
+    one = np.array([0x3C00], np.uint16).view(np.uint8)          # f16 1.0
+    if t in (O.Q4_0, O.Q8_0):
+        blocks[:, 0:2] = one
+    elif t in (O.Q4_K, O.Q5_K):
+        blocks[:, 0:2] = one; blocks[:, 2:4] = one
+    else:
+        blocks[:, 208:210] = one
+        blocks[:, 192:208] = (blocks[:, 192:208].view(np.int8) // 16).view(np.uint8)     # |scale| <= 8
+    blocks = blocks.reshape(rows, -1)
+    act = rng.integers(-8, 9, (n_tok, k)).astype(np.float32)
+    blk = O.BLCK[O.VEC_DOT_TYPE[t]]
+    act.reshape(n_tok, -1, blk)[:, :, 0] = -128.0 if O.VEC_DOT_TYPE[t] == O.Q8_K else -127.0     # pins d_y = 1 exactly
+    w = upload_weight(lib, t, rows, k, blocks)
+    want = o.mul_mat(t, blocks, k, rows, act)
+    got = gpu_mul_mat(lib, U, t, w, k, rows, act)
+    assert np.abs(want).max() < 2 ** 24 and np.all(want == np.rint(want))
+    assert np.array_equal(got, want)
+    lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("t", QTYPES + [O.F32, O.F16])
+def test_get_rows_exact(gpu, t):
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    k, rows = 1024, 50
+    rng = np.random.default_rng(t)
+    if t == O.F32:
+        blocks = rng.standard_normal((rows, k)).astype(np.float32)
+    elif t == O.F16:
+        blocks = O.f32_to_f16_bits(rng.standard_normal((rows, k)))
+    else:
+        blocks = synth.random_blocks(t, rows * k, rng, 0.05).reshape(rows, -1)
+    w = upload_weight(lib, t, rows, k, blocks)
+    ids = np.array([0, 49, 7, 7, 13], np.int32)
+    out = U.Dev(nbytes=4 * ids.size * k)
+    L.check(lib.pi_op_get_rows(w, U.Dev(ids).ptr, ids.size, out.ptr, None))
+    assert np.array_equal(out.get(np.float32, (ids.size, k)).view(np.uint32), o.get_rows(t, blocks, k, rows, ids).view(np.uint32))
+    lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("n", [256, 2048, 4096, 4544, 8192])
+def test_norms(gpu, n):
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    x = np.stack([signal(n, s) for s in range(3)])
+    rng = np.random.default_rng(n)
+    w = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    xd, wd, bd = U.Dev(x), U.Dev(w), U.Dev(b)
+    y = U.Dev(nbytes=x.nbytes)
+    L.check(lib.pi_op_norm(xd.ptr, wd.ptr, None, y.ptr, n, 3, 1e-5, 1, None))
+    want = o.rms_norm(x, 1e-5) * w
+    got = y.get(np.float32, x.shape)
+    assert np.abs(got - want).max() <= 2e-7 * np.abs(want).max() + 1e-12          # double-sum order: at most 1 ulp of the scale
+    L.check(lib.pi_op_norm(xd.ptr, wd.ptr, bd.ptr, y.ptr, n, 3, 1e-5, 0, None))
+    want = o.norm(x, 1e-5) * w + b
+    got = y.get(np.float32, x.shape)
+    assert np.abs(got - want).max() <= 4e-7 * np.abs(want).max() + 1e-12
+
+
+@pytest.mark.parametrize("neox,hd,n_head,n_head_kv", [(0, 128, 8, 8), (0, 64, 32, 4), (1, 64, 71, 1), (1, 64, 16, 2)])
+def test_rope_kv_store_exact(gpu, neox, hd, n_head, n_head_kv):
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(hd + n_head)
+    n_tok, n_ctx, kv_head = 5, 64, 20
+    pos = np.array([0, 1, 9, 300, 1023], np.int32)
+    q = rng.standard_normal((n_tok, n_head, hd)).astype(np.float32)
+    k = rng.standard_normal((n_tok, n_head_kv, hd)).astype(np.float32)
+    v = rng.standard_normal((n_tok, n_head_kv * hd)).astype(np.float32)
+    table = lib.pi_rope_table_create(1024, hd, 10000.0, 1.0, neox)
+    assert table
+    g = n_head_kv * hd
+    q16, kc, vc = U.Dev(nbytes=2 * q.size), U.Dev(nbytes=2 * n_ctx * g), U.Dev(nbytes=2 * n_ctx * g)
+    L.check(lib.pi_op_rope_kv_store(U.Dev(q).ptr, U.Dev(k).ptr, U.Dev(v).ptr, U.Dev(pos).ptr, table, neox, hd, n_head, n_head_kv, n_tok, kv_head,
+                                    q16.ptr, kc.ptr, vc.ptr, None))
+    mode = 2 if neox else 0
+    assert np.array_equal(q16.get(np.uint16, q.shape), O.f32_to_f16_bits(o.rope(q, pos, mode)))
+    kc_h = kc.get(np.uint16, (n_ctx, g))
+    assert np.array_equal(kc_h[kv_head:kv_head + n_tok].reshape(k.shape), O.f32_to_f16_bits(o.rope(k, pos, mode)))
+    assert not kc_h[:kv_head].any() and not kc_h[kv_head + n_tok:].any()
+    assert np.array_equal(vc.get(np.uint16, (n_ctx, g))[kv_head:kv_head + n_tok], O.f32_to_f16_bits(v))
+    lib.pi_rope_table_free(table)
+
+
+def mask_bits(mask):
+    """additive 0/-inf [n_tok, n_kv] -> uint32 bitmap"""
+    n_tok, n_kv = mask.shape
+    words = (n_kv + 31) // 32
+    bits = np.zeros((n_tok, words * 32), np.uint8)
+    bits[:, :n_kv] = (mask == 0)
+    return np.packbits(bits.reshape(n_tok, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(n_tok, words)
+
+
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok", [(128, 8, 8, 45, 3), (64, 32, 4, 70, 2), (64, 71, 1, 33, 1), (128, 64, 8, 300, 9), (64, 8, 2, 1024, 4)])
+def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(hd + n_kv)
+    n_ctx, kv_head = n_kv + 8, n_kv - n_tok
+    g = hd * n_head_kv
+    k_rows = O.f32_to_f16_bits(rng.standard_normal((n_ctx, g)))            # [cell][n_embd_gqa]
+    v_rows = O.f32_to_f16_bits(rng.standard_normal((n_ctx, g)))
+    q = rng.standard_normal((n_tok, n_head, hd)).astype(np.float32)
+    mask = np.zeros((n_tok, n_kv), np.float32)
+    for t in range(n_tok):
+        mask[t, kv_head + t + 1:] = -np.inf                                   # causal among the new tokens
+    mask[:, 5:9] = -np.inf                                                    # a hole (cells of another sequence)
+    # oracle: reference layouts (V transposed), no new tokens written (n_tok rows already in the cache)
+    kc_o, vc_o = k_rows.copy(), np.ascontiguousarray(v_rows.T)
+    kcur = k_rows[kv_head:kv_head + n_tok].view(np.float16).astype(np.float32).reshape(n_tok, n_head_kv, hd)
+    vcur = v_rows[kv_head:kv_head + n_tok].view(np.float16).astype(np.float32)
+    want = o.attention(kc_o, vc_o, n_ctx, q, kcur, vcur, mask, hd, n_head, n_head_kv, kv_head, n_kv)
+    q16 = O.f32_to_f16_bits(q)
+    out = U.Dev(nbytes=4 * n_tok * n_head * hd)
+    L.check(lib.pi_op_attention(U.Dev(q16).ptr, U.Dev(k_rows).ptr, U.Dev(v_rows).ptr, U.Dev(mask_bits(mask)).ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None))
+    got = out.get(np.float32, want.shape)
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+
+
+def test_elementwise_exact(gpu):
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    K = np.load(os.path.join(GOLD, "kernels.npz"))
+    x = K["unary_x"]
+    u = np.random.default_rng(3).standard_normal(x.size).astype(np.float32)
+    xd, ud, out = U.Dev(x), U.Dev(u), U.Dev(nbytes=x.nbytes)
+    L.check(lib.pi_op_silu_mul(xd.ptr, ud.ptr, out.ptr, x.size, None))
+    assert np.array_equal(out.get(np.float32).view(np.uint32), (K["silu_y"] * u).view(np.uint32))
+    L.check(lib.pi_op_gelu(xd.ptr, out.ptr, x.size, None))
+    assert np.array_equal(out.get(np.float32).view(np.uint32), K["gelu_y"].view(np.uint32))
+    L.check(lib.pi_op_add(xd.ptr, ud.ptr, out.ptr, x.size, None))
+    assert np.array_equal(out.get(np.float32), x + u)
+    # every finite fp16 input of the tables
+    allx = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    allx = allx[np.isfinite(allx)]
+    ad, od = U.Dev(allx), U.Dev(nbytes=allx.nbytes)
+    L.check(lib.pi_op_gelu(ad.ptr, od.ptr, allx.size, None))
+    assert np.array_equal(od.get(np.float32).view(np.uint32), o.gelu(allx).view(np.uint32))
+    L.check(lib.pi_op_silu_mul(ad.ptr, U.Dev(np.ones_like(allx)).ptr, od.ptr, allx.size, None))
+    assert np.array_equal(od.get(np.float32).view(np.uint32), o.silu(allx).view(np.uint32))
+
+
+@pytest.mark.parametrize("n_vocab", [512, 32000, 65024])
+def test_topk(gpu, n_vocab):
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    rng = np.random.default_rng(n_vocab)
+    logits = (rng.standard_normal((3, n_vocab)) * 3).astype(np.float32)
+    logits[1, 100] = logits[1, 7] = logits[1].max() + 1.0            # tie for the maximum: lower id first
+    logits[2, 5] = -np.inf
+    ids, vals, se = U.Dev(nbytes=4 * 3 * 8), U.Dev(nbytes=4 * 3 * 8), U.Dev(nbytes=4 * 3)
+    L.check(lib.pi_op_topk(U.Dev(logits).ptr, n_vocab, 3, 8, ids.ptr, vals.ptr, se.ptr, None))
+    gi, gv, gs = ids.get(np.int32, (3, 8)), vals.get(np.float32, (3, 8)), se.get(np.float32)
+    for t in range(3):
+        order = np.lexsort((np.arange(n_vocab), -logits[t]))[:8]
+        assert list(gi[t]) == list(order)
+        assert np.array_equal(gv[t], logits[t][order])
+        want = np.exp((logits[t] - logits[t].max()).astype(np.float64)).sum()
+        assert abs(gs[t] - want) / want < 1e-5
+    assert gi[1, 0] == 7 and gi[1, 1] == 100
