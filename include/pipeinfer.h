@@ -1,0 +1,87 @@
+/* pipeinfer.h — extensions beside the llama.h boundary: closed-form KV range operations, the PipeInfer driver as a
+ * library call, engine statistics for the roofline report, and a stand-alone handle on the host KV-cell table so its
+ * semantics can be tested without a GPU.
+ */
+#ifndef PIPEINFER_H
+#define PIPEINFER_H
+
+#include "llama.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- closed forms of the loops speculative.cpp runs over every sequence id (speculative.cpp:603-612, 1252-1268).
+ *      Each equals issuing the single llama_kv_cache_seq_* calls in order (same cells, used count and head). ---- */
+LLAMA_API void pipeinfer_kv_cache_seq_rm_range(struct llama_context * ctx, llama_seq_id first, llama_seq_id last, llama_pos p0, llama_pos p1);
+LLAMA_API void pipeinfer_kv_cache_seq_cp_range(struct llama_context * ctx, llama_seq_id src, llama_seq_id first, llama_seq_id last, llama_pos p0, llama_pos p1);
+LLAMA_API void pipeinfer_kv_cache_seq_rm_cp_range(struct llama_context * ctx, llama_seq_id src, llama_seq_id first, llama_seq_id last, llama_pos p0, llama_pos p1);
+
+/* uploads this process's stage weights and allocates KV cache + scratch now (otherwise done by the first decode) */
+LLAMA_API int  pipeinfer_context_prepare(struct llama_context * ctx);
+LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
+
+/* device-side top-8 of row i of the last finished run: ids/logits sorted (logit desc, id asc), sumexp = sum_j expf(l_j - max) */
+LLAMA_API int  pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp);
+
+struct pipeinfer_stats {
+    uint64_t n_calls;            /* decode calls issued on this context */
+    double   gpu_ms;             /* sum over calls of (done event - start event) on the context's stream */
+    uint64_t alg_bytes;          /* algorithmic HBM bytes of those calls (SURVEY 8d formula) */
+    uint64_t weight_bytes;       /* bytes of this stage's weights resident in HBM */
+    uint64_t kv_bytes_per_cell;  /* K+V bytes per cached token for this stage's layers */
+};
+LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
+LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);
+
+/* ---- host KV-cell table on its own (no GPU needed): used by the CPU tests ---- */
+typedef struct pi_kvcells pi_kvcells;
+LLAMA_API pi_kvcells * pi_kvcells_new(int n_ctx);
+LLAMA_API void pi_kvcells_free(pi_kvcells * c);
+LLAMA_API int  pi_kvcells_decode(pi_kvcells * c, int n_tokens, const llama_pos * pos, const int32_t * n_seq_id, const llama_seq_id * seq_ids_flat, int stride); /* pre_decode + find_slot + post_decode; returns slot head or -1 */
+LLAMA_API void pi_kvcells_seq_rm(pi_kvcells * c, int seq, int p0, int p1);
+LLAMA_API void pi_kvcells_seq_cp(pi_kvcells * c, int src, int dst, int p0, int p1);
+LLAMA_API void pi_kvcells_seq_keep(pi_kvcells * c, int seq);
+LLAMA_API void pi_kvcells_clear(pi_kvcells * c);
+LLAMA_API void pi_kvcells_seq_rm_range(pi_kvcells * c, int first, int last, int p0, int p1);
+LLAMA_API void pi_kvcells_seq_cp_range(pi_kvcells * c, int src, int first, int last, int p0, int p1);
+LLAMA_API void pi_kvcells_seq_rm_cp_range(pi_kvcells * c, int src, int first, int last, int p0, int p1);
+LLAMA_API int  pi_kvcells_head(const pi_kvcells * c);
+LLAMA_API int  pi_kvcells_used(const pi_kvcells * c);
+LLAMA_API int  pi_kvcells_n_attend(const pi_kvcells * c);
+LLAMA_API int  pi_kvcells_pos(const pi_kvcells * c, int i);
+LLAMA_API int  pi_kvcells_has(const pi_kvcells * c, int i, int seq);
+LLAMA_API int  pi_kvcells_nseq(const pi_kvcells * c, int i);
+LLAMA_API void pi_kvcells_mask(const pi_kvcells * c, int n_kv, int n_tokens, const llama_pos * pos, const int32_t * n_seq_id, const llama_seq_id * seq_ids_flat, int stride, uint32_t * out_bits);
+
+/* ---- the PipeInfer driver (examples/speculative/speculative.cpp re-stated as a library call) ---- */
+struct pipeinfer_spec_params {
+    int32_t n_predict;       /* -n   tokens to generate */
+    int32_t n_draft;         /* --draft */
+    int32_t n_parallel;      /* -np  tree branches per speculative run */
+    float   p_accept;        /* -pa */
+    float   p_split;         /* -ps */
+    float   p_recovery;      /* -pr */
+    float   p_decay;         /* -pd */
+    float   temp;            /* --temp (<= 0: greedy; < 0 also computes probabilities) */
+    int32_t ignore_eos;      /* --ignore-eos */
+    int32_t mode;            /* 0 = PipeInfer (async, continuous speculation), 2 = target only (greedy, no draft model) */
+    int32_t max_inflight;    /* cap on target runs in flight (0 = unlimited, the reference behaviour) */
+    int32_t verbose;
+};
+struct pipeinfer_spec_result {
+    int32_t n_input, n_predict, n_drafted, n_accept;       /* the reference's counters (speculative.cpp:681-718) */
+    int32_t n_accept_clean;                                 /* drafted tokens that ended up in the output */
+    int32_t n_drafted_tokens;                               /* drafted tokens sent to the target for verification */
+    int32_t n_runs_spec, n_runs_nonspec, n_runs_canceled;
+    double  t_enc_s, t_dec_s, ttft_s, itl_s;
+    double  decode_tps, encode_tps;
+};
+LLAMA_API struct pipeinfer_spec_params pipeinfer_spec_default_params(void);
+LLAMA_API int pipeinfer_speculative(struct llama_context * ctx_tgt, struct llama_context * ctx_dft, const struct pipeinfer_spec_params * params,
+                                    const llama_token * prompt, int32_t n_prompt, llama_token * out_tokens, int32_t out_cap, struct pipeinfer_spec_result * result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -66,9 +66,11 @@ PI_API int pi_op_mul_mat(const pi_weight * w, const void * q8_dev, int n_tok, fl
 /* RoPE tables as the reference iterates them: cos/sin [n_pos][head_dim/2] f32, built on the host (theta *= theta_scale) */
 PI_API void *  pi_rope_table_create(int n_pos, int head_dim, float freq_base, float freq_scale, int neox);
 PI_API void    pi_rope_table_free(void * table);
-/* q/k/v: f32 [n_tok][n_head*hd] / [n_tok][n_head_kv*hd]; writes roped Q as f16 [n_tok][n_head*hd]; K and V as f16 rows of
- * the layer's cache at cells kv_head.. (k_cache/v_cache: [n_ctx][n_head_kv*hd] f16 each) */
-PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const float * v_dev, const int32_t * pos_dev, const void * rope_table,
+/* q/k/v: f32 rows of n_head*hd / n_head_kv*hd values per token, *_stride floats apart (a fused QKV output is passed as three
+ * views); writes roped Q as f16 [n_tok][n_head*hd]; K and V as f16 rows of the layer's cache at cells kv_head..
+ * (k_cache/v_cache: [n_ctx][n_head_kv*hd] f16 each) */
+PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const float * v_dev, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                               const int32_t * pos_dev, const void * rope_table,
                                int neox, int head_dim, int n_head, int n_head_kv, int n_tok, int kv_head,
                                uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, void * stream);
 /* mask_dev: uint32 bitmap [n_tok][ceil(n_kv/32)], bit i set <=> cell i visible to the token; out f32 [n_tok][n_head*hd] */

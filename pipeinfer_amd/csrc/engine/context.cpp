@@ -1,0 +1,281 @@
+// llama_context: KV cache + scratch in HBM, one HIP stream per context, asynchronous runs.
+//
+// Run lifecycle (reference: llama_decode_internal_phased, llama.cpp:5461-5827):
+//   start  = phase 0: cell placement (find_slot) + attention mask are fixed on the host NOW, exactly as the reference fixes
+//            them at graph-build time; the stage's kernels, the logits D2H copy and a completion event are enqueued on the
+//            context's stream; the call returns a ticket.  Nothing blocks: draft and target contexts overlap on the GPU.
+//   finish = phase 1: wait for the event, copy the requested logits rows into the context's logits buffer.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#define HIP_OK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e__); return false; } } while (0)
+#define OP_OK(expr)  do { if ((expr) != 0) { ctx->last_error = std::string(#expr) + ": " + pi_last_error(); return false; } } while (0)
+
+llama_context::~llama_context() {
+    if (stream) (void) hipStreamSynchronize(stream);
+    for (pi_run * r : inflight) pool.push_back(r);
+    for (pi_run * r : pool) {
+        if (r->done) (void) hipEventDestroy(r->done);
+        if (r->begin) (void) hipEventDestroy(r->begin);
+        if (r->logits_host) (void) hipHostFree(r->logits_host);
+        if (r->topk_ids) (void) hipHostFree(r->topk_ids);
+        if (r->meta_host) (void) hipHostFree(r->meta_host);
+        delete r;
+    }
+    void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, tokens_dev, pos_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev };
+    for (void * b : bufs) pi_free(b);
+    if (rope) pi_rope_table_free(rope);
+    if (stream) (void) hipStreamDestroy(stream);
+}
+
+namespace pi {
+
+static size_t kv_bytes_per_cell(const llama_context * ctx) {
+    return (size_t) 2 * 2 * ctx->model->hparams.n_embd_gqa() * (size_t) (ctx->l1 - ctx->l0);
+}
+
+// weights of the stage + K/V read over n_kv cells + K/V written for n_tok + activation hops (+ logits)
+size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv) {
+    const pi_hparams & hp = ctx->model->hparams;
+    size_t b = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, n_tok);
+    b += (size_t) n_kv * kv_bytes_per_cell(ctx) + (size_t) n_tok * kv_bytes_per_cell(ctx);
+    b += (size_t) 8 * hp.n_embd * n_tok;
+    if (ctx->is_last) b += (size_t) 4 * hp.n_vocab * n_tok;
+    return b;
+}
+
+bool context_prepare(llama_context * ctx, std::string & err) {
+    if (ctx->x) return true;
+    llama_model * m = ctx->model;
+    const pi_hparams & hp = m->hparams;
+    if (pi_device_init(m->device) != 0) { err = pi_last_error(); return false; }
+    const int64_t t0 = time_us();
+    if (!m->ensure_loaded(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, err)) return false;
+    ctx->t_load_us += time_us() - t0;
+    const int nb = ctx->n_batch, n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, n_layer_local = ctx->l1 - ctx->l0;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+    auto dev = [&](size_t bytes) -> void * { void * p = pi_malloc(bytes); if (!p) err = pi_last_error(); return p; };
+    const size_t kv_elems = (size_t) n_layer_local * ctx->n_ctx * n_gqa;
+    if (!(ctx->k_cache = (uint16_t *) dev(kv_elems * 2)) || !(ctx->v_cache = (uint16_t *) dev(kv_elems * 2))) return false;
+    pi_memset(ctx->k_cache, 0, kv_elems * 2, nullptr); pi_memset(ctx->v_cache, 0, kv_elems * 2, nullptr);   // llama.cpp:1543 memset(cache.buf, 0)
+    const int neox = hp.arch == PI_ARCH_FALCON;
+    const float freq_base  = ctx->cparams.rope_freq_base  == 0.0f ? hp.rope_freq_base_train  : ctx->cparams.rope_freq_base;     // llama.cpp:8729-8731
+    const float freq_scale = ctx->cparams.rope_freq_scale == 0.0f ? hp.rope_freq_scale_train : ctx->cparams.rope_freq_scale;
+    if (!(ctx->rope = pi_rope_table_create(std::max(ctx->n_ctx, 32), hp.head_dim(), freq_base, freq_scale, neox))) { err = pi_last_error(); return false; }
+    const size_t qkv_w = (size_t) n_embd + 2 * n_gqa;
+    const size_t kmax = (size_t) std::max(n_embd, n_ff);
+    const size_t q8_bytes = std::max(pi_q8_nbytes(PI_Q8_K, (int64_t) ((kmax + 255) / 256 * 256), nb), pi_q8_nbytes(PI_Q8_0, (int64_t) kmax, nb));
+    if (!(ctx->x = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->x2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->nx = (float *) dev((size_t) 4 * nb * n_embd)) ||
+        !(ctx->nx2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->qkv = (float *) dev((size_t) 4 * nb * qkv_w)) || !(ctx->att = (float *) dev((size_t) 4 * nb * n_embd)) ||
+        !(ctx->up = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->gate = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->q16 = (uint16_t *) dev((size_t) 2 * nb * n_embd)) ||
+        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)))
+        return false;
+    ctx->mask_cap_words = (size_t) nb * ((ctx->n_ctx + 31) / 32);
+    if (!(ctx->mask_dev = (uint32_t *) dev(ctx->mask_cap_words * 4))) return false;
+    if (ctx->is_last) {
+        if (!(ctx->logits_dev = (float *) dev((size_t) 4 * nb * hp.n_vocab)) || !(ctx->topk_ids_dev = (int32_t *) dev((size_t) 4 * nb * 8)) ||
+            !(ctx->topk_vals_dev = (float *) dev((size_t) 4 * nb * 8)) || !(ctx->topk_sum_dev = (float *) dev((size_t) 4 * nb)))
+            return false;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { err = "hipDeviceSynchronize failed after allocation"; return false; }
+    return true;
+}
+
+static pi_run * acquire_run(llama_context * ctx, int n_tokens, size_t meta_bytes) {
+    pi_run * r = nullptr;
+    if (!ctx->pool.empty()) { r = ctx->pool.back(); ctx->pool.pop_back(); }
+    else { r = new pi_run(); if (hipEventCreate(&r->done) != hipSuccess || hipEventCreate(&r->begin) != hipSuccess) { delete r; return nullptr; } }
+    const size_t need = ctx->is_last ? (size_t) n_tokens * ctx->model->hparams.n_vocab : 0;
+    if (need > r->logits_cap) {
+        if (r->logits_host) (void) hipHostFree(r->logits_host);
+        if (r->topk_ids) (void) hipHostFree(r->topk_ids);
+        r->logits_cap = std::max(need, (size_t) 16 * ctx->model->hparams.n_vocab);
+        const size_t rows = r->logits_cap / ctx->model->hparams.n_vocab;
+        if (hipHostMalloc((void **) &r->logits_host, r->logits_cap * 4, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipHostMalloc((void **) &r->topk_ids, rows * (8 * 4 + 8 * 4 + 4), hipHostMallocDefault) != hipSuccess) return nullptr;
+        r->topk_vals = (float *) (r->topk_ids + rows * 8);
+        r->topk_sum  = r->topk_vals + rows * 8;
+    }
+    if (meta_bytes > r->meta_cap) {
+        if (r->meta_host) (void) hipHostFree(r->meta_host);
+        r->meta_cap = std::max(meta_bytes, (size_t) 4096);
+        if (hipHostMalloc((void **) &r->meta_host, r->meta_cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    }
+    r->canceled = r->launched = r->finished = false;
+    return r;
+}
+
+// ---- the forward pass of this stage: layers [l0, l1) ----------------------------------------------------------------------
+static bool mm(llama_context * ctx, const pi_weight * w, const float * act, int k, int n_tok, float * out, const float * res, int & cur_vdt, const float * & cur_src, void * q8) {
+    // quantise the activations once per (source, type); consecutive mat-muls that share both reuse the buffer (as ggml's INIT does per op)
+    const int vdt = pi_vec_dot_type(pi_weight_type(w));
+    if (vdt != cur_vdt || act != cur_src) {
+        OP_OK(pi_op_quantize(vdt, act, k, n_tok, q8, ctx->stream));
+        cur_vdt = vdt; cur_src = act;
+    }
+    OP_OK(pi_op_mul_mat(w, q8, n_tok, out, res, ctx->stream));
+    return true;
+}
+
+static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
+    llama_model * m = ctx->model;
+    const pi_hparams & hp = m->hparams;
+    const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, hd = hp.head_dim();
+    hipStream_t s = ctx->stream;
+    float * x = ctx->x, * x2 = ctx->x2;
+    if (ctx->is_first) OP_OK(pi_op_get_rows(m->tok_embd, ctx->tokens_dev, n_tok, x, s));
+    const size_t kv_layer = (size_t) ctx->n_ctx * n_gqa;
+    for (int il = ctx->l0; il < ctx->l1; il++) {
+        const pi_layer & L = m->layers[il];
+        uint16_t * kc = ctx->k_cache + (size_t) (il - ctx->l0) * kv_layer, * vc = ctx->v_cache + (size_t) (il - ctx->l0) * kv_layer;
+        int vdt = -1; const float * src = nullptr;
+        if (hp.arch == PI_ARCH_LLAMA) {
+            OP_OK(pi_op_norm(x, L.attn_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
+            float * q = ctx->qkv, * k = q + (size_t) n_tok * n_embd, * v = k + (size_t) n_tok * n_gqa;
+            if (!mm(ctx, L.wq, ctx->nx, n_embd, n_tok, q, nullptr, vdt, src, ctx->q8a)) return false;
+            if (!mm(ctx, L.wk, ctx->nx, n_embd, n_tok, k, nullptr, vdt, src, ctx->q8a)) return false;
+            if (!mm(ctx, L.wv, ctx->nx, n_embd, n_tok, v, nullptr, vdt, src, ctx->q8a)) return false;
+            OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, s));
+            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, s));
+            vdt = -1;
+            if (!mm(ctx, L.wo, ctx->att, n_embd, n_tok, x2, x, vdt, src, ctx->q8a)) return false;                  // ffn_inp = wo.att + inpSA
+            OP_OK(pi_op_norm(x2, L.ffn_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
+            vdt = -1;
+            if (!mm(ctx, L.ffn_up, ctx->nx, n_embd, n_tok, ctx->up, nullptr, vdt, src, ctx->q8a)) return false;
+            if (!mm(ctx, L.ffn_gate, ctx->nx, n_embd, n_tok, ctx->gate, nullptr, vdt, src, ctx->q8a)) return false;
+            OP_OK(pi_op_silu_mul(ctx->gate, ctx->up, ctx->gate, (int64_t) n_tok * n_ff, s));
+            vdt = -1;
+            if (!mm(ctx, L.ffn_down, ctx->gate, n_ff, n_tok, x, x2, vdt, src, ctx->q8b)) return false;             // l_out = down(..) + ffn_inp
+        } else {
+            OP_OK(pi_op_norm(x, L.attn_norm, L.attn_norm_b, ctx->nx, n_embd, n_tok, hp.f_norm_eps, 0, s));          // attn_norm (also feeds the MLP)
+            const float * cur = ctx->nx;
+            if (L.attn_norm_2) { OP_OK(pi_op_norm(x, L.attn_norm_2, L.attn_norm_2_b, ctx->nx2, n_embd, n_tok, hp.f_norm_eps, 0, s)); cur = ctx->nx2; }
+            const int64_t qw = n_embd + 2 * n_gqa;
+            if (!mm(ctx, L.wqkv, cur, n_embd, n_tok, ctx->qkv, nullptr, vdt, src, ctx->q8a)) return false;
+            OP_OK(pi_op_rope_kv_store(ctx->qkv, ctx->qkv + n_embd, ctx->qkv + n_embd + n_gqa, qw, qw, qw, ctx->pos_dev, ctx->rope, 1, hd, hp.n_head, hp.n_head_kv,
+                                      n_tok, kv_head, ctx->q16, kc, vc, s));
+            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, s));
+            vdt = -1;
+            if (!mm(ctx, L.wo, ctx->att, n_embd, n_tok, x2, nullptr, vdt, src, ctx->q8a)) return false;             // ffn_inp = attention output
+            vdt = -1;
+            if (!mm(ctx, L.ffn_up, ctx->nx, n_embd, n_tok, ctx->up, nullptr, vdt, src, ctx->q8b)) return false;     // MLP consumes attn_norm (llama.cpp:4194)
+            OP_OK(pi_op_gelu(ctx->up, ctx->up, (int64_t) n_tok * n_ff, s));
+            vdt = -1;
+            if (!mm(ctx, L.ffn_down, ctx->up, n_ff, n_tok, ctx->att, x2, vdt, src, ctx->q8b)) return false;         // ffn_out + ffn_inp
+            OP_OK(pi_op_add(ctx->att, x, x, (int64_t) n_tok * n_embd, s));                                            // + inpL
+        }
+    }
+    if (ctx->is_last) {
+        int vdt = -1; const float * src = nullptr;
+        if (hp.arch == PI_ARCH_LLAMA) OP_OK(pi_op_norm(x, m->output_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
+        else                          OP_OK(pi_op_norm(x, m->output_norm, m->output_norm_b, ctx->nx, n_embd, n_tok, hp.f_norm_eps, 0, s));
+        if (!mm(ctx, m->output, ctx->nx, n_embd, n_tok, ctx->logits_dev, nullptr, vdt, src, ctx->q8a)) return false;
+        OP_OK(pi_op_topk(ctx->logits_dev, hp.n_vocab, n_tok, 8, ctx->topk_ids_dev, ctx->topk_vals_dev, ctx->topk_sum_dev, s));
+    }
+    return true;
+}
+
+pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & rc) {
+    rc = -1;
+    std::string err;
+    if (!context_prepare(ctx, err)) { ctx->last_error = err; fprintf(stderr, "llama_decode: %s\n", err.c_str()); return nullptr; }
+    const int n_tokens = batch_in.n_tokens;
+    if (n_tokens <= 0) { ctx->last_error = "n_tokens == 0"; return nullptr; }
+    if (n_tokens > ctx->n_batch) { ctx->last_error = "n_tokens > n_batch"; fprintf(stderr, "llama_decode: n_tokens (%d) > n_batch (%d)\n", n_tokens, ctx->n_batch); return nullptr; }
+    if (!batch_in.token) { ctx->last_error = "embedding input batches are not supported on this path"; return nullptr; }
+    // defaults for the legacy all_pos/all_seq_id form (llama.cpp:5519-5543)
+    std::vector<llama_pos> pos_buf; std::vector<int32_t> nseq_buf; std::vector<llama_seq_id> seq_store; std::vector<llama_seq_id *> seq_ptrs;
+    const llama_pos * pos = batch_in.pos; const int32_t * n_seq_id = batch_in.n_seq_id; llama_seq_id * const * seq_id = batch_in.seq_id;
+    if (!pos) { pos_buf.resize(n_tokens); for (int i = 0; i < n_tokens; i++) pos_buf[i] = batch_in.all_pos_0 + i * batch_in.all_pos_1; pos = pos_buf.data(); }
+    if (!seq_id) {
+        nseq_buf.assign(n_tokens, 1); seq_store.assign(n_tokens, batch_in.all_seq_id); seq_ptrs.resize(n_tokens);
+        for (int i = 0; i < n_tokens; i++) seq_ptrs[i] = &seq_store[i];
+        n_seq_id = nseq_buf.data(); seq_id = seq_ptrs.data();
+    }
+    for (int i = 0; i < n_tokens; i++) if (pos[i] < 0 || pos[i] >= std::max(ctx->n_ctx, 32)) { ctx->last_error = "token position outside the RoPE table"; return nullptr; }
+
+    ctx->cells->pre_decode(n_tokens);
+    const int kv_head = ctx->cells->find_slot(n_tokens, pos, n_seq_id, seq_id);
+    if (kv_head < 0) { rc = 1; return nullptr; }                              // reference prints "Cannot find cache slot" and fails the decode
+    const int n_kv = ctx->cells->n_attend();
+    const int words = (n_kv + 31) / 32;
+    const size_t meta_bytes = (size_t) n_tokens * 8 + (size_t) n_tokens * words * 4;
+    pi_run * run = acquire_run(ctx, n_tokens, meta_bytes);
+    if (!run) { ctx->last_error = "out of pinned host memory"; return nullptr; }
+    run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us();
+    if (hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
+    // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
+    run->want_logits.assign(n_tokens, 1);
+    run->last_only = false;
+    if (batch_in.logits) for (int i = 0; i < n_tokens; i++) run->want_logits[i] = batch_in.logits[i] != 0;
+    else if (!ctx->cparams.logits_all) run->last_only = true;
+    int32_t * h_tok = (int32_t *) run->meta_host, * h_pos = h_tok + n_tokens; uint32_t * h_mask = (uint32_t *) (h_pos + n_tokens);
+    memcpy(h_tok, batch_in.token, (size_t) 4 * n_tokens);
+    memcpy(h_pos, pos, (size_t) 4 * n_tokens);
+    ctx->cells->build_mask(n_kv, n_tokens, pos, n_seq_id, seq_id, h_mask);
+    ctx->cells->post_decode(n_tokens);
+
+    run->canceled = ctx->canceled_batches.count(run->batch_id) > 0;
+    bool ok = true;
+    if (!run->canceled) {                                                     // a cancelled run still occupies its cells and completes "empty" (llama.cpp:5627-5716)
+        hipStream_t s = ctx->stream;
+        ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (!ok) ctx->last_error = "H2D of batch metadata failed";
+        ok = ok && forward(ctx, n_tokens, kv_head, n_kv);
+        if (ok && ctx->is_last) {
+            const size_t nv = ctx->model->hparams.n_vocab;
+            ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(run->topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(run->topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(run->topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
+            if (!ok) ctx->last_error = "D2H of logits failed";
+        }
+        run->launched = ok;
+        ctx->stat_calls++;
+        ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, n_kv);
+    }
+    if (ok) ok = hipEventRecord(run->done, ctx->stream) == hipSuccess;
+    if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); ctx->pool.push_back(run); return nullptr; }
+    ctx->inflight.push_back(run);
+    rc = 0;
+    return run;
+}
+
+bool context_poll_oldest(llama_context * ctx) {
+    if (ctx->inflight.empty()) return false;
+    return hipEventQuery(ctx->inflight.front()->done) == hipSuccess;
+}
+
+int context_finish(llama_context * ctx, pi_run * run) {
+    if (!run) return -1;
+    if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; return -1; }
+    const size_t nv = ctx->model->hparams.n_vocab;
+    const int n = run->n_tokens;
+    if (ctx->is_last) {
+        ctx->logits.resize(run->last_only ? nv : (size_t) n * nv);             // llama.cpp:5734-5743
+        if (run->launched) {
+            if (run->last_only) memcpy(ctx->logits.data(), run->logits_host + (size_t) (n - 1) * nv, nv * 4);
+            else for (int i = 0; i < n; i++) if (run->want_logits[i]) memcpy(ctx->logits.data() + (size_t) i * nv, run->logits_host + (size_t) i * nv, nv * 4);
+            ctx->last_topk_ids.assign(run->topk_ids, run->topk_ids + (size_t) n * 8);
+            ctx->last_topk_vals.assign(run->topk_vals, run->topk_vals + (size_t) n * 8);
+            ctx->last_topk_sum.assign(run->topk_sum, run->topk_sum + n);
+            ctx->last_n_tokens = n;
+        } else {
+            ctx->last_n_tokens = 0;
+        }
+    }
+    if (run->launched) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_gpu_ms += ms; }
+    const int64_t dt = time_us() - run->t_start_us;
+    if (n == 1) { ctx->t_eval_us += dt; ctx->n_eval++; } else { ctx->t_p_eval_us += dt; ctx->n_p_eval += n; }     // llama.cpp:5807-5815
+    for (auto it = ctx->inflight.begin(); it != ctx->inflight.end(); ++it) if (*it == run) { ctx->inflight.erase(it); break; }
+    run->finished = true;
+    ctx->pool.push_back(run);
+    return 1;
+}
+
+}  // namespace pi

@@ -1,0 +1,116 @@
+// Engine internals behind include/llama.h: model (GGUF -> HBM), context (KV cache, streams, in-flight runs) and the
+// per-stage forward pass that strings the HIP operators together in the order the reference graphs use
+// (build_llama llama.cpp:3872-3983, build_falcon llama.cpp:4106-4227).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../../include/llama.h"
+#include "../../../include/pipeinfer.h"
+#include "../../../include/pipeinfer_ops.h"
+#include "gguf.h"
+#include "kv_cells.h"
+#include "vocab.h"
+
+enum pi_arch { PI_ARCH_LLAMA = 0, PI_ARCH_FALCON = 1 };
+
+struct pi_hparams {
+    pi_arch arch = PI_ARCH_LLAMA;
+    int n_vocab = 0, n_ctx_train = 0, n_embd = 0, n_head = 0, n_head_kv = 0, n_layer = 0, n_ff = 0, n_rot = 0;
+    float f_norm_eps = 0.0f, f_norm_rms_eps = 0.0f, rope_freq_base_train = 10000.0f, rope_freq_scale_train = 1.0f;
+    int head_dim() const { return n_embd / n_head; }
+    int n_embd_gqa() const { return head_dim() * n_head_kv; }
+};
+
+struct pi_layer {
+    pi_weight * wq = nullptr, * wk = nullptr, * wv = nullptr, * wo = nullptr, * wqkv = nullptr;
+    pi_weight * ffn_gate = nullptr, * ffn_down = nullptr, * ffn_up = nullptr;
+    float * attn_norm = nullptr, * attn_norm_b = nullptr, * attn_norm_2 = nullptr, * attn_norm_2_b = nullptr, * ffn_norm = nullptr;
+    bool loaded = false;
+};
+
+struct llama_model {
+    pi::gguf_file file;
+    pi_hparams hparams;
+    pi::vocab vocab;
+    std::string name, path;
+    int device = 0;
+    uint64_t n_elements = 0, n_bytes = 0;
+    pi_weight * tok_embd = nullptr, * output = nullptr;
+    float * output_norm = nullptr, * output_norm_b = nullptr;
+    std::vector<pi_layer> layers;
+    std::vector<void *> f32_allocs;
+    size_t hbm_bytes = 0;                     // bytes resident in HBM for this process's stage(s)
+
+    ~llama_model();
+    // uploads (once) token_embd if first, layers [l0,l1), final norm + output if last
+    bool ensure_loaded(int l0, int l1, bool first, bool last, std::string & err);
+    size_t stage_weight_bytes(int l0, int l1, bool first, bool last, int n_tok) const;
+};
+
+struct pi_run {                                // one llama_start_async_decode .. llama_finish_async_decode
+    int32_t batch_id = 0;
+    int n_tokens = 0;
+    bool canceled = false, launched = false, finished = false, last_only = false;
+    std::vector<int8_t> want_logits;
+    hipEvent_t done = nullptr, begin = nullptr;
+    float * logits_host = nullptr;            // pinned [n_tokens][n_vocab]
+    size_t logits_cap = 0;
+    int32_t * topk_ids = nullptr; float * topk_vals = nullptr; float * topk_sum = nullptr;   // pinned [n_tokens][8], [n_tokens]
+    uint8_t * meta_host = nullptr; size_t meta_cap = 0;                                       // pinned staging for tokens/pos/mask
+    int64_t t_start_us = 0;
+};
+
+struct llama_context {
+    llama_model * model = nullptr;
+    llama_context_params cparams;
+    int n_ctx = 0, n_batch = 512;
+    // pipeline stage owned by this process (single process: the whole model)
+    int l0 = 0, l1 = 0; bool is_first = true, is_last = true;
+    int node_id = 0; bool comm_swapped = false; int comm_color = 0, comm_color_alt = 0;
+
+    std::unique_ptr<pi::kv_cells> cells;
+    uint16_t * k_cache = nullptr, * v_cache = nullptr;        // [n_layer_local][n_ctx][n_embd_gqa] f16 each
+    void * rope = nullptr;
+    hipStream_t stream = nullptr;
+
+    // device scratch, sized for n_batch tokens
+    float * x = nullptr, * x2 = nullptr, * nx = nullptr, * nx2 = nullptr, * qkv = nullptr, * att = nullptr, * up = nullptr, * gate = nullptr, * logits_dev = nullptr;
+    uint16_t * q16 = nullptr;
+    void * q8a = nullptr, * q8b = nullptr;
+    int32_t * tokens_dev = nullptr, * pos_dev = nullptr; uint32_t * mask_dev = nullptr;
+    int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr;
+    size_t mask_cap_words = 0;
+
+    std::deque<pi_run *> inflight;            // oldest at front
+    std::vector<pi_run *> pool;
+    std::set<int32_t> canceled_batches;
+    std::vector<float> logits;                // API-visible buffer (llama_get_logits)
+    std::vector<int32_t> last_topk_ids; std::vector<float> last_topk_vals, last_topk_sum; int last_n_tokens = 0;
+
+    // timings (llama.cpp:10170-10206)
+    int64_t t_start_us = 0, t_load_us = 0, t_eval_us = 0, t_p_eval_us = 0, t_sample_us = 0;
+    int32_t n_eval = 0, n_p_eval = 0, n_sample = 0;
+    // roofline accounting
+    uint64_t stat_calls = 0; double stat_gpu_ms = 0.0; uint64_t stat_alg_bytes = 0;
+
+    std::string last_error;
+    ~llama_context();
+};
+
+namespace pi {
+int64_t time_us();
+bool context_prepare(llama_context * ctx, std::string & err);          // uploads weights, allocates KV + scratch
+pi_run * context_start(llama_context * ctx, const llama_batch & batch, int & rc);   // rc: 0 ok, 1 no slot, <0 error
+int  context_finish(llama_context * ctx, pi_run * run);
+bool context_poll_oldest(llama_context * ctx);
+size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
+}

@@ -1,0 +1,281 @@
+// The extern "C" surface declared in include/llama.h and include/pipeinfer.h.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+// ---- defaults (llama.cpp:8566-8620) ---------------------------------------------------------------------------------------
+extern "C" struct llama_model_params llama_model_default_params(void) {
+    struct llama_model_params r;
+    memset(&r, 0, sizeof r);
+    r.n_gpu_layers = 0; r.main_gpu = 0; r.tensor_split = nullptr; r.progress_callback = nullptr; r.progress_callback_user_data = nullptr;
+    r.vocab_only = false; r.use_mmap = true; r.use_mlock = false;
+    return r;
+}
+
+extern "C" struct llama_context_params llama_context_default_params(void) {
+    struct llama_context_params r;
+    memset(&r, 0, sizeof r);
+    r.seed = LLAMA_DEFAULT_SEED; r.n_ctx = 512; r.n_batch = 512; r.n_threads = 4; r.n_threads_batch = 4;
+    r.rope_scaling_type = -1; r.rope_freq_base = 0.0f; r.rope_freq_scale = 0.0f;
+    r.yarn_ext_factor = -1.0f; r.yarn_attn_factor = 1.0f; r.yarn_beta_fast = 32.0f; r.yarn_beta_slow = 1.0f; r.yarn_orig_ctx = 0;
+    r.mul_mat_q = true; r.f16_kv = true; r.logits_all = false; r.embedding = false;
+    return r;
+}
+
+extern "C" void llama_backend_init(bool) {}
+extern "C" void llama_backend_free(void) {}
+extern "C" int64_t llama_time_us(void) { return pi::time_us(); }
+extern "C" int64_t ggml_time_us(void) { return pi::time_us(); }
+extern "C" const char * llama_print_system_info(void) { return "MI355X (gfx950) | HIP kernels: mmvq q4_0/q8_0/q4_K/q5_K/q6_K, attention, norms, rope | wave64 | "; }
+
+extern "C" struct llama_context * llama_new_context_with_model(struct llama_model * model, struct llama_context_params params) {
+    if (!model) return nullptr;
+    if (!params.f16_kv) { fprintf(stderr, "llama_new_context_with_model: only an f16 KV cache is supported\n"); return nullptr; }
+    llama_context * ctx = new llama_context();
+    ctx->model = model;
+    ctx->cparams = params;
+    ctx->n_ctx = params.n_ctx == 0 ? model->hparams.n_ctx_train : (int) params.n_ctx;       // llama.cpp:8726
+    ctx->n_batch = (int) std::max<uint32_t>(params.n_batch, 1);
+    ctx->l0 = 0; ctx->l1 = model->hparams.n_layer; ctx->is_first = ctx->is_last = true;
+    ctx->cells.reset(new pi::kv_cells(ctx->n_ctx));
+    ctx->t_start_us = pi::time_us();
+    return ctx;
+}
+
+extern "C" void llama_free(struct llama_context * ctx) { delete ctx; }
+extern "C" const struct llama_model * llama_get_model(const struct llama_context * ctx) { return ctx->model; }
+extern "C" int llama_n_ctx(const struct llama_context * ctx) { return ctx->n_ctx; }
+extern "C" void llama_set_n_threads(struct llama_context *, uint32_t, uint32_t) {}
+
+// ---- PipeInfer pipeline control -------------------------------------------------------------------------------------------
+// One process drives every stage of its pipeline, so the calling thread is always the root of whichever communicator is
+// current; the only driver-visible state is llama_node_id (-1 after llama_split_comm(ctx, <0), llama.cpp:8915-8927).
+extern "C" int llama_node_id(struct llama_context * ctx) { return ctx->node_id; }
+extern "C" void llama_split_comm(struct llama_context * ctx, int color) { ctx->comm_color = color; ctx->node_id = color < 0 ? -1 : 0; }
+extern "C" void llama_swap_comm(struct llama_context * ctx) {
+    std::swap(ctx->comm_color, ctx->comm_color_alt);
+    ctx->comm_swapped = !ctx->comm_swapped;
+    ctx->node_id = ctx->comm_color < 0 ? -1 : 0;
+}
+extern "C" void llama_sync_token(struct llama_context *, llama_token *, int) {}                   // MPI_Bcast among roots (llama.cpp:8901-8906): one process
+extern "C" void llama_sync_token_data(struct llama_context *, llama_token_data *, int) {}
+
+// llama_split_layers_weighted (llama.cpp:8929-8938 -> ggml_mpi_split_range, ggml-mpi.c:523-559).  In a single process the
+// context owns every stage; the split only matters to the multi-process pipeline (pipeinfer_amd/pipeline.py), which sets
+// the stage range through pipeinfer_context_set_stage.
+extern "C" void llama_split_layers_weighted(struct llama_context *, float *, size_t) {}
+
+extern "C" bool llama_mpi_iprobe(struct llama_context * ctx) { return pi::context_poll_oldest(ctx); }
+
+extern "C" void llama_cancel_run(struct llama_context * ctx, int32_t * canceled, int count) {
+    for (int i = 0; i < count; i++) ctx->canceled_batches.insert(canceled[i]);                     // llama.cpp:9981-9993
+}
+
+extern "C" struct ggml_cgraph * llama_start_async_decode(struct llama_context * ctx, struct llama_batch batch) {
+    if (ctx->node_id < 0) return nullptr;                                                           // llama.cpp:5466-5468
+    int rc;
+    return (struct ggml_cgraph *) pi::context_start(ctx, batch, rc);
+}
+
+extern "C" int llama_finish_async_decode(struct llama_context * ctx, struct llama_batch, struct ggml_cgraph * cgraph) {
+    if (!cgraph) return -1;                                                                         // llama.cpp:5862-5871
+    return pi::context_finish(ctx, (pi_run *) cgraph);
+}
+
+extern "C" int llama_decode(struct llama_context * ctx, struct llama_batch batch) {
+    if (ctx->node_id < 0) return 0;                                                                 // llama.cpp:10007-10008
+    int rc;
+    pi_run * run = pi::context_start(ctx, batch, rc);
+    if (!run) return rc;
+    return pi::context_finish(ctx, run) == 1 ? 0 : -1;
+}
+
+extern "C" float * llama_get_logits(struct llama_context * ctx) { return ctx->logits.data(); }
+extern "C" float * llama_get_logits_ith(struct llama_context * ctx, int32_t i) { return ctx->logits.data() + (size_t) i * ctx->model->hparams.n_vocab; }
+
+// ---- batches (llama.cpp:9839-9898) ------------------------------------------------------------------------------------------
+extern "C" struct llama_batch llama_batch_get_one(llama_token * tokens, int32_t n_tokens, llama_pos pos_0, llama_seq_id seq_id) {
+    struct llama_batch b;
+    memset(&b, 0, sizeof b);
+    b.n_tokens = n_tokens; b.token = tokens; b.all_pos_0 = pos_0; b.all_pos_1 = 1; b.all_seq_id = seq_id; b.max_n_seq = 1;
+    return b;
+}
+
+extern "C" struct llama_batch llama_batch_init(int32_t n_tokens, int32_t embd, int32_t n_seq_max) {
+    struct llama_batch b;
+    memset(&b, 0, sizeof b);
+    b.max_n_seq = n_seq_max;
+    if (embd) b.embd = (float *) malloc(sizeof(float) * n_tokens * embd);
+    else      b.token = (llama_token *) malloc(sizeof(llama_token) * n_tokens);
+    b.pos      = (llama_pos *) malloc(sizeof(llama_pos) * n_tokens);
+    b.n_seq_id = (int32_t *) malloc(sizeof(int32_t) * n_tokens);
+    b.seq_id   = (llama_seq_id **) malloc(sizeof(llama_seq_id *) * n_tokens);
+    // one block for all rows (the reference mallocs n_tokens rows and frees only the first batch.n_tokens of them)
+    llama_seq_id * rows = (llama_seq_id *) malloc(sizeof(llama_seq_id) * (size_t) n_tokens * (size_t) std::max(n_seq_max, 1));
+    for (int i = 0; i < n_tokens; ++i) b.seq_id[i] = rows + (size_t) i * std::max(n_seq_max, 1);
+    b.logits   = (int8_t *) malloc(sizeof(int8_t) * n_tokens);
+    return b;
+}
+
+extern "C" void llama_batch_free(struct llama_batch * b) {
+    if (b->token) free(b->token);
+    if (b->embd) free(b->embd);
+    if (b->pos) free(b->pos);
+    if (b->n_seq_id) free(b->n_seq_id);
+    if (b->seq_id) { free(b->seq_id[0]); free(b->seq_id); }
+    if (b->logits) free(b->logits);
+    memset(b, 0, sizeof *b);
+}
+
+// ---- KV cache API (llama.cpp:9238-9359; MPI transactions become plain host calls) --------------------------------------------
+extern "C" int  llama_get_kv_cache_token_count(const struct llama_context * ctx) { return ctx->cells->token_count(); }
+extern "C" int  llama_get_kv_cache_used_cells(const struct llama_context * ctx) { return ctx->cells->used(); }
+extern "C" void llama_kv_cache_clear(struct llama_context * ctx) { ctx->cells->clear(); }
+extern "C" void llama_kv_cache_seq_rm(struct llama_context * ctx, llama_seq_id s, llama_pos p0, llama_pos p1) { ctx->cells->seq_rm(s, p0, p1); }
+extern "C" void llama_kv_cache_seq_cp(struct llama_context * ctx, llama_seq_id a, llama_seq_id b, llama_pos p0, llama_pos p1) {
+    if (a == b) return;                                                                             // llama.cpp:9296-9298
+    ctx->cells->seq_cp(a, b, p0, p1);
+}
+extern "C" void llama_kv_cache_seq_keep(struct llama_context * ctx, llama_seq_id s) { ctx->cells->seq_keep(s); }
+extern "C" void pipeinfer_kv_cache_seq_rm_range(struct llama_context * ctx, llama_seq_id a, llama_seq_id b, llama_pos p0, llama_pos p1) { ctx->cells->seq_rm_range(a, b, p0, p1); }
+extern "C" void pipeinfer_kv_cache_seq_cp_range(struct llama_context * ctx, llama_seq_id src, llama_seq_id a, llama_seq_id b, llama_pos p0, llama_pos p1) { ctx->cells->seq_cp_range(src, a, b, p0, p1); }
+extern "C" void pipeinfer_kv_cache_seq_rm_cp_range(struct llama_context * ctx, llama_seq_id src, llama_seq_id a, llama_seq_id b, llama_pos p0, llama_pos p1) { ctx->cells->seq_rm_cp_range(src, a, b, p0, p1); }
+
+extern "C" struct llama_kv_cache_view llama_kv_cache_view_init(const struct llama_context * ctx, int32_t n_max_seq) {     // llama.cpp:9157-9171
+    struct llama_kv_cache_view v;
+    memset(&v, 0, sizeof v);
+    v.n_cells = 0; v.n_max_seq = n_max_seq;
+    (void) ctx;
+    return v;
+}
+extern "C" void llama_kv_cache_view_free(struct llama_kv_cache_view * v) {
+    if (v->cells) { free(v->cells); v->cells = nullptr; }
+    if (v->cells_sequences) { free(v->cells_sequences); v->cells_sequences = nullptr; }
+}
+extern "C" void llama_kv_cache_view_update(const struct llama_context * ctx, struct llama_kv_cache_view * v) {            // llama.cpp:9184-9236
+    const pi::kv_cells & c = *ctx->cells;
+    if (v->n_cells < c.size() || !v->cells) {
+        v->n_cells = c.size();
+        v->cells = (struct llama_kv_cache_view_cell *) realloc(v->cells, sizeof(struct llama_kv_cache_view_cell) * v->n_cells);
+        v->cells_sequences = (llama_seq_id *) realloc(v->cells_sequences, sizeof(llama_seq_id) * v->n_max_seq * v->n_cells);
+    }
+    int used = 0, tokens = 0, cur_contig = 0, max_contig = 0, max_idx = -1;
+    for (int i = 0; i < c.size(); i++) {
+        llama_seq_id * cs = v->cells_sequences + (size_t) i * v->n_max_seq;
+        const int sz = c.nseq(i);
+        tokens += sz;
+        v->cells[i].pos = c.pos(i);
+        if (sz > 0) {
+            if (cur_contig > max_contig) { max_contig = cur_contig; max_idx = i - cur_contig; }
+            cur_contig = 0;
+        } else cur_contig++;
+        int k = 0;
+        for (int s = 0; k < v->n_max_seq && k < sz && s < 1 << 20; s++) if (c.has(i, s)) cs[k++] = s;
+        if (k > 0) used++;
+        for (; k < v->n_max_seq; k++) cs[k] = -1;
+    }
+    if (cur_contig > max_contig) { max_contig = cur_contig; max_idx = c.size() - cur_contig; }
+    v->max_contiguous = max_contig; v->max_contiguous_idx = max_idx; v->token_count = tokens; v->used_cells = used;
+}
+
+// ---- greedy samplers (llama.cpp:7019-7046, 7496-7510) ---------------------------------------------------------------------------
+extern "C" void llama_sample_softmax(struct llama_context * ctx, llama_token_data_array * c) {
+    const int64_t t0 = pi::time_us();
+    if (!c->sorted) {
+        std::stable_sort(c->data, c->data + c->size, [](const llama_token_data & a, const llama_token_data & b) { return a.logit > b.logit; });
+        c->sorted = true;
+    }
+    const float max_l = c->data[0].logit;
+    float cum = 0.0f;
+    for (size_t i = 0; i < c->size; ++i) { const float p = expf(c->data[i].logit - max_l); c->data[i].p = p; cum += p; }
+    for (size_t i = 0; i < c->size; ++i) c->data[i].p /= cum;
+    if (ctx) ctx->t_sample_us += pi::time_us() - t0;
+}
+
+extern "C" llama_token llama_sample_token_greedy(struct llama_context * ctx, llama_token_data_array * c) {
+    const int64_t t0 = pi::time_us();
+    size_t best = 0;
+    for (size_t i = 1; i < c->size; i++) if (c->data[best].logit < c->data[i].logit) best = i;      // std::max_element: first maximum
+    if (ctx) { ctx->t_sample_us += pi::time_us() - t0; ctx->n_sample++; }
+    return c->data[best].id;
+}
+
+// ---- timings ------------------------------------------------------------------------------------------------------------------
+extern "C" struct llama_timings llama_get_timings(struct llama_context * ctx) {
+    struct llama_timings r;
+    r.t_start_ms = 1e-3 * ctx->t_start_us; r.t_end_ms = 1e-3 * pi::time_us(); r.t_load_ms = 1e-3 * ctx->t_load_us;
+    r.t_sample_ms = 1e-3 * ctx->t_sample_us; r.t_p_eval_ms = 1e-3 * ctx->t_p_eval_us; r.t_eval_ms = 1e-3 * ctx->t_eval_us;
+    r.n_sample = std::max(1, ctx->n_sample); r.n_p_eval = std::max(1, ctx->n_p_eval); r.n_eval = std::max(1, ctx->n_eval);
+    return r;
+}
+extern "C" void llama_print_timings(struct llama_context * ctx) {
+    const struct llama_timings t = llama_get_timings(ctx);
+    fprintf(stderr, "\n");
+    fprintf(stderr, "llama_print_timings:        load time = %10.2f ms\n", t.t_load_ms);
+    fprintf(stderr, "llama_print_timings:      sample time = %10.2f ms / %5d runs   (%8.2f ms per token)\n", t.t_sample_ms, t.n_sample, t.t_sample_ms / t.n_sample);
+    fprintf(stderr, "llama_print_timings: prompt eval time = %10.2f ms / %5d tokens (%8.2f ms per token)\n", t.t_p_eval_ms, t.n_p_eval, t.t_p_eval_ms / t.n_p_eval);
+    fprintf(stderr, "llama_print_timings:        eval time = %10.2f ms / %5d runs   (%8.2f ms per token)\n", t.t_eval_ms, t.n_eval, t.t_eval_ms / t.n_eval);
+    fprintf(stderr, "llama_print_timings:       total time = %10.2f ms\n", t.t_end_ms - t.t_start_ms);
+}
+extern "C" void llama_reset_timings(struct llama_context * ctx) {
+    ctx->t_start_us = pi::time_us(); ctx->t_sample_us = ctx->t_eval_us = ctx->t_p_eval_us = 0; ctx->n_sample = ctx->n_eval = ctx->n_p_eval = 0;
+}
+
+// ---- extensions ------------------------------------------------------------------------------------------------------------------
+extern "C" int pipeinfer_context_prepare(struct llama_context * ctx) {
+    std::string err;
+    if (!pi::context_prepare(ctx, err)) { ctx->last_error = err; return -1; }
+    return 0;
+}
+extern "C" const char * pipeinfer_context_error(struct llama_context * ctx) { return ctx->last_error.c_str(); }
+
+extern "C" int pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp) {
+    if (i < 0 || i >= ctx->last_n_tokens) return -1;
+    memcpy(ids, ctx->last_topk_ids.data() + (size_t) i * 8, 8 * sizeof(llama_token));
+    memcpy(logits, ctx->last_topk_vals.data() + (size_t) i * 8, 8 * sizeof(float));
+    *sumexp = ctx->last_topk_sum[i];
+    return 0;
+}
+
+extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out) {
+    out->n_calls = ctx->stat_calls; out->gpu_ms = ctx->stat_gpu_ms; out->alg_bytes = ctx->stat_alg_bytes;
+    out->weight_bytes = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, 1);
+    out->kv_bytes_per_cell = (uint64_t) 4 * ctx->model->hparams.n_embd_gqa() * (uint64_t) (ctx->l1 - ctx->l0);
+}
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; }
+
+// ---- stand-alone KV-cell table (host logic tests) ---------------------------------------------------------------------------------
+struct pi_kvcells { pi::kv_cells cells; explicit pi_kvcells(int n) : cells(n) {} };
+extern "C" pi_kvcells * pi_kvcells_new(int n_ctx) { return new pi_kvcells(n_ctx); }
+extern "C" void pi_kvcells_free(pi_kvcells * c) { delete c; }
+static std::vector<llama_seq_id *> row_ptrs(const llama_seq_id * flat, int n, int stride) {
+    std::vector<llama_seq_id *> p((size_t) n);
+    for (int i = 0; i < n; i++) p[i] = const_cast<llama_seq_id *>(flat) + (size_t) i * stride;
+    return p;
+}
+extern "C" int pi_kvcells_decode(pi_kvcells * c, int n, const llama_pos * pos, const int32_t * n_seq_id, const llama_seq_id * flat, int stride) {
+    auto p = row_ptrs(flat, n, stride);
+    c->cells.pre_decode(n);
+    const int head = c->cells.find_slot(n, pos, n_seq_id, p.data());
+    if (head >= 0) c->cells.post_decode(n);
+    return head;
+}
+extern "C" void pi_kvcells_seq_rm(pi_kvcells * c, int s, int p0, int p1) { c->cells.seq_rm(s, p0, p1); }
+extern "C" void pi_kvcells_seq_cp(pi_kvcells * c, int a, int b, int p0, int p1) { c->cells.seq_cp(a, b, p0, p1); }
+extern "C" void pi_kvcells_seq_keep(pi_kvcells * c, int s) { c->cells.seq_keep(s); }
+extern "C" void pi_kvcells_clear(pi_kvcells * c) { c->cells.clear(); }
+extern "C" void pi_kvcells_seq_rm_range(pi_kvcells * c, int a, int b, int p0, int p1) { c->cells.seq_rm_range(a, b, p0, p1); }
+extern "C" void pi_kvcells_seq_cp_range(pi_kvcells * c, int src, int a, int b, int p0, int p1) { c->cells.seq_cp_range(src, a, b, p0, p1); }
+extern "C" void pi_kvcells_seq_rm_cp_range(pi_kvcells * c, int src, int a, int b, int p0, int p1) { c->cells.seq_rm_cp_range(src, a, b, p0, p1); }
+extern "C" int  pi_kvcells_head(const pi_kvcells * c) { return c->cells.head(); }
+extern "C" int  pi_kvcells_used(const pi_kvcells * c) { return c->cells.used(); }
+extern "C" int  pi_kvcells_n_attend(const pi_kvcells * c) { return c->cells.n_attend(); }
+extern "C" int  pi_kvcells_pos(const pi_kvcells * c, int i) { return c->cells.pos(i); }
+extern "C" int  pi_kvcells_has(const pi_kvcells * c, int i, int s) { return c->cells.has(i, s); }
+extern "C" int  pi_kvcells_nseq(const pi_kvcells * c, int i) { return c->cells.nseq(i); }
+extern "C" void pi_kvcells_mask(const pi_kvcells * c, int n_kv, int n, const llama_pos * pos, const int32_t * n_seq_id, const llama_seq_id * flat, int stride, uint32_t * out) {
+    auto p = row_ptrs(flat, n, stride);
+    c->cells.build_mask(n_kv, n, pos, n_seq_id, p.data(), out);
+}

@@ -1,0 +1,177 @@
+// GGUF -> llama_model: hyper-parameters (llama.cpp:2203-2381), vocabulary, and per-stage upload of the weights into HBM
+// (tensor names/shapes: llama.cpp:2756-2824 Llama, :2891-2968 Falcon).
+#include "engine.h"
+
+#include <chrono>
+#include <cstring>
+
+namespace pi {
+int64_t time_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}
+
+llama_model::~llama_model() {
+    for (auto & l : layers) {
+        pi_weight_free(l.wq); pi_weight_free(l.wk); pi_weight_free(l.wv); pi_weight_free(l.wo); pi_weight_free(l.wqkv);
+        pi_weight_free(l.ffn_gate); pi_weight_free(l.ffn_down); pi_weight_free(l.ffn_up);
+    }
+    pi_weight_free(tok_embd); pi_weight_free(output);
+    for (void * p : f32_allocs) pi_free(p);
+}
+
+static pi_weight * upload_matrix(llama_model & m, const std::string & name, int64_t ne0, int64_t ne1, std::string & err) {
+    const pi::gguf_tensor * t = m.file.tensor(name);
+    if (!t) { err = "missing tensor " + name; return nullptr; }
+    if (t->ne[0] != ne0 || t->ne[1] != ne1) {
+        err = "tensor " + name + " has shape [" + std::to_string(t->ne[0]) + "," + std::to_string(t->ne[1]) + "], expected [" + std::to_string(ne0) + "," + std::to_string(ne1) + "]";
+        return nullptr;
+    }
+    pi_weight * w = pi_weight_upload(t->type, ne0, ne1, t->data, nullptr);
+    if (!w) { err = std::string("upload of ") + name + " failed: " + pi_last_error(); return nullptr; }
+    m.hbm_bytes += pi_weight_nbytes(w);
+    return w;
+}
+
+static float * upload_f32(llama_model & m, const std::string & name, int64_t n, bool required, std::string & err) {
+    const pi::gguf_tensor * t = m.file.tensor(name);
+    if (!t) { if (required) err = "missing tensor " + name; return nullptr; }
+    if (t->type != PI_F32 || t->ne[0] != n) { err = "tensor " + name + " must be f32[" + std::to_string(n) + "]"; return nullptr; }
+    float * d = (float *) pi_malloc((size_t) n * 4);
+    if (!d || pi_memcpy_h2d(d, t->data, (size_t) n * 4, nullptr) || pi_stream_sync(nullptr)) { err = std::string("upload of ") + name + " failed: " + pi_last_error(); return nullptr; }
+    m.f32_allocs.push_back(d);
+    m.hbm_bytes += (size_t) n * 4;
+    return d;
+}
+
+bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, std::string & err) {
+    const pi_hparams & hp = hparams;
+    const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff;
+    if (first && !tok_embd) { if (!(tok_embd = upload_matrix(*this, "token_embd.weight", n_embd, hp.n_vocab, err))) return false; }
+    for (int il = l0; il < l1; il++) {
+        pi_layer & L = layers[il];
+        if (L.loaded) continue;
+        const std::string p = "blk." + std::to_string(il) + ".";
+        if (hp.arch == PI_ARCH_LLAMA) {
+            if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
+            if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err))) return false;
+            if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err))) return false;
+            if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err))) return false;
+            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
+            if (!(L.ffn_norm = upload_f32(*this, p + "ffn_norm.weight", n_embd, true, err))) return false;
+            if (!(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err))) return false;
+            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
+            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+        } else {
+            if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
+            if (!(L.attn_norm_b = upload_f32(*this, p + "attn_norm.bias", n_embd, true, err))) return false;
+            if (file.tensor(p + "attn_norm_2.weight")) {                       // Falcon-40B style second norm (llama.cpp:2921-2926)
+                if (!(L.attn_norm_2 = upload_f32(*this, p + "attn_norm_2.weight", n_embd, true, err))) return false;
+                if (!(L.attn_norm_2_b = upload_f32(*this, p + "attn_norm_2.bias", n_embd, true, err))) return false;
+            }
+            if (!(L.wqkv = upload_matrix(*this, p + "attn_qkv.weight", n_embd, n_embd + 2 * n_gqa, err))) return false;
+            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
+            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
+            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+        }
+        L.loaded = true;
+    }
+    if (last && !output) {
+        if (!(output_norm = upload_f32(*this, "output_norm.weight", n_embd, true, err))) return false;
+        if (hp.arch == PI_ARCH_FALCON && !(output_norm_b = upload_f32(*this, "output_norm.bias", n_embd, true, err))) return false;
+        if (!(output = upload_matrix(*this, "output.weight", n_embd, hp.n_vocab, err))) return false;
+    }
+    return true;
+}
+
+// sum of ggml_nbytes of the tensors one decode call on this stage streams: the embedding contributes n_tok rows
+size_t llama_model::stage_weight_bytes(int l0, int l1, bool first, bool last, int n_tok) const {
+    size_t b = 0;
+    auto add = [&](const std::string & name, int64_t rows_used) {
+        const pi::gguf_tensor * t = file.tensor(name);
+        if (t) b += rows_used < 0 ? t->nbytes : pi::type_row_size(t->type, t->ne[0]) * (size_t) rows_used;
+    };
+    if (first) add("token_embd.weight", n_tok);
+    static const char * names[] = { "attn_norm.weight", "attn_norm.bias", "attn_norm_2.weight", "attn_norm_2.bias", "attn_q.weight", "attn_k.weight", "attn_v.weight",
+                                    "attn_qkv.weight", "attn_output.weight", "ffn_norm.weight", "ffn_gate.weight", "ffn_down.weight", "ffn_up.weight" };
+    for (int il = l0; il < l1; il++) for (const char * n : names) add("blk." + std::to_string(il) + "." + n, -1);
+    if (last) { add("output_norm.weight", -1); add("output_norm.bias", -1); add("output.weight", -1); }
+    return b;
+}
+
+extern "C" struct llama_model * llama_load_model_from_file(const char * path, struct llama_model_params params) {
+    std::unique_ptr<llama_model> m(new llama_model());
+    std::string err;
+    m->path = path;
+    m->device = params.main_gpu;
+    if (!m->file.open(path, err)) { fprintf(stderr, "llama_load_model_from_file: %s\n", err.c_str()); return nullptr; }
+    const pi::gguf_file & f = m->file;
+    const std::string arch = f.get_str("general.architecture", "");
+    pi_hparams & hp = m->hparams;
+    if (arch == "llama") hp.arch = PI_ARCH_LLAMA;
+    else if (arch == "falcon") hp.arch = PI_ARCH_FALCON;
+    else { fprintf(stderr, "llama_load_model_from_file: architecture '%s' is outside this engine's scope (llama, falcon)\n", arch.c_str()); return nullptr; }
+    m->name = f.get_str("general.name", "");
+    hp.n_ctx_train = (int) f.get_u32(arch + ".context_length", 0);
+    hp.n_embd      = (int) f.get_u32(arch + ".embedding_length", 0);
+    hp.n_layer     = (int) f.get_u32(arch + ".block_count", 0);
+    hp.n_ff        = (int) f.get_u32(arch + ".feed_forward_length", 0);
+    hp.n_head      = (int) f.get_u32(arch + ".attention.head_count", 0);
+    hp.n_head_kv   = (int) f.get_u32(arch + ".attention.head_count_kv", (uint32_t) hp.n_head);
+    if (!hp.n_embd || !hp.n_head || !hp.n_layer) { fprintf(stderr, "llama_load_model_from_file: missing hyper-parameters in %s\n", path); return nullptr; }
+    hp.n_rot       = (int) f.get_u32(arch + ".rope.dimension_count", (uint32_t) (hp.n_embd / hp.n_head));
+    hp.f_norm_rms_eps = f.get_f32(arch + ".attention.layer_norm_rms_epsilon", 0.0f);
+    hp.f_norm_eps     = f.get_f32(arch + ".attention.layer_norm_epsilon", 0.0f);
+    hp.rope_freq_base_train = f.get_f32(arch + ".rope.freq_base", 10000.0f);
+    float ropescale = f.get_f32(arch + ".rope.scaling.factor", 0.0f);
+    if (ropescale == 0.0f) ropescale = f.get_f32(arch + ".rope.scale_linear", 0.0f);
+    hp.rope_freq_scale_train = ropescale == 0.0f ? 1.0f : 1.0f / ropescale;
+    if (hp.n_rot != hp.n_embd / hp.n_head) { fprintf(stderr, "llama_load_model_from_file: invalid n_rot %d (expected %d)\n", hp.n_rot, hp.n_embd / hp.n_head); return nullptr; }   // llama.cpp:2269-2273
+    if (hp.head_dim() != 64 && hp.head_dim() != 128) { fprintf(stderr, "llama_load_model_from_file: head_dim %d not supported by the attention kernel\n", hp.head_dim()); return nullptr; }
+    if (!m->vocab.load(f, err)) { fprintf(stderr, "llama_load_model_from_file: %s\n", err.c_str()); return nullptr; }
+    if (hp.n_ff == 0) { const pi::gguf_tensor * t = f.tensor("blk.0.ffn_up.weight"); if (t) hp.n_ff = (int) t->ne[1]; }
+    if (!params.vocab_only) {
+        const pi::gguf_tensor * te = f.tensor("token_embd.weight");
+        if (!te) { fprintf(stderr, "llama_load_model_from_file: no token_embd.weight in %s\n", path); return nullptr; }
+        hp.n_vocab = (int) te->ne[1];
+        m->layers.resize(hp.n_layer);
+    } else {
+        hp.n_vocab = (int) m->vocab.id_to_token.size();
+    }
+    for (const auto & t : f.tensors) { m->n_elements += (uint64_t) (t.ne[0] * t.ne[1] * t.ne[2] * t.ne[3]); m->n_bytes += t.nbytes; }
+    return m.release();
+}
+
+extern "C" void llama_free_model(struct llama_model * model) { delete model; }
+
+extern "C" int llama_n_vocab(const struct llama_model * m) { return m->hparams.n_vocab; }
+extern "C" int llama_n_ctx_train(const struct llama_model * m) { return m->hparams.n_ctx_train; }
+extern "C" int llama_n_embd(const struct llama_model * m) { return m->hparams.n_embd; }
+extern "C" enum llama_vocab_type llama_vocab_type(const struct llama_model * m) { return (enum llama_vocab_type) m->vocab.type; }
+extern "C" uint64_t llama_model_size(const struct llama_model * m) { return m->n_bytes; }
+extern "C" uint64_t llama_model_n_params(const struct llama_model * m) { return m->n_elements; }
+extern "C" int llama_model_desc(const struct llama_model * m, char * buf, size_t n) {
+    return snprintf(buf, n, "%s %s", m->hparams.arch == PI_ARCH_LLAMA ? "llama" : "falcon", m->name.c_str());
+}
+
+extern "C" const char * llama_token_get_text(const struct llama_model * m, llama_token t) { return m->vocab.id_to_token[t].text.c_str(); }
+extern "C" float llama_token_get_score(const struct llama_model * m, llama_token t) { return m->vocab.id_to_token[t].score; }
+extern "C" enum llama_token_type llama_token_get_type(const struct llama_model * m, llama_token t) { return (enum llama_token_type) m->vocab.id_to_token[t].type; }
+extern "C" llama_token llama_token_bos(const struct llama_model * m) { return m->vocab.bos_id; }
+extern "C" llama_token llama_token_eos(const struct llama_model * m) { return m->vocab.eos_id; }
+extern "C" llama_token llama_token_nl(const struct llama_model * m) { return m->vocab.linefeed_id; }
+extern "C" int llama_add_bos_token(const struct llama_model * m) { return m->vocab.add_bos; }
+extern "C" int llama_add_eos_token(const struct llama_model * m) { return m->vocab.add_eos; }
+
+extern "C" int llama_tokenize(const struct llama_model * m, const char * text, int text_len, llama_token * tokens, int n_max, bool add_bos, bool special) {
+    std::vector<int32_t> res;
+    try { res = m->vocab.tokenize(std::string(text, (size_t) text_len), add_bos, special); }
+    catch (const std::exception & e) { fprintf(stderr, "llama_tokenize: %s\n", e.what()); return 0; }
+    if (n_max < (int) res.size()) return -(int) res.size();                  // llama.cpp:10092-10110
+    for (size_t i = 0; i < res.size(); i++) tokens[i] = res[i];
+    return (int) res.size();
+}
+
+extern "C" int llama_token_to_piece(const struct llama_model * m, llama_token token, char * buf, int length) {
+    return m->vocab.token_to_piece(token, buf, length);
+}

@@ -209,21 +209,21 @@ extern "C" void * pi_rope_table_create(int n_pos, int head_dim, float freq_base,
 extern "C" void pi_rope_table_free(void * t_) { pi_rope_table * t = (pi_rope_table *) t_; if (t) { (void) hipFree(t->cs); delete t; } }
 
 // grid (n_tok, n_head + 2*n_head_kv) — one workgroup of hd/2 threads per head vector
-__global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict__ k, const float * __restrict__ v, const int32_t * __restrict__ pos,
-                          const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head,
+__global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict__ k, const float * __restrict__ v, int64_t qs, int64_t ks, int64_t vs,
+                          const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head,
                           uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc) {
     const int t = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;           // i: pair index
     const int n_embd = n_head * hd, n_gqa = n_head_kv * hd;
     if (hh >= n_head + n_head_kv) {                                         // V: plain f32 -> f16 copy into the cache row
         const int h = hh - n_head - n_head_kv;
-        const float * src = v + (int64_t) t * n_gqa + h * hd;
+        const float * src = v + (int64_t) t * vs + h * hd;
         uint16_t * dst = vc + (int64_t) (kv_head + t) * n_gqa + h * hd;
         dst[2 * i] = pi_f2h(src[2 * i]); dst[2 * i + 1] = pi_f2h(src[2 * i + 1]);
         return;
     }
     const bool is_q = hh < n_head;
     const int h = is_q ? hh : hh - n_head;
-    const float * src = is_q ? q + (int64_t) t * n_embd + h * hd : k + (int64_t) t * n_gqa + h * hd;
+    const float * src = is_q ? q + (int64_t) t * qs + h * hd : k + (int64_t) t * ks + h * hd;
     uint16_t * dst = is_q ? q16 + (int64_t) t * n_embd + h * hd : kc + (int64_t) (kv_head + t) * n_gqa + h * hd;
     const float2 c = *(const float2 *) (cs + ((int64_t) pos[t] * (hd / 2) + i) * 2);
     const int i0 = neox ? i : 2 * i, i1 = neox ? i + hd / 2 : 2 * i + 1;
@@ -232,13 +232,14 @@ __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict
     dst[i1] = pi_f2h(x0 * c.y + x1 * c.x);
 }
 
-extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float * v, const int32_t * pos, const void * table_, int neox,
+extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float * v, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                   const int32_t * pos, const void * table_, int neox,
                                    int hd, int n_head, int n_head_kv, int n_tok, int kv_head, uint16_t * q16, uint16_t * kc, uint16_t * vc, void * stream) {
     if (n_tok <= 0) return 0;
     const pi_rope_table * t = (const pi_rope_table *) table_;
     if (t->head_dim != hd) { pi_set_error("pi_op_rope_kv_store: table head_dim %d != %d", t->head_dim, hd); return -1; }
     hipLaunchKernelGGL(k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
-                       q, k, v, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc);
+                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc);
     PI_CHECK_LAUNCH();
     return 0;
 }

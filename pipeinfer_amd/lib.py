@@ -96,7 +96,7 @@ def _declare(lib):
     lib.pi_rope_table_create.restype = vp
     lib.pi_rope_table_create.argtypes = [i32, i32, f32, f32, i32]
     lib.pi_rope_table_free.argtypes = [vp]
-    lib.pi_op_rope_kv_store.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.pi_op_rope_kv_store.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.pi_op_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.pi_op_silu_mul.argtypes = [vp, vp, vp, i64, vp]
     lib.pi_op_gelu.argtypes = [vp, vp, i64, vp]

@@ -1,0 +1,136 @@
+"""-m gpu: the engine behind the llama.h boundary against golden logits produced by the REAL reference kernels
+(tests/golden/*.npz, made by tests/golden/make_golden.py), on the tiny quantised Llama / Falcon fixtures:
+  * every decode of a PipeInfer-style KV script (multi-seq prompt, partition fork, tree batch, accept/prune, cell reuse)
+  * greedy continuation == the reference's (the lossless-speculation ground truth)
+  * the PipeInfer driver's accepted tokens == that same greedy continuation, for several draft models and settings
+Tolerance on logits: 1e-3 absolute (BASELINE.json north_star); measured spread is printed."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15}
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def LL():
+    from pipeinfer_amd import llama as LL
+    from tests import gpu_util as U
+    U.init()
+    return LL
+
+
+class EngineBackend:
+    def __init__(self, LL, stem, n_ctx=128):
+        self.model = LL.Model(os.path.join(GOLD, stem + ".gguf"))
+        self.ctx = LL.Context(self.model, n_ctx=n_ctx, n_batch=64)
+
+    def decode(self, tokens, pos, seq_ids):
+        return self.ctx.decode(tokens, pos, seq_ids)
+
+    def seq_rm(self, *a):
+        self.ctx.seq_rm(*a)
+
+    def seq_cp(self, *a):
+        self.ctx.seq_cp(*a)
+
+    def seq_keep(self, *a):
+        self.ctx.seq_keep(*a)
+
+    def close(self):
+        self.ctx.free(); self.model.free()
+
+
+@pytest.mark.parametrize("stem", list(SEEDS))
+def test_scenario_logits_match_reference(LL, stem):
+    g = np.load(os.path.join(GOLD, stem + ".npz"))
+    b = EngineBackend(LL, stem)
+    outs = S.run_scenario(S.scenario_spec_like(b.model.n_vocab, seed=SEEDS[stem]), b)
+    worst = 0.0
+    for i, lg in enumerate(outs):
+        ref = g[f"spec_like_{i}"]
+        err = float(np.abs(lg - ref).max())
+        worst = max(worst, err)
+        assert err <= LOGIT_TOL, (stem, i, err)
+        assert np.array_equal(lg.argmax(1), ref.argmax(1)), (stem, i)
+    print(f"{stem}: max |logit - reference| over the KV script = {worst:.2e}")
+    b.close()
+
+
+@pytest.mark.parametrize("stem", list(SEEDS))
+def test_greedy_continuation_matches_reference(LL, stem):
+    g = np.load(os.path.join(GOLD, stem + ".npz"))
+    b = EngineBackend(LL, stem)
+    prompt, n_gen = S.scenario_greedy(b.model.n_vocab, seed=SEEDS[stem])
+    lg = b.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
+    assert np.abs(lg - g["greedy_prompt_logits"]).max() <= LOGIT_TOL
+    toks, cur = [], int(np.argmax(lg[-1]))
+    ids, vals, _ = b.ctx.topk(len(prompt) - 1)
+    assert ids[0] == cur                                   # device top-k agrees with the host argmax
+    for i in range(n_gen):
+        toks.append(cur)
+        lg = b.decode([cur], [len(prompt) + i], [[0]])
+        cur = int(np.argmax(lg[0]))
+    assert toks == list(g["greedy_tokens"]), stem
+    assert np.abs(lg - g["greedy_last_logits"]).max() <= LOGIT_TOL
+    b.close()
+
+
+def test_async_decode_and_iprobe(LL):
+    """start/finish split: several runs in flight on the stream, results identical to synchronous decodes"""
+    import time
+    b = EngineBackend(LL, "tiny_llama_q4_k_m")
+    rng = np.random.default_rng(0)
+    toks = [int(x) for x in rng.integers(3, 512, 12)]
+    sync = [b.decode([t], [i], [[0]]) for i, t in enumerate(toks)]
+    b.ctx.kv_clear()
+    tickets = [b.ctx.start([t], [i], [[0]], batch_id=i + 1) for i, t in enumerate(toks)]
+    t0 = time.time()
+    while not b.ctx.iprobe():
+        assert time.time() - t0 < 10
+    outs = [b.ctx.finish(t) for t in tickets]
+    assert not b.ctx.iprobe()                               # nothing in flight any more
+    for a, c in zip(sync, outs):
+        assert np.array_equal(a, c)
+    b.close()
+
+
+def greedy_reference(stem, n_prompt, n_gen):
+    g = np.load(os.path.join(GOLD, stem + ".npz"))
+    prompt, _ = S.scenario_greedy(512, seed=SEEDS[stem], n_prompt=n_prompt)
+    return prompt, list(g["greedy_tokens"][:n_gen])
+
+
+@pytest.mark.parametrize("tgt,dft", [("tiny_llama_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_llama_q4_k_m", "tiny_llama_q4_0"),
+                                      ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0")])
+@pytest.mark.parametrize("n_draft,n_parallel,p_split", [(3, 3, 0.9), (8, 1, 0.9), (4, 3, 0.05)])
+def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split):
+    """accepted-token sequence of the asynchronous speculative driver == the reference target's greedy continuation"""
+    prompt, want = greedy_reference(tgt, 8, 24)
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
+    out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=p_split, ignore_eos=0)
+    assert out[:24] == want, (out, want, res)
+    assert res["n_predict"] >= 24
+    if tgt == dft:
+        assert res["n_accept_clean"] > 0                    # identical draft: speculation is actually being accepted
+    print(tgt, dft, n_draft, n_parallel, {k: res[k] for k in ("n_drafted", "n_accept", "n_accept_clean", "n_drafted_tokens", "n_runs_spec", "n_runs_canceled")})
+    for c in (ct, cd):
+        c.free()
+    for m in (mt, md):
+        m.free()
+
+
+def test_target_only_mode_matches(LL):
+    prompt, want = greedy_reference("tiny_llama_q4_k_m", 8, 24)
+    mt = LL.Model(os.path.join(GOLD, "tiny_llama_q4_k_m.gguf"))
+    ct = LL.Context(mt, n_ctx=256, n_batch=64)
+    out, res = LL.speculative(ct, None, prompt, n_predict=23, mode=2, ignore_eos=0)
+    assert out[:24] == want
+    ct.free(); mt.free()

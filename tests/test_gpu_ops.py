@@ -44,6 +44,7 @@ def gpu_quantize(lib, U, vdt, x):
     q8 = U.Dev(nbytes=lib.pi_q8_nbytes(vdt, k, n_tok))
     from pipeinfer_amd import lib as L
     L.check(lib.pi_op_quantize(vdt, xd.ptr, k, n_tok, q8.ptr, None), "quantize")
+    L.check(lib.pi_stream_sync(None))            # xd is released on return
     return q8
 
 
@@ -165,8 +166,8 @@ def test_get_rows_exact(gpu, t):
         blocks = synth.random_blocks(t, rows * k, rng, 0.05).reshape(rows, -1)
     w = upload_weight(lib, t, rows, k, blocks)
     ids = np.array([0, 49, 7, 7, 13], np.int32)
-    out = U.Dev(nbytes=4 * ids.size * k)
-    L.check(lib.pi_op_get_rows(w, U.Dev(ids).ptr, ids.size, out.ptr, None))
+    out, idd = U.Dev(nbytes=4 * ids.size * k), U.Dev(ids)
+    L.check(lib.pi_op_get_rows(w, idd.ptr, ids.size, out.ptr, None))
     assert np.array_equal(out.get(np.float32, (ids.size, k)).view(np.uint32), o.get_rows(t, blocks, k, rows, ids).view(np.uint32))
     lib.pi_weight_free(w)
 
@@ -207,7 +208,8 @@ def test_rope_kv_store_exact(gpu, neox, hd, n_head, n_head_kv):
     assert table
     g = n_head_kv * hd
     q16, kc, vc = U.Dev(nbytes=2 * q.size), U.Dev(nbytes=2 * n_ctx * g), U.Dev(nbytes=2 * n_ctx * g)
-    L.check(lib.pi_op_rope_kv_store(U.Dev(q).ptr, U.Dev(k).ptr, U.Dev(v).ptr, U.Dev(pos).ptr, table, neox, hd, n_head, n_head_kv, n_tok, kv_head,
+    qd, kd, vd, pd = U.Dev(q), U.Dev(k), U.Dev(v), U.Dev(pos)      # keep the buffers alive across the launch
+    L.check(lib.pi_op_rope_kv_store(qd.ptr, kd.ptr, vd.ptr, n_head * hd, n_head_kv * hd, n_head_kv * hd, pd.ptr, table, neox, hd, n_head, n_head_kv, n_tok, kv_head,
                                     q16.ptr, kc.ptr, vc.ptr, None))
     mode = 2 if neox else 0
     assert np.array_equal(q16.get(np.uint16, q.shape), O.f32_to_f16_bits(o.rope(q, pos, mode)))
@@ -249,9 +251,13 @@ def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
     want = o.attention(kc_o, vc_o, n_ctx, q, kcur, vcur, mask, hd, n_head, n_head_kv, kv_head, n_kv)
     q16 = O.f32_to_f16_bits(q)
     out = U.Dev(nbytes=4 * n_tok * n_head * hd)
-    L.check(lib.pi_op_attention(U.Dev(q16).ptr, U.Dev(k_rows).ptr, U.Dev(v_rows).ptr, U.Dev(mask_bits(mask)).ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None))
+    qd, kd, vd, md = U.Dev(q16), U.Dev(k_rows), U.Dev(v_rows), U.Dev(mask_bits(mask))
+    L.check(lib.pi_op_attention(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None))
     got = out.get(np.float32, want.shape)
-    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    # fp32 summation order moves a score by ~1e-7; where that flips the f16 rounding of (x - max) or of P, one probability
+    # moves by one f16 ulp (2^-11 relative), i.e. up to ~1e-4 absolute on O(1) outputs.  BASELINE tolerance on logits: 1e-3.
+    assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert np.abs(got - want).mean() <= 2e-6
 
 
 def test_elementwise_exact(gpu):
@@ -274,7 +280,8 @@ def test_elementwise_exact(gpu):
     ad, od = U.Dev(allx), U.Dev(nbytes=allx.nbytes)
     L.check(lib.pi_op_gelu(ad.ptr, od.ptr, allx.size, None))
     assert np.array_equal(od.get(np.float32).view(np.uint32), o.gelu(allx).view(np.uint32))
-    L.check(lib.pi_op_silu_mul(ad.ptr, U.Dev(np.ones_like(allx)).ptr, od.ptr, allx.size, None))
+    ones = U.Dev(np.ones_like(allx))
+    L.check(lib.pi_op_silu_mul(ad.ptr, ones.ptr, od.ptr, allx.size, None))
     assert np.array_equal(od.get(np.float32).view(np.uint32), o.silu(allx).view(np.uint32))
 
 
@@ -287,7 +294,8 @@ def test_topk(gpu, n_vocab):
     logits[1, 100] = logits[1, 7] = logits[1].max() + 1.0            # tie for the maximum: lower id first
     logits[2, 5] = -np.inf
     ids, vals, se = U.Dev(nbytes=4 * 3 * 8), U.Dev(nbytes=4 * 3 * 8), U.Dev(nbytes=4 * 3)
-    L.check(lib.pi_op_topk(U.Dev(logits).ptr, n_vocab, 3, 8, ids.ptr, vals.ptr, se.ptr, None))
+    ld = U.Dev(logits)
+    L.check(lib.pi_op_topk(ld.ptr, n_vocab, 3, 8, ids.ptr, vals.ptr, se.ptr, None))
     gi, gv, gs = ids.get(np.int32, (3, 8)), vals.get(np.float32, (3, 8)), se.get(np.float32)
     for t in range(3):
         order = np.lexsort((np.arange(n_vocab), -logits[t]))[:8]
