@@ -146,6 +146,13 @@ int o_model_info(const o_model * m, int what) {
 }
 o_kv_cache * o_model_kv(o_model * m) { return m->kv; }
 
+static void trace(const char * what, int il, const float * x, int n, int n_tok) {
+    if (!getenv("PI_TRACE")) return;
+    fprintf(stderr, "TRACE %d %-8s", il, what);
+    for (int t = 0; t < n_tok; t++) { double s = 0; for (int i = 0; i < n; i++) s += fabs((double) x[(size_t) t * n + i]); fprintf(stderr, " %.6e", s); }
+    fprintf(stderr, "\n");
+}
+
 static void mm(const o_tensor * w, const float * act, int n_tok, float * out) {
     o_mul_mat(w->type, w->data, (int) w->ne[0], (int) w->ne[1], act, n_tok, out);
 }
@@ -198,9 +205,12 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
         const int mode = m->is_falcon ? 2 : 0;
         o_rope(Q, Qr, hd, m->n_head,    n_tok, pos, mode, m->freq_base, 1.0f);
         o_rope(K, Kr, hd, m->n_head_kv, n_tok, pos, mode, m->freq_base, 1.0f);
+        trace("q", il, Q, n_embd, n_tok); trace("k", il, K, n_embd_gqa, n_tok); trace("v", il, V, n_embd_gqa, n_tok);
         o_attention(m->k_cache + il * kv_layer, m->v_cache + il * kv_layer, m->n_ctx, Qr, Kr, V, mask,
                     hd, m->n_head, m->n_head_kv, n_tok, kv_head, n_kv, att);
+        trace("att", il, att, n_embd, n_tok);
         mm(layer_tensor(m, il, "attn_output.weight", 1), att, n_tok, cur);
+        trace("wo", il, cur, n_embd, n_tok);
 
         if (!m->is_falcon) {
             for (size_t i = 0; i < T * n_embd; i++) ffn_inp[i] = cur[i] + inpL[i];
@@ -211,11 +221,14 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
             for (size_t i = 0; i < T * n_ff; i++) gate[i] = gate[i] * up[i];
             mm(layer_tensor(m, il, "ffn_down.weight", 1), gate, n_tok, tmp);
             for (size_t i = 0; i < T * n_embd; i++) inpL[i] = tmp[i] + ffn_inp[i];
+            trace("lout", il, inpL, n_embd, n_tok);
         } else {
             mm(layer_tensor(m, il, "ffn_up.weight", 1), attn_norm, n_tok, up);  // parallel block: MLP consumes attn_norm (llama.cpp:4194)
             o_gelu(up, up, (int) (T * n_ff));
             mm(layer_tensor(m, il, "ffn_down.weight", 1), up, n_tok, tmp);
+            trace("up", il, up, n_ff, n_tok);
             for (size_t i = 0; i < T * n_embd; i++) { const float a = tmp[i] + cur[i]; inpL[i] = a + inpL[i]; }
+            trace("lout", il, inpL, n_embd, n_tok);
         }
     }
     if (m->is_falcon) norm_wb(inpL, cur, n_embd, n_tok, 0, m->eps, find_tensor(m, "output_norm.weight"), find_tensor(m, "output_norm.bias"));

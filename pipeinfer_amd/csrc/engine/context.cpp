@@ -120,6 +120,17 @@ static bool mm(llama_context * ctx, const pi_weight * w, const float * act, int 
     return true;
 }
 
+static void trace(llama_context * ctx, const char * what, int il, const float * x, int64_t n, int n_tok, int64_t stride = 0) {
+    if (!getenv("PI_TRACE")) return;
+    if (!stride) stride = n;
+    std::vector<float> h((size_t) stride * n_tok);
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipMemcpy(h.data(), x, h.size() * 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "TRACE %d %-8s", il, what);
+    for (int t = 0; t < n_tok; t++) { double s = 0; for (int64_t i = 0; i < n; i++) s += std::fabs((double) h[(size_t) t * stride + i]); fprintf(stderr, " %.6e", s); }
+    fprintf(stderr, "\n");
+}
+
 static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
     llama_model * m = ctx->model;
     const pi_hparams & hp = m->hparams;
@@ -138,8 +149,10 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             if (!mm(ctx, L.wq, ctx->nx, n_embd, n_tok, q, nullptr, vdt, src, ctx->q8a)) return false;
             if (!mm(ctx, L.wk, ctx->nx, n_embd, n_tok, k, nullptr, vdt, src, ctx->q8a)) return false;
             if (!mm(ctx, L.wv, ctx->nx, n_embd, n_tok, v, nullptr, vdt, src, ctx->q8a)) return false;
+            trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
             OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, s));
             OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, s));
+            trace(ctx, "att", il, ctx->att, n_embd, n_tok);
             vdt = -1;
             if (!mm(ctx, L.wo, ctx->att, n_embd, n_tok, x2, x, vdt, src, ctx->q8a)) return false;                  // ffn_inp = wo.att + inpSA
             OP_OK(pi_op_norm(x2, L.ffn_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
@@ -149,6 +162,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             OP_OK(pi_op_silu_mul(ctx->gate, ctx->up, ctx->gate, (int64_t) n_tok * n_ff, s));
             vdt = -1;
             if (!mm(ctx, L.ffn_down, ctx->gate, n_ff, n_tok, x, x2, vdt, src, ctx->q8b)) return false;             // l_out = down(..) + ffn_inp
+            trace(ctx, "lout", il, x, n_embd, n_tok);
         } else {
             OP_OK(pi_op_norm(x, L.attn_norm, L.attn_norm_b, ctx->nx, n_embd, n_tok, hp.f_norm_eps, 0, s));          // attn_norm (also feeds the MLP)
             const float * cur = ctx->nx;
@@ -157,15 +171,20 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             if (!mm(ctx, L.wqkv, cur, n_embd, n_tok, ctx->qkv, nullptr, vdt, src, ctx->q8a)) return false;
             OP_OK(pi_op_rope_kv_store(ctx->qkv, ctx->qkv + n_embd, ctx->qkv + n_embd + n_gqa, qw, qw, qw, ctx->pos_dev, ctx->rope, 1, hd, hp.n_head, hp.n_head_kv,
                                       n_tok, kv_head, ctx->q16, kc, vc, s));
+            trace(ctx, "q", il, ctx->qkv, n_embd, n_tok, qw); trace(ctx, "k", il, ctx->qkv + n_embd, n_gqa, n_tok, qw); trace(ctx, "v", il, ctx->qkv + n_embd + n_gqa, n_gqa, n_tok, qw);
             OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, s));
+            trace(ctx, "att", il, ctx->att, n_embd, n_tok);
             vdt = -1;
             if (!mm(ctx, L.wo, ctx->att, n_embd, n_tok, x2, nullptr, vdt, src, ctx->q8a)) return false;             // ffn_inp = attention output
+            trace(ctx, "wo", il, x2, n_embd, n_tok);
             vdt = -1;
             if (!mm(ctx, L.ffn_up, ctx->nx, n_embd, n_tok, ctx->up, nullptr, vdt, src, ctx->q8b)) return false;     // MLP consumes attn_norm (llama.cpp:4194)
             OP_OK(pi_op_gelu(ctx->up, ctx->up, (int64_t) n_tok * n_ff, s));
+            trace(ctx, "up", il, ctx->up, n_ff, n_tok);
             vdt = -1;
             if (!mm(ctx, L.ffn_down, ctx->up, n_ff, n_tok, ctx->att, x2, vdt, src, ctx->q8b)) return false;         // ffn_out + ffn_inp
             OP_OK(pi_op_add(ctx->att, x, x, (int64_t) n_tok * n_embd, s));                                            // + inpL
+            trace(ctx, "lout", il, x, n_embd, n_tok);
         }
     }
     if (ctx->is_last) {
