@@ -67,6 +67,7 @@ struct pipeinfer_spec_params {
     int32_t ignore_eos;      /* --ignore-eos */
     int32_t mode;            /* 0 = PipeInfer (async, continuous speculation), 2 = target only (greedy, no draft model) */
     int32_t max_inflight;    /* cap on target runs in flight (0 = unlimited, the reference behaviour) */
+    int32_t min_spec_iters;  /* speculation iterations to run even when the target is already back (0 = reference behaviour) */
     int32_t verbose;
 };
 struct pipeinfer_spec_result {

@@ -255,13 +255,17 @@ struct driver {
         return false;
     }
 
-    // speculative.cpp:765-844
+    // speculative.cpp:765-844.  min_spec_iters > 0 (our addition, default 0 = reference behaviour) runs that many speculation
+    // iterations even if the oldest target run has already finished — on one fast GPU the target is often back before the
+    // first draft token, and tests need the accept / cancel paths exercised.
     void run_speculation_loop() {
         bool is_waiting = llama_mpi_iprobe(tgt);
-        if (is_waiting) free_offsets.push_back(current.seq_offset);
-        int iter = 0;
+        const int forced = P.min_spec_iters;
+        bool returned_offset = false;
+        if (is_waiting && forced == 0) { free_offsets.push_back(current.seq_offset); returned_offset = true; }
+        int iter = 0, launched = 0;
         float padj;
-        while (!is_waiting && P.p_accept + (padj = p_adjust(iter)) < 1.0f) {
+        while ((!is_waiting || iter < forced) && P.p_accept + (padj = p_adjust(iter)) < 1.0f) {
             if (P.max_inflight > 0 && (int) tgt_runs.size() >= P.max_inflight) break;
             const int orig_offset = current.seq_offset;
             bool should_run_spec = true;
@@ -278,10 +282,17 @@ struct driver {
             if (!should_run_spec) break;
             auto it = std::find(free_offsets.begin(), free_offsets.end(), current.seq_offset);
             if (it != free_offsets.end()) free_offsets.erase(it);
-            if (start_async_spec_run(n_past_tgt, orig_offset, padj)) break;
+            if (start_async_spec_run(n_past_tgt, orig_offset, padj)) { launched = -1; break; }      // (that path already returned the offset)
+            launched++;
             is_waiting = llama_mpi_iprobe(tgt);
             first_run = false;
             iter++;
+        }
+        if (is_waiting && forced > 0 && launched == 0 && !returned_offset &&
+            std::find(free_offsets.begin(), free_offsets.end(), current.seq_offset) == free_offsets.end()) {
+            bool in_use = false;
+            for (const auto & r : tgt_runs) if (r->speculative && r->seq_offset == current.seq_offset) in_use = true;
+            if (!in_use) free_offsets.push_back(current.seq_offset);
         }
     }
 

@@ -24,14 +24,14 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
         case PI_F32: y = ((const float *) w.p0)[row * w.ne0 + e]; break;
         case PI_F16: y = pi_h2f(((const uint16_t *) w.p0)[row * w.ne0 + e]); break;
         case PI_Q4_0: {
-            const int64_t b = row * w.nb + (e >> 5); const int l = (int) (e & 31);
-            const uint8_t q = w.p0[b * 16 + (l & 15)];
+            const int64_t blk = e >> 5, grp = row * w.ng + (blk >> 2); const int bi = (int) (blk & 3), l = (int) (e & 31);
+            const uint8_t q = w.p0[grp * 64 + ((l & 15) >> 2) * 16 + bi * 4 + (l & 3)];        // dword c = byte/4 of the block's 16 quant bytes
             const int x = (l < 16 ? (q & 0xF) : (q >> 4)) - 8;
-            y = x * pi_h2f(((const uint16_t *) w.p1)[b]);
+            y = x * pi_h2f(((const uint16_t *) w.p1)[grp * 4 + bi]);
         } break;
         case PI_Q8_0: {
-            const int64_t b = row * w.nb + (e >> 5);
-            y = (int) ((const int8_t *) w.p0)[b * 32 + (e & 31)] * pi_h2f(((const uint16_t *) w.p1)[b]);
+            const int64_t blk = e >> 5, grp = row * w.ng + (blk >> 2); const int bi = (int) (blk & 3), l = (int) (e & 31);
+            y = (int) ((const int8_t *) w.p0)[grp * 128 + (l >> 2) * 16 + bi * 4 + (l & 3)] * pi_h2f(((const uint16_t *) w.p1)[grp * 4 + bi]);
         } break;
         case PI_Q4_K: case PI_Q5_K: {
             const int ts = w.type == PI_Q4_K ? 144 : 176;
@@ -40,7 +40,8 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
             const float d = pi_h2f(blk[0] | (blk[1] << 8)), mn = pi_h2f(blk[2] | (blk[3] << 8));
             int sc, m; k4_scale_min(s, blk + 4, sc, m);
             const uint8_t * qs = blk + (w.type == PI_Q4_K ? 16 : 48);
-            int q = h ? qs[32 * j + l] >> 4 : qs[32 * j + l] & 0xF;
+            const uint8_t qb = qs[(l >> 2) * 16 + j * 4 + (l & 3)];                               // k-major: lane k = l/4, dword j
+            int q = h ? qb >> 4 : qb & 0xF;
             if (w.type == PI_Q5_K) q += ((blk[16 + l] >> (2 * j + h)) & 1) << 4;
             const float d1 = d * sc, m1 = mn * m;
             y = d1 * q - m1;
@@ -48,11 +49,12 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
         case PI_Q6_K: {
             const int64_t b = row * w.nb + (e >> 8);
             const int ee = (int) (e & 255), n = ee >> 7, g = (ee >> 5) & 3, l = ee & 31;
-            const uint8_t lo = w.p0[b * 128 + 64 * n + 32 * (g & 1) + l];
-            const int q6 = ((g & 2) ? lo >> 4 : lo & 0xF) | (((w.p1[b * 64 + 32 * n + l] >> (2 * g)) & 3) << 4);
+            const uint8_t lo = w.p0[b * 192 + (l >> 2) * 16 + (2 * n + (g & 1)) * 4 + (l & 3)];   // ql[64n + 32(g&1) + l]
+            const uint8_t hb = w.p0[b * 192 + 128 + (l >> 2) * 8 + n * 4 + (l & 3)];               // qh[32n + l]
+            const int q6 = ((g & 2) ? lo >> 4 : lo & 0xF) | (((hb >> (2 * g)) & 3) << 4);
             const int8_t q = (int8_t) (q6 - 32);
-            const float d = pi_h2f(((const uint16_t *) w.p3)[b]);
-            y = d * (float) ((const int8_t *) w.p2)[b * 16 + (ee >> 4)] * (float) q;
+            const float d = pi_h2f(((const uint16_t *) w.p2)[b]);
+            y = d * (float) ((const int8_t *) w.p1)[b * 16 + (ee >> 4)] * (float) q;
         } break;
     }
     out[(int64_t) t * w.ne0 + e] = y;
@@ -141,19 +143,21 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__
         d = 1 / iscale;
     }
     const uint32_t packed = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
-    *(uint32_t *) (qs + (int64_t) t * k + (int64_t) blk * 256 + lane * 4) = packed;
+    // k-major: values 4*lane..4*lane+3 are dword (lane & 7) of 32-group (lane >> 3) -> lane k = lane & 7 keeps 8 consecutive dwords
+    ((uint32_t *) (qs + ((int64_t) t * nb + blk) * 256))[(lane & 7) * 8 + (lane >> 3)] = packed;
     int s = q[0] + q[1] + q[2] + q[3];
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
     if ((lane & 3) == 0) bsums[((int64_t) t * nb + blk) * 16 + (lane >> 2)] = (int16_t) s;
     if (lane == 0) dd[(int64_t) t * nb + blk] = d;
 }
 
-__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, uint16_t * __restrict__ dd) {
+// one wave = 8 blocks of 32 = two groups of 4 blocks; values past k belong to the zero padding of the last group
+__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int64_t ng, uint32_t * __restrict__ qs, uint16_t * __restrict__ dd) {
     const int t = blockIdx.y, lane = threadIdx.x;
     const int64_t e0 = (int64_t) blockIdx.x * 256 + lane * 4;
-    if (e0 >= k) return;                    // k is a multiple of 32, so whole 8-lane groups drop out together
-    const float4 v = *(const float4 *) (x + (int64_t) t * k + e0);
-    const float xs[4] = { v.x, v.y, v.z, v.w };
+    if (e0 >= ng * 128) return;
+    float xs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (e0 < k) { const float4 v = *(const float4 *) (x + (int64_t) t * k + e0); xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w; }
     float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
     amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
     const float d = amax / 127.f;
@@ -161,8 +165,9 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__
     int q[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { int r = __float2int_rn(xs[i] * id); q[i] = r > 127 ? 127 : (r < -128 ? -128 : r); }
-    *(uint32_t *) (qs + (int64_t) t * k + e0) = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
-    if ((lane & 7) == 0) dd[(int64_t) t * (k >> 5) + (e0 >> 5)] = pi_f2h(d);
+    const int64_t blk = e0 >> 5, grp = (int64_t) t * ng + (blk >> 2); const int bi = (int) (blk & 3), kk = lane & 7;
+    qs[(grp * 8 + kk) * 4 + bi] = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
+    if (kk == 0) dd[grp * 4 + bi] = pi_f2h(d);
 }
 
 extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, void * q8, void * stream) {
@@ -175,7 +180,8 @@ extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, vo
         hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob));
     } else if (vdt == PI_Q8_0) {
         if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 needs k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
-        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((k + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (uint16_t *) (base + od));
+        const int64_t ng = (k / 32 + 3) / 4;
+        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((ng * 128 + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, ng, (uint32_t *) (base + oq), (uint16_t *) (base + od));
     } else { pi_set_error("pi_op_quantize: unsupported activation type %d", vdt); return -1; }
     PI_CHECK_LAUNCH();
     return 0;

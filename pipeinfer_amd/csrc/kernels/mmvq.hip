@@ -1,289 +1,292 @@
-// Quantised mat-vec / tiny-batch mat-mat for the decode and verify path (n_tok <= 8 per launch).
+// Quantised mat-vec / tiny-batch mat-mat for the decode and verify path (n_tok <= 8 per launch), BIT-EXACT with the
+// reference's x86 AVX2 arm.
 //
-//   out[t][row] = residual[t][row] + sum_blocks dot(W[row][blk], act[t][blk])
+//   out[t][row] = residual[t][row] + vec_dot(W[row], act[t])
 //
-// Reference: ggml_compute_forward_mul_mat (ggml.c:9388-9597) calling ggml_vec_dot_{q4_K,q5_K,q6_K}_q8_K and
-// ggml_vec_dot_{q4_0,q8_0}_q8_0 (ggml-quants.c:5216, 5864, 6594, 2426, 3521).  The integer part of every block dot
-// product is exact (v_dot4_i32_i8); only the order in which the per-block fp32 terms are added differs from the CPU.
+// Reference: ggml_compute_forward_mul_mat (ggml.c:9388-9597) calling ggml_vec_dot_q4_K_q8_K (ggml-quants.c:5318-5381),
+// q5_K (:5967-6050), q6_K (:6741-6810), q4_0_q8_0 (:2500-2523), q8_0_q8_0 (:3584-3605).  That code keeps EIGHT fp32
+// accumulators per row — lane k owns bytes 4k..4k+3 of every 32-value group — updates each with one fma per block
+// in block order, and folds them with hsum_float_8 (:67-73).  Activation quantisation (Q8_K/Q8_0) and the fp16 paths
+// downstream amplify a 1-ulp difference in these sums into 1e-2 logit differences, so the summation order is part of
+// the contract: this kernel keeps exactly those eight chains.
 //
-// Work decomposition (wave64):
-//   * K-quants: 4 lanes per 256-value super-block, so one wave spans 16 super-blocks (4096 values) of a row with
-//     three 16-byte loads per lane (header / two quant slices), all 16-byte aligned.
-//   * Q4_0/Q8_0: one lane per 32-value block, a wave spans 64 blocks (2048 values).
-//   * Rows longer than one wave span are split over NKW "K-waves" of the workgroup whose partial sums meet in LDS.
-//     Rows shorter than a span pack several rows into one wave (LPR lanes per row).
-//   * Each lane keeps ITS slice of the quantised activations of all NT tokens in registers for the whole launch and
-//     streams weight rows past them: weights are read exactly once from HBM, activations once per wave from L2.
+// Mapping (wave64): a wave is 8 rows x 8 lanes; lane (r, k) IS accumulator lane k of row r.  It walks the row's blocks in
+// order; the k-major weight layout (ops_common.h) gives it its share of a block with one 16-byte load, and the block's
+// integer sub-sums are exact (v_dot4_i32_i8).  The quantised activations of the tile of blocks in flight are staged in LDS
+// once per workgroup (all rows and lanes re-read them; 8 of every 64 lanes hit distinct banks, the rest broadcast).
+// Weights are streamed from HBM exactly once, straight into registers.
 #include "ops_common.h"
+
+#define MMVQ_TILE 16            // K-quant super-blocks (or groups of four 32-blocks) staged in LDS per step
 
 struct mmvq_args {
     pi_weight w;
-    const int8_t *  aq;       // [n_tok][K]
-    const void *    ad;       // Q8_K: f32 [n_tok][K/256]   Q8_0: f16 [n_tok][K/32]
-    const int16_t * abs_;     // Q8_K: [n_tok][K/16]
-    float *         out;      // [n_tok][M]
-    const float *   res;      // nullable
-    int M, K;
-    int nkw;                  // K-waves per row
-    int nrg;                  // row groups (waves along rows) per workgroup
-    int rpw;                  // rows per wave (multiple of rows-per-iteration)
-    int lpr;                  // lanes per row (<= 64, power of two)
+    const uint8_t * aq;         // activation planes (pi_q8_layout)
+    const uint8_t * ad;
+    const uint8_t * abs_;
+    float *         out;        // [n_tok][M]
+    const float *   res;        // nullable
+    int M, K, nb;               // nb: super-blocks (K-quants) or groups of 4 blocks (Q4_0/Q8_0) per row
 };
 
-template <int TYPE> struct qtraits;
-template <> struct qtraits<PI_Q4_K> { static constexpr int LPB = 4, NY = 16, KQ = 1; };   // lanes per block, act dwords per lane, K-quant?
-template <> struct qtraits<PI_Q5_K> { static constexpr int LPB = 4, NY = 16, KQ = 1; };
-template <> struct qtraits<PI_Q6_K> { static constexpr int LPB = 4, NY = 16, KQ = 1; };
-template <> struct qtraits<PI_Q4_0> { static constexpr int LPB = 1, NY = 8,  KQ = 0; };
-template <> struct qtraits<PI_Q8_0> { static constexpr int LPB = 1, NY = 8,  KQ = 0; };
+static __device__ __forceinline__ int bytes_sub(int v, int c) {            // per-byte v - c for bytes whose result fits int8 (no borrow across bytes)
+    return (int) ((((uint32_t) v | 0x80808080u) - (uint32_t) c) ^ 0x80808080u);
+}
+static __device__ __forceinline__ int ub(uint32_t w, int i) { return (int) ((w >> (8 * i)) & 0xff); }
 
-// per-lane activation slice of one token
-template <int TYPE> struct act_slice {
-    int   y[qtraits<TYPE>::NY];
-    float d;
-    int   s[4];               // type specific sums (see load)
-};
-
-template <int TYPE>
-static __device__ __forceinline__ void load_act(act_slice<TYPE> & a, const mmvq_args & g, int t, int64_t gb, int part) {
-    if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
-        // part j: values 64j .. 64j+63 (sub-blocks 2j, 2j+1)
-        const int4 * p = (const int4 *) (g.aq + (int64_t) t * g.K + gb * 256 + part * 64);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const int4 v = p[i]; a.y[4 * i] = v.x; a.y[4 * i + 1] = v.y; a.y[4 * i + 2] = v.z; a.y[4 * i + 3] = v.w; }
-        a.d = ((const float *) g.ad)[(int64_t) t * (g.K >> 8) + gb];
-        const short4 b = *(const short4 *) (g.abs_ + ((int64_t) t * (g.K >> 8) + gb) * 16 + part * 4);
-        a.s[0] = (int) (short) (b.x + b.y);           // the reference adds the pair in int16 (_mm_hadd_epi16)
-        a.s[1] = (int) (short) (b.z + b.w);
-    } else if constexpr (TYPE == PI_Q6_K) {
-        // part = 2n + hl: four runs of 16 values at 128n + 32g + 16hl, g = 0..3; scale index of run g = 8n + 2g + hl
-        const int n = part >> 1, hl = part & 1;
-        const int8_t * base = g.aq + (int64_t) t * g.K + gb * 256 + 128 * n + 16 * hl;
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int4 v = *(const int4 *) (base + 32 * r); a.y[4 * r] = v.x; a.y[4 * r + 1] = v.y; a.y[4 * r + 2] = v.z; a.y[4 * r + 3] = v.w; }
-        a.d = ((const float *) g.ad)[(int64_t) t * (g.K >> 8) + gb];
-        const int16_t * bs = g.abs_ + ((int64_t) t * (g.K >> 8) + gb) * 16 + 8 * n + hl;
-#pragma unroll
-        for (int r = 0; r < 4; r++) a.s[r] = bs[2 * r];
-    } else {
-        const int4 * p = (const int4 *) (g.aq + (int64_t) t * g.K + gb * 32);
-        const int4 v0 = p[0], v1 = p[1];
-        a.y[0] = v0.x; a.y[1] = v0.y; a.y[2] = v0.z; a.y[3] = v0.w; a.y[4] = v1.x; a.y[5] = v1.y; a.y[6] = v1.z; a.y[7] = v1.w;
-        a.d = pi_h2f(((const uint16_t *) g.ad)[(int64_t) t * (g.K >> 5) + gb]);
-        int sum = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) sum = pi_dot4(a.y[i], 0x01010101, sum);
-        a.s[0] = sum;
-    }
+// folds the 8 lanes of a row exactly like hsum_float_8: (a4+a0, a5+a1, a6+a2, a7+a3) -> (r0+r2, r1+r3) -> s0+s1
+static __device__ __forceinline__ float hsum8_lanes(float a) {
+    a = a + __shfl_xor(a, 4, 64);
+    a = a + __shfl_xor(a, 2, 64);
+    a = a + __shfl_xor(a, 1, 64);
+    return a;
 }
 
-// per-lane weight slice of one row
-template <int TYPE> struct w_slice { int4 a, b, c, d, e; uint16_t dh; };
-
-template <int TYPE>
-static __device__ __forceinline__ void load_w(w_slice<TYPE> & s, const pi_weight & w, int64_t row, int64_t gb, int part) {
-    if constexpr (TYPE == PI_Q4_K) {
-        const uint8_t * blk = w.p0 + (row * w.nb + gb) * 144;
-        s.a = *(const int4 *) blk;                                  // d, dmin, scales[12]
-        s.b = *(const int4 *) (blk + 16 + 32 * part);
-        s.c = *(const int4 *) (blk + 32 + 32 * part);
-    } else if constexpr (TYPE == PI_Q5_K) {
-        const uint8_t * blk = w.p0 + (row * w.nb + gb) * 176;
-        s.a = *(const int4 *) blk;
-        s.d = *(const int4 *) (blk + 16);                           // qh[0..15]
-        s.e = *(const int4 *) (blk + 32);                           // qh[16..31]
-        s.b = *(const int4 *) (blk + 48 + 32 * part);
-        s.c = *(const int4 *) (blk + 64 + 32 * part);
-    } else if constexpr (TYPE == PI_Q6_K) {
-        const int64_t b = row * w.nb + gb;
-        const int n = part >> 1, hl = part & 1;
-        s.a = *(const int4 *) (w.p0 + b * 128 + 64 * n + 16 * hl);        // ql, groups 0 (low nibble) and 2 (high)
-        s.b = *(const int4 *) (w.p0 + b * 128 + 64 * n + 32 + 16 * hl);   // ql, groups 1 and 3
-        s.c = *(const int4 *) (w.p1 + b * 64 + 32 * n + 16 * hl);         // qh
-        s.d = *(const int4 *) (w.p2 + b * 16);                            // 16 int8 scales
-        s.dh = ((const uint16_t *) w.p3)[b];
-    } else if constexpr (TYPE == PI_Q4_0) {
-        const int64_t b = row * w.nb + gb;
-        s.a = *(const int4 *) (w.p0 + b * 16);
-        s.dh = ((const uint16_t *) w.p1)[b];
-    } else {
-        const int64_t b = row * w.nb + gb;
-        s.a = *(const int4 *) (w.p0 + b * 32);
-        s.b = *(const int4 *) (w.p0 + b * 32 + 16);
-        s.dh = ((const uint16_t *) w.p1)[b];
-    }
-}
-
-static __device__ __forceinline__ int byte_of(const int4 & v, int i) {      // i in 0..15, runtime
-    const int wsel = i >> 2;
-    const uint32_t word = wsel == 0 ? (uint32_t) v.x : wsel == 1 ? (uint32_t) v.y : wsel == 2 ? (uint32_t) v.z : (uint32_t) v.w;
-    return (word >> (8 * (i & 3))) & 0xff;
-}
-
-// 6-bit scale/min of sub-block `is` (get_scale_min_k4, ggml-quants.c:1446-1453); hdr bytes 4..15 are scales[0..11]
-static __device__ __forceinline__ void k4_unpack(const int4 & hdr, int is, int & sc, int & m) {
-    if (is < 4) { sc = byte_of(hdr, 4 + is) & 63; m = byte_of(hdr, 8 + is) & 63; }
-    else {
-        const int hi = byte_of(hdr, 8 + is);                        // scales[is + 4]
-        sc = (hi & 0xF) | ((byte_of(hdr, is) >> 6) << 4);           // scales[is - 4]  (hdr byte 4 + is - 4)
-        m  = (hi >> 4)  | ((byte_of(hdr, 4 + is) >> 6) << 4);       // scales[is]
-    }
-}
-
-template <int TYPE>
-static __device__ __forceinline__ float dot_slice(const w_slice<TYPE> & s, const act_slice<TYPE> & a, int part) {
-    if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
-        int sc0, m0, sc1, m1;
-        k4_unpack(s.a, 2 * part, sc0, m0);
-        k4_unpack(s.a, 2 * part + 1, sc1, m1);
-        const int q[8] = { s.b.x, s.b.y, s.b.z, s.b.w, s.c.x, s.c.y, s.c.z, s.c.w };
-        int lo = 0, hi = 0;
-        if constexpr (TYPE == PI_Q4_K) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                lo = pi_dot4(q[i] & 0x0F0F0F0F, a.y[i], lo);
-                hi = pi_dot4((q[i] >> 4) & 0x0F0F0F0F, a.y[8 + i], hi);
-            }
-        } else {
-            const int h[8] = { s.d.x, s.d.y, s.d.z, s.d.w, s.e.x, s.e.y, s.e.z, s.e.w };
-            const int sh = 2 * part;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int hb = (int) ((uint32_t) h[i] >> sh);
-                lo = pi_dot4((q[i] & 0x0F0F0F0F) | ((hb & 0x01010101) << 4), a.y[i], lo);
-                hi = pi_dot4(((q[i] >> 4) & 0x0F0F0F0F) | (((hb >> 1) & 0x01010101) << 4), a.y[8 + i], hi);
-            }
-        }
-        const int isum = sc0 * lo + sc1 * hi;
-        const int msum = m0 * a.s[0] + m1 * a.s[1];
-        const float d    = pi_h2f((uint16_t) (s.a.x & 0xffff)) * a.d;
-        const float dmin = pi_h2f((uint16_t) ((uint32_t) s.a.x >> 16)) * a.d;
-        return d * (float) isum - dmin * (float) msum;
-    } else if constexpr (TYPE == PI_Q6_K) {
-        const int n = part >> 1, hl = part & 1;
-        const int l1[4] = { s.a.x, s.a.y, s.a.z, s.a.w }, l2[4] = { s.b.x, s.b.y, s.b.z, s.b.w }, qh[4] = { s.c.x, s.c.y, s.c.z, s.c.w };
-        int dg[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t h = (uint32_t) qh[i];
-            dg[0] = pi_dot4((l1[i] & 0x0F0F0F0F)        | (int) ((h & 0x03030303u) << 4),        a.y[i],      dg[0]);
-            dg[1] = pi_dot4((l2[i] & 0x0F0F0F0F)        | (int) (((h >> 2) & 0x03030303u) << 4), a.y[4 + i],  dg[1]);
-            dg[2] = pi_dot4(((l1[i] >> 4) & 0x0F0F0F0F) | (int) (((h >> 4) & 0x03030303u) << 4), a.y[8 + i],  dg[2]);
-            dg[3] = pi_dot4(((l2[i] >> 4) & 0x0F0F0F0F) | (int) (((h >> 6) & 0x03030303u) << 4), a.y[12 + i], dg[3]);
-        }
-        int isum = 0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int sc = (int) (int8_t) byte_of(s.d, 8 * n + 2 * r + hl);
-            isum += sc * (dg[r] - 32 * a.s[r]);
-        }
-        return (pi_h2f(s.dh) * a.d) * (float) isum;
-    } else if constexpr (TYPE == PI_Q4_0) {
-        const int q[4] = { s.a.x, s.a.y, s.a.z, s.a.w };
-        int isum = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            isum = pi_dot4(q[i] & 0x0F0F0F0F, a.y[i], isum);
-            isum = pi_dot4((q[i] >> 4) & 0x0F0F0F0F, a.y[4 + i], isum);
-        }
-        isum -= 8 * a.s[0];
-        return (pi_h2f(s.dh) * a.d) * (float) isum;
-    } else {
-        const int q[8] = { s.a.x, s.a.y, s.a.z, s.a.w, s.b.x, s.b.y, s.b.z, s.b.w };
-        int isum = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) isum = pi_dot4(q[i], a.y[i], isum);
-        return (pi_h2f(s.dh) * a.d) * (float) isum;
-    }
-}
-
+// ================================================================================================================
+// K-quants x Q8_K
+// ================================================================================================================
 template <int TYPE, int NT>
-__global__ void __launch_bounds__(qtraits<TYPE>::KQ ? 512 : 1024) k_mmvq(const mmvq_args g) {
-    extern __shared__ float lds[];                       // [nrg][nkw][rpw][NT] partial sums when nkw > 1
-    constexpr int LPB = qtraits<TYPE>::LPB;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int kw = wave % g.nkw, rg = wave / g.nkw;
-    const int rpi = 64 / g.lpr;                          // rows per wave iteration
-    const int sub = lane / g.lpr, l = lane % g.lpr;
-    const int blk = l / LPB, part = l % LPB;
-    const int64_t gb = (int64_t) kw * (64 / LPB) + blk;  // block index within the row
-    const bool live = gb < g.w.nb;
+__global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // LDS tile: qs [NT][TILE][256] | d [NT][TILE] f32 | bsums [NT][TILE][16] i16
+    uint8_t * l_qs = lds;
+    float   * l_d  = (float *) (lds + (size_t) NT * MMVQ_TILE * 256);
+    int16_t * l_bs = (int16_t *) ((uint8_t *) l_d + (size_t) NT * MMVQ_TILE * 4);
 
-    act_slice<TYPE> act[NT];
-    if (live) {
-#pragma unroll
-        for (int t = 0; t < NT; t++) load_act<TYPE>(act[t], g, t, gb, part);
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, k = lane & 7;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
+    const bool live = row < g.M;
+    const int nb = g.nb;
 
-    const int64_t row0 = ((int64_t) blockIdx.x * g.nrg + rg) * g.rpw;
-    for (int it = 0; it < g.rpw; it += rpi) {
-        const int64_t row = row0 + it + sub;
-        float acc[NT];
+    float acc[NT], accm[NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = 0.0f;
-        if (live && row < g.M) {
-            w_slice<TYPE> ws;
-            load_w<TYPE>(ws, g.w, row, gb, part);
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = dot_slice<TYPE>(ws, act[t], part);
+    for (int t = 0; t < NT; t++) { acc[t] = 0.0f; accm[t] = 0.0f; }
+
+    for (int b0 = 0; b0 < nb; b0 += MMVQ_TILE) {
+        const int nbt = min(MMVQ_TILE, nb - b0);
+        __syncthreads();
+        // ---- stage the activations of blocks [b0, b0+nbt) for all NT tokens ----
+        for (int u = tid; u < NT * nbt * 16; u += blockDim.x) {                 // 16-byte units of qs
+            const int t = u / (nbt * 16), rem = u % (nbt * 16);
+            *(uint4 *) (l_qs + ((size_t) t * MMVQ_TILE * 256) + rem * 16) = *(const uint4 *) (g.aq + ((size_t) t * nb + b0) * 256 + (size_t) rem * 16);
         }
+        for (int u = tid; u < NT * nbt; u += blockDim.x) {
+            const int t = u / nbt, b = u % nbt;
+            l_d[t * MMVQ_TILE + b] = ((const float *) g.ad)[(size_t) t * nb + b0 + b];
+        }
+        for (int u = tid; u < NT * nbt * 2; u += blockDim.x) {                  // 16-byte units of bsums (32 B per block)
+            const int t = u / (nbt * 2), rem = u % (nbt * 2);
+            *(uint4 *) ((uint8_t *) l_bs + ((size_t) t * MMVQ_TILE * 32) + rem * 16) = *(const uint4 *) (g.abs_ + ((size_t) t * nb + b0) * 32 + (size_t) rem * 16);
+        }
+        __syncthreads();
+        if (!live) continue;
+
+#pragma unroll 2
+        for (int bi = 0; bi < nbt; bi++) {
+            const int64_t blk = row * nb + b0 + bi;
+            float dx, dminx = 0.0f;
+            uint32_t scA = 0, scB = 0, mA = 0, mB = 0;
+            int q[4], qx[2] = { 0, 0 };
+            uint4 sc6 = { 0, 0, 0, 0 };
+            if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
+                constexpr int BS = TYPE == PI_Q4_K ? 144 : 176, QOFF = TYPE == PI_Q4_K ? 16 : 48;
+                const uint8_t * p = g.w.p0 + blk * BS;
+                const uint4 hdr = *(const uint4 *) p;
+                const uint4 qv = *(const uint4 *) (p + QOFF + 16 * k);
+                q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+                if constexpr (TYPE == PI_Q5_K) qx[0] = *(const int *) (p + 16 + 4 * k);
+                dx = pi_h2f((uint16_t) (hdr.x & 0xffff)); dminx = pi_h2f((uint16_t) (hdr.x >> 16));
+                // 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:1446-1453) unpacked four at a time like the reference's utmp[]
+                scA = hdr.y & 0x3f3f3f3fu;
+                mA  = hdr.z & 0x3f3f3f3fu;
+                scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
+                mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
+            } else {
+                const uint8_t * p = g.w.p0 + blk * 192;
+                const uint4 qv = *(const uint4 *) (p + 16 * k);
+                q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+                const uint2 hv = *(const uint2 *) (p + 128 + 8 * k);
+                qx[0] = hv.x; qx[1] = hv.y;
+                sc6 = *(const uint4 *) (g.w.p1 + blk * 16);
+                dx = pi_h2f(((const uint16_t *) g.w.p2)[blk]);
+            }
+            // token-independent unpacking of this lane's 32 weights (8 dwords, in the order the activations are stored)
+            int wq[8];
+            if constexpr (TYPE == PI_Q4_K) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = pi_lanes_sum_rt(acc[t], g.lpr);
-        if (l == 0 && row < g.M) {
-            if (g.nkw == 1) {
+                for (int j = 0; j < 4; j++) { wq[2 * j] = q[j] & 0x0F0F0F0F; wq[2 * j + 1] = (q[j] >> 4) & 0x0F0F0F0F; }
+            } else if constexpr (TYPE == PI_Q5_K) {
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int64_t o = (int64_t) t * g.M + row;
-                    g.out[o] = g.res ? g.res[o] + acc[t] : acc[t];
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t h = (uint32_t) qx[0] >> (2 * j);
+                    wq[2 * j]     = (q[j] & 0x0F0F0F0F)        | (int) ((h & 0x01010101u) << 4);
+                    wq[2 * j + 1] = ((q[j] >> 4) & 0x0F0F0F0F) | (int) (((h >> 1) & 0x01010101u) << 4);
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < NT; t++) lds[(((rg * g.nkw + kw) * g.rpw) + it + sub) * NT + t] = acc[t];
+                for (int n = 0; n < 2; n++) {
+                    const uint32_t h = (uint32_t) qx[n];
+                    const int la = q[2 * n], lb = q[2 * n + 1];
+                    wq[4 * n + 0] = bytes_sub((la & 0x0F0F0F0F)        | (int) ((h & 0x03030303u) << 4),        0x20202020);
+                    wq[4 * n + 1] = bytes_sub((lb & 0x0F0F0F0F)        | (int) (((h >> 2) & 0x03030303u) << 4), 0x20202020);
+                    wq[4 * n + 2] = bytes_sub(((la >> 4) & 0x0F0F0F0F) | (int) (((h >> 4) & 0x03030303u) << 4), 0x20202020);
+                    wq[4 * n + 3] = bytes_sub(((lb >> 4) & 0x0F0F0F0F) | (int) (((h >> 6) & 0x03030303u) << 4), 0x20202020);
+                }
+            }
+            int sc[8];
+            if constexpr (TYPE == PI_Q6_K) {
+                const uint32_t s4[4] = { sc6.x, sc6.y, sc6.z, sc6.w };
+                const int hi = k >> 2;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {                                   // i = 4n + g: scale index 8n + 2g + hi
+                    const int idx = 8 * (i >> 2) + 2 * (i & 3);
+                    sc[i] = (int) (int8_t) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xff);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { sc[i] = ub(scA, i); sc[4 + i] = ub(scB, i); }
+            }
+            int m0 = 0, m1 = 0;
+            if constexpr (TYPE != PI_Q6_K) {
+                const uint32_t mw = (k & 2) ? mB : mA;
+                const int sh = (k & 1) * 16;
+                m0 = (int) ((mw >> sh) & 0xff); m1 = (int) ((mw >> (sh + 8)) & 0xff);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint4 y0 = *(const uint4 *) (l_qs + ((size_t) t * MMVQ_TILE + bi) * 256 + 32 * k);
+                const uint4 y1 = *(const uint4 *) (l_qs + ((size_t) t * MMVQ_TILE + bi) * 256 + 32 * k + 16);
+                const int y[8] = { (int) y0.x, (int) y0.y, (int) y0.z, (int) y0.w, (int) y1.x, (int) y1.y, (int) y1.z, (int) y1.w };
+                const float dy = l_d[t * MMVQ_TILE + bi];
+                int sumi = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) sumi += sc[i] * pi_dot4(wq[i], y[i], 0);
+                acc[t] = fmaf(dy * dx, (float) sumi, acc[t]);
+                if constexpr (TYPE != PI_Q6_K) {
+                    // mins: lanes 0..3 own prod[k] = m[2k]*(bsums[4k]+bsums[4k+1]) + m[2k+1]*(bsums[4k+2]+bsums[4k+3])   (int16 pair sums like _mm_hadd_epi16)
+                    const short4 bs = *(const short4 *) (l_bs + ((size_t) t * MMVQ_TILE + bi) * 16 + 4 * (k & 3));
+                    int prod = m0 * (int) (short) (bs.x + bs.y) + m1 * (int) (short) (bs.z + bs.w);
+                    const float dmin = -dy * dminx;
+                    if constexpr (TYPE == PI_Q4_K) {
+                        accm[t] = fmaf(dmin, (float) prod, accm[t]);           // used from lanes 0..3 only
+                    } else {
+                        prod += __shfl_xor(prod, 1, 64); prod += __shfl_xor(prod, 2, 64);      // lanes 0..3 of the row hold the total
+                        accm[t] = accm[t] + dmin * (float) prod;               // summs += dmin * hsum (mul, then add)
+                    }
+                }
             }
         }
     }
-    if (g.nkw > 1) {
-        __syncthreads();
-        const int n_out = g.nrg * g.rpw * NT;
-        for (int i = threadIdx.x; i < n_out; i += blockDim.x) {
-            const int t = i % NT, r = (i / NT) % g.rpw, rgi = i / (NT * g.rpw);
-            const int64_t row = ((int64_t) blockIdx.x * g.nrg + rgi) * g.rpw + r;
-            if (row >= g.M) continue;
-            float s = 0.0f;
-            for (int k = 0; k < g.nkw; k++) s += lds[(((rgi * g.nkw + k) * g.rpw) + r) * NT + t];
+    // ---- fold the eight chains ----
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        float v = hsum8_lanes(acc[t]);
+        if constexpr (TYPE == PI_Q4_K) {
+            float mv = (k < 4) ? accm[t] : 0.0f;
+            mv = mv + __shfl_xor(mv, 2, 64);                                    // (m0+m2, m1+m3)
+            mv = mv + __shfl_xor(mv, 1, 64);                                    // (m0+m2) + (m1+m3)
+            v = v + mv;
+        } else if constexpr (TYPE == PI_Q5_K) {
+            v = v + accm[t];
+        }
+        if (live && k == 0) {
             const int64_t o = (int64_t) t * g.M + row;
-            g.out[o] = g.res ? g.res[o] + s : s;
+            g.out[o] = g.res ? g.res[o] + v : v;
         }
     }
 }
 
-static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+// ================================================================================================================
+// Q4_0 / Q8_0 x Q8_0: lane (r, k) walks groups of four 32-blocks
+// ================================================================================================================
+template <int TYPE, int NT>
+__global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // LDS tile: qs [NT][TILE groups][128] | d [NT][TILE][4] f16
+    uint8_t * l_qs = lds;
+    uint16_t * l_d = (uint16_t *) (lds + (size_t) NT * MMVQ_TILE * 128);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, k = lane & 7;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
+    const bool live = row < g.M;
+    const int ng = g.nb;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = 0.0f;
+
+    for (int g0 = 0; g0 < ng; g0 += MMVQ_TILE) {
+        const int ngt = min(MMVQ_TILE, ng - g0);
+        __syncthreads();
+        for (int u = tid; u < NT * ngt * 8; u += blockDim.x) {
+            const int t = u / (ngt * 8), rem = u % (ngt * 8);
+            *(uint4 *) (l_qs + ((size_t) t * MMVQ_TILE * 128) + rem * 16) = *(const uint4 *) (g.aq + ((size_t) t * ng + g0) * 128 + (size_t) rem * 16);
+        }
+        for (int u = tid; u < NT * ngt; u += blockDim.x) {
+            const int t = u / ngt, gi = u % ngt;
+            *(uint2 *) (l_d + ((size_t) t * MMVQ_TILE + gi) * 4) = *(const uint2 *) (g.ad + ((size_t) t * ng + g0 + gi) * 8);
+        }
+        __syncthreads();
+        if (!live) continue;
+#pragma unroll 2
+        for (int gi = 0; gi < ngt; gi++) {
+            const int64_t grp = row * ng + g0 + gi;
+            uint4 xv;
+            if constexpr (TYPE == PI_Q4_0) xv = *(const uint4 *) (g.w.p0 + grp * 64 + 16 * (k & 3));
+            else                           xv = *(const uint4 *) (g.w.p0 + grp * 128 + 16 * k);
+            const uint2 dv = *(const uint2 *) (g.w.p1 + grp * 8);
+            const uint32_t x4[4] = { xv.x, xv.y, xv.z, xv.w };
+            int xs[4]; float dx[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if constexpr (TYPE == PI_Q4_0) xs[b] = bytes_sub((int) (((k & 4) ? (x4[b] >> 4) : x4[b]) & 0x0F0F0F0Fu), 0x08080808);
+                else                           xs[b] = (int) x4[b];
+                dx[b] = pi_h2f((uint16_t) (((b < 2 ? dv.x : dv.y) >> (16 * (b & 1))) & 0xffff));
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint4 yv = *(const uint4 *) (l_qs + ((size_t) t * MMVQ_TILE + gi) * 128 + 16 * k);
+                const uint2 dyv = *(const uint2 *) (l_d + ((size_t) t * MMVQ_TILE + gi) * 4);
+                const int y4[4] = { (int) yv.x, (int) yv.y, (int) yv.z, (int) yv.w };
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const float dy = pi_h2f((uint16_t) (((b < 2 ? dyv.x : dyv.y) >> (16 * (b & 1))) & 0xffff));
+                    acc[t] = fmaf(dx[b] * dy, (float) pi_dot4(xs[b], y4[b], 0), acc[t]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float v = hsum8_lanes(acc[t]);
+        if (live && k == 0) {
+            const int64_t o = (int64_t) t * g.M + row;
+            g.out[o] = g.res ? g.res[o] + v : v;
+        }
+    }
+}
 
 template <int TYPE, int NT>
-static int launch_mmvq(mmvq_args & g, hipStream_t stream) {
-    constexpr int LPB = qtraits<TYPE>::LPB;
-    const int span = 64 / LPB;                                   // blocks per wave
-    const int nb = (int) g.w.nb;
-    if (nb >= span) { g.nkw = (nb + span - 1) / span; g.lpr = 64; }
-    else            { g.nkw = 1; g.lpr = LPB * next_pow2(nb); }
-    constexpr int MAX_KW = qtraits<TYPE>::KQ ? 8 : 16;          // K-quants keep 19 act dwords/token in VGPRs: 512 threads max
-    if (g.nkw > MAX_KW) { pi_set_error("pi_op_mul_mat: K=%d too long for one workgroup (nkw=%d)", g.K, g.nkw); return -1; }
-    const int rpi = 64 / g.lpr;
-    g.nrg = g.nkw >= 4 ? 1 : (g.nkw >= 2 ? 2 : 4);               // 4..8 waves per workgroup (more for very long rows)
-    // rows per wave: keep ~2-4k waves in the launch (256 CUs x 8-16 resident waves), at least one iteration
-    int rpw = rpi;
-    while ((int64_t) g.M * g.nkw / ((int64_t) (rpw / rpi) * 2) >= 2048 && rpw < 16 * rpi) rpw *= 2;
-    g.rpw = rpw;
-    const int rows_per_wg = g.nrg * g.rpw;
-    const unsigned grid = (unsigned) ((g.M + rows_per_wg - 1) / rows_per_wg);
-    const size_t lds = g.nkw > 1 ? (size_t) g.nrg * g.nkw * g.rpw * NT * sizeof(float) : 0;
-    hipLaunchKernelGGL((k_mmvq<TYPE, NT>), dim3(grid), dim3(64 * g.nkw * g.nrg), lds, stream, g);
+static int launch_mmvq(const mmvq_args & g, hipStream_t stream) {
+    // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
+    int wpb = 1;
+    while (wpb < 4 && (int64_t) g.M / (8 * wpb * 2) >= 512) wpb *= 2;
+    const unsigned grid = (unsigned) ((g.M + 8 * wpb - 1) / (8 * wpb));
+    const int tile = g.nb < MMVQ_TILE ? g.nb : MMVQ_TILE;
+    (void) tile;
+    if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
+        const size_t lds = (size_t) NT * MMVQ_TILE * (128 + 8);
+        hipLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+    } else {
+        const size_t lds = (size_t) NT * MMVQ_TILE * (256 + 4 + 32);
+        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+    }
     PI_CHECK_LAUNCH();
     return 0;
 }
 
 template <int TYPE>
-static int dispatch_nt(mmvq_args & g, int nt, hipStream_t stream) {
+static int dispatch_nt(const mmvq_args & g, int nt, hipStream_t stream) {
     switch (nt) {
         case 1: return launch_mmvq<TYPE, 1>(g, stream);
         case 2: return launch_mmvq<TYPE, 2>(g, stream);
@@ -306,16 +309,19 @@ extern "C" int pi_op_mul_mat(const pi_weight * w, const void * q8, int n_tok, fl
     pi_q8_layout(vdt, w->ne0, n_tok, &oq, &od, &ob);
     const uint8_t * base = (const uint8_t *) q8;
     const int64_t K = w->ne0, M = w->ne1;
-    for (int t0 = 0; t0 < n_tok; t0 += 8) {                   // verify batches are <= 8 wide; prompts loop over chunks
+    const int64_t nbq = vdt == PI_Q8_K ? K / 256 : w->ng;
+    for (int t0 = 0; t0 < n_tok; t0 += 8) {                   // verify batches are <= 8 wide; prompts loop over chunks of 8
         const int nt = n_tok - t0 < 8 ? n_tok - t0 : 8;
         mmvq_args g;
         g.w = *w;
-        g.aq = (const int8_t *) (base + oq) + (int64_t) t0 * K;
-        g.ad = vdt == PI_Q8_K ? (const void *) ((const float *) (base + od) + (int64_t) t0 * (K / 256)) : (const void *) ((const uint16_t *) (base + od) + (int64_t) t0 * (K / 32));
-        g.abs_ = vdt == PI_Q8_K ? (const int16_t *) (base + ob) + (int64_t) t0 * (K / 16) : nullptr;
+        g.M = (int) M; g.K = (int) K; g.nb = (int) nbq;
+        if (vdt == PI_Q8_K) {
+            g.aq = base + oq + (size_t) t0 * nbq * 256; g.ad = base + od + (size_t) t0 * nbq * 4; g.abs_ = base + ob + (size_t) t0 * nbq * 32;
+        } else {
+            g.aq = base + oq + (size_t) t0 * nbq * 128; g.ad = base + od + (size_t) t0 * nbq * 8; g.abs_ = nullptr;
+        }
         g.out = out + (int64_t) t0 * M;
         g.res = res ? res + (int64_t) t0 * M : nullptr;
-        g.M = (int) M; g.K = (int) K;
         int rc = -1;
         switch (w->type) {
             case PI_Q4_K: rc = dispatch_nt<PI_Q4_K>(g, nt, stream); break;

@@ -8,16 +8,22 @@
 #include "../../../include/pipeinfer_ops.h"
 #include "pi_device.h"
 
-// A weight matrix in HBM.  Layouts (all planes 16-byte aligned, total bytes == ggml_nbytes):
-//   Q4_K / Q5_K / F32 / F16 : native ggml rows (144 B / 176 B super-blocks are multiples of 16 B already)
-//   Q6_K (210 B blocks, 2-byte aligned in GGUF) : four planes  ql[rows][nb*128] | qh[rows][nb*64] | scales[rows][nb*16] | d[rows][nb] f16
-//   Q4_0 (18 B) : qs[rows][nb*16] | d[rows][nb] f16          Q8_0 (34 B) : qs[rows][nb*32] | d[rows][nb] f16
+// A weight matrix in HBM.  Bytes are only re-ordered at load time (never changed) so that lane k of an 8-lane row group —
+// the lane that owns bytes 4k..4k+3 of every 32-value group, exactly like lane k of the reference's AVX2 accumulators —
+// reads its share of a block with one or two 16-byte loads ("k-major" layouts):
+//   Q4_K (144 B)  [d,dmin,scales 16 B][qs: 8 lanes x 16 B]            lane k: dword j = original qs[32j + 4k .. +3], j = 0..3
+//   Q5_K (176 B)  [hdr 16 B][qh 32 B natural][qs: 8 lanes x 16 B]     same qs permutation; lane k also reads qh[4k .. +3]
+//   Q6_K (210 B)  p0: [blocks][192 B] = [8 lanes][16 B: ql[4k], ql[32+4k], ql[64+4k], ql[96+4k]] + [8 lanes][8 B: qh[4k], qh[32+4k]]   p1: scales [blocks][16]   p2: d [blocks] f16
+//   Q4_0 (18 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][4 dwords c][4 blocks b]   p1: d [groups][4] f16
+//   Q8_0 (34 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][8 lanes k][4 blocks b]    p1: d [groups][4] f16
+//   F32 / F16     native rows
 struct pi_weight {
     int      type;
     int64_t  ne0, ne1;     // K (contiguous), rows
     int64_t  nb;           // blocks per row
+    int64_t  ng;           // Q4_0/Q8_0: groups of 4 blocks per row (ceil(nb/4))
     void *   base;         // allocation
-    size_t   nbytes;
+    size_t   nbytes;       // == ggml_nbytes of the tensor (padding of Q4_0/Q8_0 tails not counted)
     const uint8_t * p0, * p1, * p2, * p3;
 };
 

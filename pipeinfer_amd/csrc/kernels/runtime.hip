@@ -103,29 +103,45 @@ extern "C" int pi_memset(void * dst, int v, size_t n, void * stream) { PI_CHECK_
 extern "C" int pi_stream_sync(void * stream) { PI_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream)); return 0; }
 
 // ---- weight upload + re-layout ------------------------------------------------------------------------------------
-// one thread per block: split the GGUF block into the planes (bytes are only moved, never changed)
-__global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * ql, uint8_t * qh, uint8_t * sc, uint16_t * d, int64_t nblocks) {
+// one thread per source block; bytes are moved into the k-major layouts of ops_common.h
+__global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t nblocks, int bsize, int qs_off) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks) return;
-    const uint8_t * b = src + i * 210;
-    for (int k = 0; k < 128; k++) ql[i * 128 + k] = b[k];
-    for (int k = 0; k < 64; k++)  qh[i * 64 + k]  = b[128 + k];
-    for (int k = 0; k < 16; k++)  sc[i * 16 + k]  = b[192 + k];
+    const uint8_t * s = src + i * bsize; uint8_t * d = dst + i * bsize;
+    for (int b = 0; b < qs_off; b++) d[b] = s[b];
+    const uint32_t * sq = (const uint32_t *) (s + qs_off); uint32_t * dq = (uint32_t *) (d + qs_off);
+    for (int k = 0; k < 8; k++) for (int j = 0; j < 4; j++) dq[k * 4 + j] = sq[j * 8 + k];
+}
+__global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint16_t * d, int64_t nblocks) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint8_t * b = src + i * 210;                       // 2-byte aligned only: assemble dwords from bytes
+    auto ld = [&](int off) { return (uint32_t) b[off] | (uint32_t) b[off + 1] << 8 | (uint32_t) b[off + 2] << 16 | (uint32_t) b[off + 3] << 24; };
+    uint32_t * o = (uint32_t *) (a + i * 192);                // [8 lanes][4 dwords of ql] then [8 lanes][2 dwords of qh]
+    for (int k = 0; k < 8; k++) {
+        o[k * 4 + 0] = ld(4 * k); o[k * 4 + 1] = ld(32 + 4 * k); o[k * 4 + 2] = ld(64 + 4 * k); o[k * 4 + 3] = ld(96 + 4 * k);
+        o[32 + k * 2 + 0] = ld(128 + 4 * k); o[32 + k * 2 + 1] = ld(160 + 4 * k);
+    }
+    for (int k = 0; k < 16; k++) sc[i * 16 + k] = b[192 + k];
     d[i] = (uint16_t) (b[208] | (b[209] << 8));
 }
-__global__ void k_repack_q4_0(const uint8_t * __restrict__ src, uint8_t * qs, uint16_t * d, int64_t nblocks) {
+__global__ void k_repack_q4_0(const uint8_t * __restrict__ src, uint32_t * qs, uint16_t * d, int64_t rows, int64_t nb, int64_t ng) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblocks) return;
+    if (i >= rows * nb) return;
+    const int64_t row = i / nb, blk = i % nb, g = blk >> 2, bi = blk & 3;
     const uint8_t * b = src + i * 18;
-    d[i] = (uint16_t) (b[0] | (b[1] << 8));
-    for (int k = 0; k < 16; k++) qs[i * 16 + k] = b[2 + k];
+    d[(row * ng + g) * 4 + bi] = (uint16_t) (b[0] | (b[1] << 8));
+    for (int c = 0; c < 4; c++)
+        qs[((row * ng + g) * 4 + c) * 4 + bi] = (uint32_t) b[2 + 4 * c] | (uint32_t) b[3 + 4 * c] << 8 | (uint32_t) b[4 + 4 * c] << 16 | (uint32_t) b[5 + 4 * c] << 24;
 }
-__global__ void k_repack_q8_0(const uint8_t * __restrict__ src, uint8_t * qs, uint16_t * d, int64_t nblocks) {
+__global__ void k_repack_q8_0(const uint8_t * __restrict__ src, uint32_t * qs, uint16_t * d, int64_t rows, int64_t nb, int64_t ng) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblocks) return;
+    if (i >= rows * nb) return;
+    const int64_t row = i / nb, blk = i % nb, g = blk >> 2, bi = blk & 3;
     const uint8_t * b = src + i * 34;
-    d[i] = (uint16_t) (b[0] | (b[1] << 8));
-    for (int k = 0; k < 32; k++) qs[i * 32 + k] = b[2 + k];
+    d[(row * ng + g) * 4 + bi] = (uint16_t) (b[0] | (b[1] << 8));
+    for (int k = 0; k < 8; k++)
+        qs[((row * ng + g) * 8 + k) * 4 + bi] = (uint32_t) b[2 + 4 * k] | (uint32_t) b[3 + 4 * k] << 8 | (uint32_t) b[4 + 4 * k] << 16 | (uint32_t) b[5 + 4 * k] << 24;
 }
 
 extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host, void * stream_) {
@@ -134,37 +150,39 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     if (!tsz || type == PI_Q8_K) { pi_set_error("pi_weight_upload: unsupported tensor type %d", type); return nullptr; }
     if (ne0 % blck) { pi_set_error("pi_weight_upload: ne0=%lld not a multiple of the block size %d", (long long) ne0, blck); return nullptr; }
     pi_weight * w = new pi_weight();
-    w->type = type; w->ne0 = ne0; w->ne1 = ne1; w->nb = ne0 / blck;
+    w->type = type; w->ne0 = ne0; w->ne1 = ne1; w->nb = ne0 / blck; w->ng = (w->nb + 3) / 4;
     const int64_t nblocks = w->nb * ne1;
     w->nbytes = (size_t) nblocks * tsz;
-    if (hipMalloc(&w->base, w->nbytes + 256) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", w->nbytes); delete w; return nullptr; }
+    const bool small = type == PI_Q4_0 || type == PI_Q8_0;
+    const size_t alloc = small ? (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32) + (size_t) ne1 * w->ng * 8 + 512 : w->nbytes + 512;
+    if (hipMalloc(&w->base, alloc) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", alloc); delete w; return nullptr; }
     uint8_t * base = (uint8_t *) w->base;
     w->p0 = base; w->p1 = w->p2 = w->p3 = nullptr;
-    const bool planar = type == PI_Q6_K || type == PI_Q4_0 || type == PI_Q8_0;
-    if (!planar) {
-        if (hipMemcpyAsync(base, host, w->nbytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
-            pi_set_error("pi_weight_upload: H2D copy failed"); (void) hipFree(w->base); delete w; return nullptr;
-        }
+    auto fail = [&](const char * what) { pi_set_error("pi_weight_upload: %s", what); (void) hipFree(w->base); delete w; return (pi_weight *) nullptr; };
+    if (type == PI_F32 || type == PI_F16) {
+        if (hipMemcpyAsync(base, host, w->nbytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail("H2D copy failed");
         return w;
     }
     uint8_t * staging = nullptr;
-    if (hipMalloc((void **) &staging, w->nbytes) != hipSuccess) { pi_set_error("pi_weight_upload: staging hipMalloc failed"); (void) hipFree(w->base); delete w; return nullptr; }
+    if (hipMalloc((void **) &staging, w->nbytes) != hipSuccess) return fail("staging hipMalloc failed");
     (void) hipMemcpyAsync(staging, host, w->nbytes, hipMemcpyHostToDevice, stream);
     const int threads = 256;
     const unsigned grid = (unsigned) ((nblocks + threads - 1) / threads);
-    if (type == PI_Q6_K) {
-        w->p1 = base + nblocks * 128; w->p2 = w->p1 + nblocks * 64; w->p3 = w->p2 + nblocks * 16;
-        hipLaunchKernelGGL(k_repack_q6_K, dim3(grid), dim3(threads), 0, stream, staging, base, (uint8_t *) w->p1, (uint8_t *) w->p2, (uint16_t *) w->p3, nblocks);
-    } else if (type == PI_Q4_0) {
-        w->p1 = base + nblocks * 16;
-        hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, base, (uint16_t *) w->p1, nblocks);
+    if (type == PI_Q4_K) hipLaunchKernelGGL(k_repack_k45, dim3(grid), dim3(threads), 0, stream, staging, base, nblocks, 144, 16);
+    else if (type == PI_Q5_K) hipLaunchKernelGGL(k_repack_k45, dim3(grid), dim3(threads), 0, stream, staging, base, nblocks, 176, 48);
+    else if (type == PI_Q6_K) {
+        w->p1 = base + nblocks * 192; w->p2 = w->p1 + nblocks * 16;
+        hipLaunchKernelGGL(k_repack_q6_K, dim3(grid), dim3(threads), 0, stream, staging, base, (uint8_t *) w->p1, (uint16_t *) w->p2, nblocks);
     } else {
-        w->p1 = base + nblocks * 32;
-        hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, base, (uint16_t *) w->p1, nblocks);
+        const size_t qbytes = (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32);
+        w->p1 = base + ((qbytes + 255) & ~(size_t) 255);
+        (void) hipMemsetAsync(base, 0, alloc, stream);                    // zero blocks pad the last group of every row
+        if (type == PI_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
+        else                 hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
     }
     const hipError_t e = hipStreamSynchronize(stream);
     (void) hipFree(staging);
-    if (e != hipSuccess) { pi_set_error("pi_weight_upload: repack failed: %s", hipGetErrorString(e)); (void) hipFree(w->base); delete w; return nullptr; }
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
     return w;
 }
 
@@ -183,9 +201,14 @@ extern "C" int pi_vec_dot_type(int t) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t) 255; }
 
+// Device layout of quantised activations (k-major, mirrors the weight layouts):
+//   Q8_K: qs [n_tok][K/256][8 lanes k][8 dwords = (j, lo/hi)]   byte of value e: k*32 + ((e>>6)*2 + ((e>>5)&1))*4 + (e&3), k = (e&31)>>2
+//         d  [n_tok][K/256] f32       bsums [n_tok][K/256][16] int16
+//   Q8_0: qs [n_tok][groups of 4 blocks][8 lanes k][4 blocks b] dwords (zero padded)     d [n_tok][groups][4] f16
 extern "C" void pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size_t * off_d, size_t * off_bsums) {
-    const size_t qs = align256((size_t) n_tok * k);
-    const size_t d  = vdt == PI_Q8_K ? align256((size_t) n_tok * (k / 256) * 4) : align256((size_t) n_tok * (k / 32) * 2);
+    size_t qs, d;
+    if (vdt == PI_Q8_K) { qs = align256((size_t) n_tok * k); d = align256((size_t) n_tok * (k / 256) * 4); }
+    else { const size_t ng = (size_t) (k / 32 + 3) / 4; qs = align256((size_t) n_tok * ng * 128); d = align256((size_t) n_tok * ng * 8); }
     if (off_qs) *off_qs = 0;
     if (off_d) *off_d = qs;
     if (off_bsums) *off_bsums = qs + d;

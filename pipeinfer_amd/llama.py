@@ -32,7 +32,7 @@ class llama_context_params(C.Structure):
 class pipeinfer_spec_params(C.Structure):
     _fields_ = [("n_predict", C.c_int32), ("n_draft", C.c_int32), ("n_parallel", C.c_int32), ("p_accept", C.c_float), ("p_split", C.c_float),
                 ("p_recovery", C.c_float), ("p_decay", C.c_float), ("temp", C.c_float), ("ignore_eos", C.c_int32), ("mode", C.c_int32),
-                ("max_inflight", C.c_int32), ("verbose", C.c_int32)]
+                ("max_inflight", C.c_int32), ("min_spec_iters", C.c_int32), ("verbose", C.c_int32)]
 
 
 class pipeinfer_spec_result(C.Structure):

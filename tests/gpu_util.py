@@ -49,21 +49,29 @@ def init():
 
 
 def q8_planes(lib, vdt, k, n_tok, dev):
-    """read back the activation planes -> (qs int8 [n_tok,k], d, bsums)"""
+    """read back the device activation planes (k-major, see pi_q8_layout) and undo the permutation
+    -> (qs int8 [n_tok,k] in natural order, d, bsums)"""
     oq, od, ob = C.c_size_t(), C.c_size_t(), C.c_size_t()
     lib.pi_q8_layout(vdt, k, n_tok, C.byref(oq), C.byref(od), C.byref(ob))
-    qs = dev.get(np.int8, (n_tok, k), oq.value, n_tok * k)
     if vdt == 15:
-        d = dev.get(np.float32, (n_tok, k // 256), od.value, n_tok * (k // 256))
+        nb = k // 256
+        raw = dev.get(np.int8, (n_tok, nb, 8, 4, 2, 4), oq.value, n_tok * k)            # [k][j][lo/hi][byte]
+        qs = raw.transpose(0, 1, 3, 4, 2, 5).reshape(n_tok, k)                          # value e = 64j + 32h + 4k + byte
+        d = dev.get(np.float32, (n_tok, nb), od.value, n_tok * nb)
         bs = dev.get(np.int16, (n_tok, k // 16), ob.value, n_tok * (k // 16))
         return qs, d, bs
-    d = dev.get(np.uint16, (n_tok, k // 32), od.value, n_tok * (k // 32))
+    nb = k // 32
+    ng = (nb + 3) // 4
+    raw = dev.get(np.int8, (n_tok, ng, 8, 4, 4), oq.value, n_tok * ng * 128)            # [group][k][block][byte]
+    qs = raw.transpose(0, 1, 3, 2, 4).reshape(n_tok, ng * 128)[:, :k]
+    d = dev.get(np.uint16, (n_tok, ng * 4), od.value, n_tok * ng * 4)[:, :nb]
     return qs, d, None
 
 
 def q8_as_ref_blocks(vdt, qs, d, bs):
     """re-assemble the reference block format (block_q8_K 292 B / block_q8_0 34 B) for byte comparison"""
     n_tok, k = qs.shape
+    qs = np.ascontiguousarray(qs); d = np.ascontiguousarray(d)
     if vdt == 15:
         nb = k // 256
         out = np.zeros((n_tok, nb, 292), np.uint8)

@@ -1,6 +1,10 @@
 """-m gpu: every hot-path HIP operator, called through the C ABI (include/pipeinfer_ops.h), against the oracle on the same
-seeded inputs and against the committed golden vectors.  Integer/byte results must be identical; fp32 results within the
-tolerance written at each assert (BASELINE.json: logits within 1e-3; the per-operator bounds here are far tighter)."""
+seeded inputs and against the committed golden vectors (outputs of the real reference kernels).
+
+The bar here is BIT-EXACT, fp32 included: the mat-vec and attention kernels keep the reference AVX2 arm's accumulation order
+(eight fp32 lanes per row, fma per block in block order, hsum tree), because f16 rounding and Q8 activation quantisation
+downstream amplify a 1-ulp difference into 1e-2 logit differences.  Only the norms (double-precision sums in a different
+order) carry a tolerance, stated at the assert."""
 import ctypes as C
 import os
 
@@ -94,17 +98,16 @@ def test_mul_mat_golden_blocks(gpu, t):
     rows, k = blocks.shape[0], act.shape[1]
     w = upload_weight(lib, t, rows, k, blocks)
     got = gpu_mul_mat(lib, U, t, w, k, rows, act)
-    scale = np.abs(dots).max()
-    assert np.abs(got - dots).max() <= 1e-5 * scale, np.abs(got - dots).max() / scale
+    assert np.array_equal(got.view(np.uint32), dots.view(np.uint32))          # same fp32 bits as the reference's vec_dot
     lib.pi_weight_free(w)
 
 
 @pytest.mark.parametrize("t", QTYPES)
-@pytest.mark.parametrize("k,rows", [(256, 37), (768, 64), (1024, 100), (2048, 256), (4096, 515), (11008, 96), (28672, 40)])
-@pytest.mark.parametrize("n_tok", [1, 2, 3, 5, 8, 11])
+@pytest.mark.parametrize("k,rows,n_tok", [(256, 37, 3), (768, 64, 1), (1024, 100, 8), (2048, 256, 2), (4096, 515, 1), (4096, 515, 5), (11008, 96, 11),
+                                          (28672, 40, 8), (11008, 96, 1), (4544, 71, 4), (18176, 24, 2), (256, 1024, 7), (512, 8, 6)])
 def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
-    if (k, rows, n_tok) not in {(256, 37, 3), (768, 64, 1), (1024, 100, 8), (2048, 256, 2), (4096, 515, 1), (4096, 515, 5), (11008, 96, 11), (28672, 40, 8), (11008, 96, 1)}:
-        pytest.skip("sampled grid")
+    if k % O.BLCK[t]:
+        pytest.skip("K-quants need K % 256 == 0")
     lib, U = gpu
     o = O.Impl("oracle")
     rng = np.random.default_rng(k + rows + n_tok)
@@ -114,11 +117,9 @@ def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
     w = upload_weight(lib, t, rows, k, blocks)
     want = o.mul_mat(t, blocks, k, rows, act)
     got = gpu_mul_mat(lib, U, t, w, k, rows, act)
-    scale = np.abs(want).max()
-    err = np.abs(got - want).max() / scale
-    assert err <= 2e-5, err                                    # fp32 summation-order spread only
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
     got_r = gpu_mul_mat(lib, U, t, w, k, rows, act, residual=res)
-    assert np.abs(got_r - (res + want)).max() / scale <= 2e-5
+    assert np.array_equal(got_r.view(np.uint32), (res + want).view(np.uint32))
     lib.pi_weight_free(w)
 
 
@@ -229,7 +230,8 @@ def mask_bits(mask):
     return np.packbits(bits.reshape(n_tok, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(n_tok, words)
 
 
-@pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok", [(128, 8, 8, 45, 3), (64, 32, 4, 70, 2), (64, 71, 1, 33, 1), (128, 64, 8, 300, 9), (64, 8, 2, 1024, 4)])
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok", [(128, 8, 8, 45, 3), (64, 32, 4, 70, 2), (64, 71, 1, 33, 1), (128, 64, 8, 300, 9), (64, 8, 2, 1024, 4),
+                                                             (64, 4, 1, 32, 7), (64, 4, 4, 32, 8), (128, 32, 32, 256, 1), (128, 16, 2, 97, 5), (64, 4, 2, 64, 16)])
 def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
     lib, U = gpu
     from pipeinfer_amd import lib as L
@@ -254,10 +256,7 @@ def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
     qd, kd, vd, md = U.Dev(q16), U.Dev(k_rows), U.Dev(v_rows), U.Dev(mask_bits(mask))
     L.check(lib.pi_op_attention(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None))
     got = out.get(np.float32, want.shape)
-    # fp32 summation order moves a score by ~1e-7; where that flips the f16 rounding of (x - max) or of P, one probability
-    # moves by one f16 ulp (2^-11 relative), i.e. up to ~1e-4 absolute on O(1) outputs.  BASELINE tolerance on logits: 1e-3.
-    assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
-    assert np.abs(got - want).mean() <= 2e-6
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()      # vec_dot_f16 order + exact soft-max sum
 
 
 def test_elementwise_exact(gpu):
