@@ -109,16 +109,19 @@ def greedy_reference(stem, n_prompt, n_gen):
 
 @pytest.mark.parametrize("tgt,dft", [("tiny_llama_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_llama_q4_k_m", "tiny_llama_q4_0"),
                                       ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0")])
-@pytest.mark.parametrize("n_draft,n_parallel,p_split", [(3, 3, 0.9), (8, 1, 0.9), (4, 3, 0.05)])
-def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split):
-    """accepted-token sequence of the asynchronous speculative driver == the reference target's greedy continuation"""
+@pytest.mark.parametrize("n_draft,n_parallel,p_split,min_spec", [(3, 3, 0.9, 0), (3, 3, 0.9, 1), (8, 1, 0.9, 2), (4, 3, 0.05, 3)])
+def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split, min_spec):
+    """accepted-token sequence of the asynchronous speculative driver == the reference target's greedy continuation.
+    min_spec > 0 forces speculation iterations even when the (tiny, fast) target is already back, so that the draft tree,
+    accept/prune, continuous speculation and cancel paths all run."""
     prompt, want = greedy_reference(tgt, 8, 24)
     mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
     ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
-    out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=p_split, ignore_eos=0)
+    out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=p_split, ignore_eos=0,
+                              min_spec_iters=min_spec)
     assert out[:24] == want, (out, want, res)
     assert res["n_predict"] >= 24
-    if tgt == dft:
+    if tgt == dft and min_spec > 0:
         assert res["n_accept_clean"] > 0                    # identical draft: speculation is actually being accepted
     print(tgt, dft, n_draft, n_parallel, {k: res[k] for k in ("n_drafted", "n_accept", "n_accept_clean", "n_drafted_tokens", "n_runs_spec", "n_runs_canceled")})
     for c in (ct, cd):
