@@ -43,6 +43,11 @@ PI_API int     pi_memcpy_h2d(void * dst_dev, const void * src, size_t bytes, voi
 PI_API int     pi_memcpy_d2h(void * dst, const void * src_dev, size_t bytes, void * stream);
 PI_API int     pi_memset(void * dst_dev, int value, size_t bytes, void * stream);
 PI_API int     pi_stream_sync(void * stream);
+PI_API int     pi_device_sync(void);
+
+/* sampled per-launch timing of the quantised mat-vec kernels (HIP events on the launch stream around every Nth launch) */
+PI_API void    pi_kernel_timing(int on, int sample_every);
+PI_API int     pi_kernel_timing_report(int weight_type, int n_tok, double * avg_us, double * avg_bytes, uint64_t * n_sampled, uint64_t * n_launches);
 
 /* host_blocks: ne1 rows of ne0 elements in the GGUF/ggml block format of `type` (row-major, rows contiguous) */
 PI_API pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host_blocks, void * stream);
@@ -60,6 +65,10 @@ PI_API void    pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size
 PI_API int pi_op_get_rows(const pi_weight * w, const int32_t * tokens_dev, int n_tok, float * out_dev, void * stream);
 PI_API int pi_op_norm(const float * x_dev, const float * w_dev, const float * b_dev, float * y_dev, int n, int n_tok, float eps, int rms, void * stream);
 PI_API int pi_op_quantize(int vdt, const float * x_dev, int64_t k, int n_tok, void * q8_dev, void * stream);
+/* fusions of the above (same arithmetic, same rounding points): norm -> quantised planes (y_f32_dev nullable: also keep the fp32 result);
+ * which = 0: silu(gate) * up, 1: gelu(gate) -> quantised planes */
+PI_API int pi_op_norm_quantize(const float * x_dev, const float * w_dev, const float * b_dev, float * y_f32_dev, int n, int n_tok, float eps, int rms, int vdt, void * q8_dev, void * stream);
+PI_API int pi_op_act_quantize(const float * gate_dev, const float * up_dev, int which, int64_t n, int n_tok, int vdt, void * q8_dev, void * stream);
 /* out[t][row] = (residual ? residual[t][row] : 0) + W[row] . act[t]      out/residual: f32 [n_tok][ne1] */
 PI_API int pi_op_mul_mat(const pi_weight * w, const void * q8_dev, int n_tok, float * out_dev, const float * residual_dev, void * stream);
 
@@ -72,14 +81,18 @@ PI_API void    pi_rope_table_free(void * table);
 PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const float * v_dev, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                                const int32_t * pos_dev, const void * rope_table,
                                int neox, int head_dim, int n_head, int n_head_kv, int n_tok, int kv_head,
-                               uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, void * stream);
-/* mask_dev: uint32 bitmap [n_tok][ceil(n_kv/32)], bit i set <=> cell i visible to the token; out f32 [n_tok][n_head*hd] */
+                               uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, const int32_t * dyn_dev, void * stream);
+/* mask_dev: uint32 bitmap [n_tok][ceil(n_kv/32)], bit i set <=> cell i visible to the token; out f32 [n_tok][n_head*hd].
+ * dyn_dev (nullable): int32 {kv_head, n_kv} in device memory that overrides the scalar arguments at run time, so that a
+ * captured HIP graph can be replayed for every call (n_kv then only sizes LDS and the mask row stride). */
 PI_API int pi_op_attention(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
-                           int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, void * stream);
+                           int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, const int32_t * dyn_dev, void * stream);
+PI_API int pi_op_attention_reserve(int head_dim, int n_kv_max);   /* once per context, outside graph capture: LDS limit for long contexts */
 PI_API int pi_op_silu_mul(const float * gate_dev, const float * up_dev, float * out_dev, int64_t n, void * stream);
 PI_API int pi_op_gelu(const float * x_dev, float * out_dev, int64_t n, void * stream);
 PI_API int pi_op_add(const float * a_dev, const float * b_dev, float * out_dev, int64_t n, void * stream);
 /* per token: ids/logits of the k largest (logit desc, id asc), max logit and sum_i expf(l_i - max) over the full vocab */
+PI_API int pi_op_topk_reserve(int n_tok_max);                       /* once, outside graph capture */
 PI_API int pi_op_topk(const float * logits_dev, int n_vocab, int n_tok, int k, int32_t * ids_dev, float * vals_dev, float * sumexp_dev, void * stream);
 
 #ifdef __cplusplus

@@ -25,7 +25,8 @@ llama_context::~llama_context() {
         if (r->meta_host) (void) hipHostFree(r->meta_host);
         delete r;
     }
-    void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, tokens_dev, pos_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev };
+    for (auto & kv : graphs) if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
+    void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, q8c, tokens_dev, pos_dev, dyn_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev };
     for (void * b : bufs) pi_free(b);
     if (rope) pi_rope_table_free(rope);
     if (stream) (void) hipStreamDestroy(stream);
@@ -71,8 +72,10 @@ bool context_prepare(llama_context * ctx, std::string & err) {
     if (!(ctx->x = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->x2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->nx = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->nx2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->qkv = (float *) dev((size_t) 4 * nb * qkv_w)) || !(ctx->att = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->up = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->gate = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->q16 = (uint16_t *) dev((size_t) 2 * nb * n_embd)) ||
-        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)))
+        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev(64)))
         return false;
+    ctx->use_graphs = getenv("PI_NO_GRAPHS") == nullptr;
+    if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0 || pi_op_topk_reserve(nb) != 0) { err = pi_last_error(); return false; }
     ctx->mask_cap_words = (size_t) nb * ((ctx->n_ctx + 31) / 32);
     if (!(ctx->mask_dev = (uint32_t *) dev(ctx->mask_cap_words * 4))) return false;
     if (ctx->is_last) {
@@ -109,17 +112,9 @@ static pi_run * acquire_run(llama_context * ctx, int n_tokens, size_t meta_bytes
 }
 
 // ---- the forward pass of this stage: layers [l0, l1) ----------------------------------------------------------------------
-static bool mm(llama_context * ctx, const pi_weight * w, const float * act, int k, int n_tok, float * out, const float * res, int & cur_vdt, const float * & cur_src, void * q8) {
-    // quantise the activations once per (source, type); consecutive mat-muls that share both reuse the buffer (as ggml's INIT does per op)
-    const int vdt = pi_vec_dot_type(pi_weight_type(w));
-    if (vdt != cur_vdt || act != cur_src) {
-        OP_OK(pi_op_quantize(vdt, act, k, n_tok, q8, ctx->stream));
-        cur_vdt = vdt; cur_src = act;
-    }
-    OP_OK(pi_op_mul_mat(w, q8, n_tok, out, res, ctx->stream));
-    return true;
-}
-
+// Kernel sequence per Llama layer (10 launches + attention):
+//   norm+quant -> wq, wk, wv -> rope+KV store -> attention -> quant -> wo(+residual) -> norm+quant -> up, gate -> silu*up+quant -> down(+residual)
+// The fused launches compute exactly what the reference's separate graph nodes compute (same fp32 rounding points).
 static void trace(llama_context * ctx, const char * what, int il, const float * x, int64_t n, int n_tok, int64_t stride = 0) {
     if (!getenv("PI_TRACE")) return;
     if (!stride) stride = n;
@@ -129,6 +124,14 @@ static void trace(llama_context * ctx, const char * what, int il, const float * 
     fprintf(stderr, "TRACE %d %-8s", il, what);
     for (int t = 0; t < n_tok; t++) { double s = 0; for (int64_t i = 0; i < n; i++) s += std::fabs((double) h[(size_t) t * stride + i]); fprintf(stderr, " %.6e", s); }
     fprintf(stderr, "\n");
+}
+
+static int vdt_of(const pi_weight * w) { return pi_vec_dot_type(pi_weight_type(w)); }
+
+// norm(x) (* w + b) quantised for the given consumers into q8; falls back to fp32 + per-type quantisation when they disagree
+static bool norm_for(llama_context * ctx, const float * x, const float * w, const float * b, int n, int n_tok, float eps, int rms, int vdt, void * q8) {
+    OP_OK(pi_op_norm_quantize(x, w, b, nullptr, n, n_tok, eps, rms, vdt, q8, ctx->stream));
+    return true;
 }
 
 static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
@@ -142,56 +145,58 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
     for (int il = ctx->l0; il < ctx->l1; il++) {
         const pi_layer & L = m->layers[il];
         uint16_t * kc = ctx->k_cache + (size_t) (il - ctx->l0) * kv_layer, * vc = ctx->v_cache + (size_t) (il - ctx->l0) * kv_layer;
-        int vdt = -1; const float * src = nullptr;
         if (hp.arch == PI_ARCH_LLAMA) {
-            OP_OK(pi_op_norm(x, L.attn_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
             float * q = ctx->qkv, * k = q + (size_t) n_tok * n_embd, * v = k + (size_t) n_tok * n_gqa;
-            if (!mm(ctx, L.wq, ctx->nx, n_embd, n_tok, q, nullptr, vdt, src, ctx->q8a)) return false;
-            if (!mm(ctx, L.wk, ctx->nx, n_embd, n_tok, k, nullptr, vdt, src, ctx->q8a)) return false;
-            if (!mm(ctx, L.wv, ctx->nx, n_embd, n_tok, v, nullptr, vdt, src, ctx->q8a)) return false;
+            const int vq = vdt_of(L.wq);
+            if (!norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vq, ctx->q8a)) return false;
+            OP_OK(pi_op_mul_mat(L.wq, ctx->q8a, n_tok, q, nullptr, s));
+            if (vdt_of(L.wk) != vq && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wk), ctx->q8c)) return false;
+            OP_OK(pi_op_mul_mat(L.wk, vdt_of(L.wk) == vq ? ctx->q8a : ctx->q8c, n_tok, k, nullptr, s));
+            if (vdt_of(L.wv) != vq && vdt_of(L.wv) != vdt_of(L.wk) && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wv), ctx->q8c)) return false;
+            OP_OK(pi_op_mul_mat(L.wv, vdt_of(L.wv) == vq ? ctx->q8a : ctx->q8c, n_tok, v, nullptr, s));
             trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
-            OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, s));
-            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, s));
+            OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
+            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, s));
             trace(ctx, "att", il, ctx->att, n_embd, n_tok);
-            vdt = -1;
-            if (!mm(ctx, L.wo, ctx->att, n_embd, n_tok, x2, x, vdt, src, ctx->q8a)) return false;                  // ffn_inp = wo.att + inpSA
-            OP_OK(pi_op_norm(x2, L.ffn_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
-            vdt = -1;
-            if (!mm(ctx, L.ffn_up, ctx->nx, n_embd, n_tok, ctx->up, nullptr, vdt, src, ctx->q8a)) return false;
-            if (!mm(ctx, L.ffn_gate, ctx->nx, n_embd, n_tok, ctx->gate, nullptr, vdt, src, ctx->q8a)) return false;
-            OP_OK(pi_op_silu_mul(ctx->gate, ctx->up, ctx->gate, (int64_t) n_tok * n_ff, s));
-            vdt = -1;
-            if (!mm(ctx, L.ffn_down, ctx->gate, n_ff, n_tok, x, x2, vdt, src, ctx->q8b)) return false;             // l_out = down(..) + ffn_inp
+            OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
+            OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, x, s));                                                   // ffn_inp = wo.att + inpSA
+            const int vu = vdt_of(L.ffn_up);
+            if (!norm_for(ctx, x2, L.ffn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vu, ctx->q8a)) return false;
+            OP_OK(pi_op_mul_mat(L.ffn_up, ctx->q8a, n_tok, ctx->up, nullptr, s));
+            if (vdt_of(L.ffn_gate) != vu && !norm_for(ctx, x2, L.ffn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.ffn_gate), ctx->q8c)) return false;
+            OP_OK(pi_op_mul_mat(L.ffn_gate, vdt_of(L.ffn_gate) == vu ? ctx->q8a : ctx->q8c, n_tok, ctx->gate, nullptr, s));
+            OP_OK(pi_op_act_quantize(ctx->gate, ctx->up, 0, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));        // silu(gate) * up
+            OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, x2, s));                                             // l_out = down(..) + ffn_inp
             trace(ctx, "lout", il, x, n_embd, n_tok);
         } else {
-            OP_OK(pi_op_norm(x, L.attn_norm, L.attn_norm_b, ctx->nx, n_embd, n_tok, hp.f_norm_eps, 0, s));          // attn_norm (also feeds the MLP)
-            const float * cur = ctx->nx;
-            if (L.attn_norm_2) { OP_OK(pi_op_norm(x, L.attn_norm_2, L.attn_norm_2_b, ctx->nx2, n_embd, n_tok, hp.f_norm_eps, 0, s)); cur = ctx->nx2; }
             const int64_t qw = n_embd + 2 * n_gqa;
-            if (!mm(ctx, L.wqkv, cur, n_embd, n_tok, ctx->qkv, nullptr, vdt, src, ctx->q8a)) return false;
+            const int vqkv = vdt_of(L.wqkv), vup = vdt_of(L.ffn_up);
+            // attn_norm feeds the MLP (llama.cpp:4194) and, without a second norm, the QKV projection too
+            if (!norm_for(ctx, x, L.attn_norm, L.attn_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vup, ctx->q8c)) return false;
+            const void * qkv_in = ctx->q8c;
+            if (L.attn_norm_2) { if (!norm_for(ctx, x, L.attn_norm_2, L.attn_norm_2_b, n_embd, n_tok, hp.f_norm_eps, 0, vqkv, ctx->q8a)) return false; qkv_in = ctx->q8a; }
+            else if (vqkv != vup) { if (!norm_for(ctx, x, L.attn_norm, L.attn_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vqkv, ctx->q8a)) return false; qkv_in = ctx->q8a; }
+            OP_OK(pi_op_mul_mat(L.wqkv, qkv_in, n_tok, ctx->qkv, nullptr, s));
             OP_OK(pi_op_rope_kv_store(ctx->qkv, ctx->qkv + n_embd, ctx->qkv + n_embd + n_gqa, qw, qw, qw, ctx->pos_dev, ctx->rope, 1, hd, hp.n_head, hp.n_head_kv,
-                                      n_tok, kv_head, ctx->q16, kc, vc, s));
+                                      n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             trace(ctx, "q", il, ctx->qkv, n_embd, n_tok, qw); trace(ctx, "k", il, ctx->qkv + n_embd, n_gqa, n_tok, qw); trace(ctx, "v", il, ctx->qkv + n_embd + n_gqa, n_gqa, n_tok, qw);
-            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, s));
+            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, s));
             trace(ctx, "att", il, ctx->att, n_embd, n_tok);
-            vdt = -1;
-            if (!mm(ctx, L.wo, ctx->att, n_embd, n_tok, x2, nullptr, vdt, src, ctx->q8a)) return false;             // ffn_inp = attention output
+            OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
+            OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, nullptr, s));                                             // ffn_inp = attention output
             trace(ctx, "wo", il, x2, n_embd, n_tok);
-            vdt = -1;
-            if (!mm(ctx, L.ffn_up, ctx->nx, n_embd, n_tok, ctx->up, nullptr, vdt, src, ctx->q8b)) return false;     // MLP consumes attn_norm (llama.cpp:4194)
-            OP_OK(pi_op_gelu(ctx->up, ctx->up, (int64_t) n_tok * n_ff, s));
-            trace(ctx, "up", il, ctx->up, n_ff, n_tok);
-            vdt = -1;
-            if (!mm(ctx, L.ffn_down, ctx->up, n_ff, n_tok, ctx->att, x2, vdt, src, ctx->q8b)) return false;         // ffn_out + ffn_inp
+            OP_OK(pi_op_mul_mat(L.ffn_up, ctx->q8c, n_tok, ctx->up, nullptr, s));
+            OP_OK(pi_op_act_quantize(ctx->up, nullptr, 1, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));           // gelu
+            OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, ctx->att, x2, s));                                      // ffn_out + ffn_inp
             OP_OK(pi_op_add(ctx->att, x, x, (int64_t) n_tok * n_embd, s));                                            // + inpL
             trace(ctx, "lout", il, x, n_embd, n_tok);
         }
     }
     if (ctx->is_last) {
-        int vdt = -1; const float * src = nullptr;
-        if (hp.arch == PI_ARCH_LLAMA) OP_OK(pi_op_norm(x, m->output_norm, nullptr, ctx->nx, n_embd, n_tok, hp.f_norm_rms_eps, 1, s));
-        else                          OP_OK(pi_op_norm(x, m->output_norm, m->output_norm_b, ctx->nx, n_embd, n_tok, hp.f_norm_eps, 0, s));
-        if (!mm(ctx, m->output, ctx->nx, n_embd, n_tok, ctx->logits_dev, nullptr, vdt, src, ctx->q8a)) return false;
+        const int vo = vdt_of(m->output);
+        if (hp.arch == PI_ARCH_LLAMA) { if (!norm_for(ctx, x, m->output_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vo, ctx->q8a)) return false; }
+        else                          { if (!norm_for(ctx, x, m->output_norm, m->output_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vo, ctx->q8a)) return false; }
+        OP_OK(pi_op_mul_mat(m->output, ctx->q8a, n_tok, ctx->logits_dev, nullptr, s));
         OP_OK(pi_op_topk(ctx->logits_dev, hp.n_vocab, n_tok, 8, ctx->topk_ids_dev, ctx->topk_vals_dev, ctx->topk_sum_dev, s));
     }
     return true;
@@ -220,21 +225,22 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     const int kv_head = ctx->cells->find_slot(n_tokens, pos, n_seq_id, seq_id);
     if (kv_head < 0) { rc = 1; return nullptr; }                              // reference prints "Cannot find cache slot" and fails the decode
     const int n_kv = ctx->cells->n_attend();
-    const int words = (n_kv + 31) / 32;
-    const size_t meta_bytes = (size_t) n_tokens * 8 + (size_t) n_tokens * words * 4;
+    const int words = (ctx->n_ctx + 31) / 32;                                   // fixed row stride of the visibility bitmap
+    const size_t meta_bytes = (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4;
     pi_run * run = acquire_run(ctx, n_tokens, meta_bytes);
     if (!run) { ctx->last_error = "out of pinned host memory"; return nullptr; }
-    run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us();
+    run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us(); run->sink = nullptr;
     if (hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
     // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
     run->want_logits.assign(n_tokens, 1);
     run->last_only = false;
     if (batch_in.logits) for (int i = 0; i < n_tokens; i++) run->want_logits[i] = batch_in.logits[i] != 0;
     else if (!ctx->cparams.logits_all) run->last_only = true;
-    int32_t * h_tok = (int32_t *) run->meta_host, * h_pos = h_tok + n_tokens; uint32_t * h_mask = (uint32_t *) (h_pos + n_tokens);
+    int32_t * h_tok = (int32_t *) run->meta_host, * h_pos = h_tok + n_tokens, * h_dyn = h_pos + n_tokens; uint32_t * h_mask = (uint32_t *) (h_dyn + 4);
     memcpy(h_tok, batch_in.token, (size_t) 4 * n_tokens);
     memcpy(h_pos, pos, (size_t) 4 * n_tokens);
-    ctx->cells->build_mask(n_kv, n_tokens, pos, n_seq_id, seq_id, h_mask);
+    h_dyn[0] = kv_head; h_dyn[1] = n_kv; h_dyn[2] = n_tokens; h_dyn[3] = 0;
+    ctx->cells->build_mask(n_kv, n_tokens, pos, n_seq_id, seq_id, h_mask, words);
     ctx->cells->post_decode(n_tokens);
 
     run->canceled = ctx->canceled_batches.count(run->batch_id) > 0;
@@ -243,9 +249,32 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         hipStream_t s = ctx->stream;
         ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
              hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
+             hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16, hipMemcpyHostToDevice, s) == hipSuccess &&
              hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
         if (!ok) ctx->last_error = "H2D of batch metadata failed";
-        ok = ok && forward(ctx, n_tokens, kv_head, n_kv);
+        if (ok && ctx->use_graphs && !getenv("PI_TRACE")) {
+            // one HIP graph per batch width: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device
+            // memory that the copies above refresh, so replaying the graph IS this call's forward pass
+            llama_context::graph_entry & ge = ctx->graphs[n_tokens];
+            if (!ge.exec) {
+                hipGraph_t graph = nullptr;
+                ge.sink.every = 16;
+                ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    pi_kt_set_sink(&ge.sink);                      // sample points are part of the graph; they are only read while timing is on
+                    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx);
+                    pi_kt_set_sink(nullptr);
+                    ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
+                }
+                if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void) hipGraphDestroy(graph);
+                if (!ok) { ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error; ge.exec = nullptr; }
+            }
+            if (ok) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
+            if (ok) run->sink = &ge.sink;
+        } else if (ok) {
+            ok = forward(ctx, n_tokens, kv_head, ctx->n_ctx);
+        }
         if (ok && ctx->is_last) {
             const size_t nv = ctx->model->hparams.n_vocab;
             ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -289,6 +318,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
         }
     }
     if (run->launched) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_gpu_ms += ms; }
+    if (run->launched && run->sink && pi_kt_enabled()) pi_kt_accumulate(run->sink, 1);
     const int64_t dt = time_us() - run->t_start_us;
     if (n == 1) { ctx->t_eval_us += dt; ctx->n_eval++; } else { ctx->t_p_eval_us += dt; ctx->n_p_eval += n; }     // llama.cpp:5807-5815
     for (auto it = ctx->inflight.begin(); it != ctx->inflight.end(); ++it) if (*it == run) { ctx->inflight.erase(it); break; }

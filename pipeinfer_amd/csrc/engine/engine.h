@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdint>
 #include <deque>
+#include <map>
 #include <memory>
 #include <set>
 #include <string>
@@ -19,6 +20,7 @@
 #include "gguf.h"
 #include "kv_cells.h"
 #include "vocab.h"
+#include "../kernels/kernel_timing.h"
 
 enum pi_arch { PI_ARCH_LLAMA = 0, PI_ARCH_FALCON = 1 };
 
@@ -67,6 +69,7 @@ struct pi_run {                                // one llama_start_async_decode .
     int32_t * topk_ids = nullptr; float * topk_vals = nullptr; float * topk_sum = nullptr;   // pinned [n_tokens][8], [n_tokens]
     uint8_t * meta_host = nullptr; size_t meta_cap = 0;                                       // pinned staging for tokens/pos/mask
     int64_t t_start_us = 0;
+    pi_kt_sink * sink = nullptr;            // kernel-timing samples of the graph this run replayed
 };
 
 struct llama_context {
@@ -85,8 +88,11 @@ struct llama_context {
     // device scratch, sized for n_batch tokens
     float * x = nullptr, * x2 = nullptr, * nx = nullptr, * nx2 = nullptr, * qkv = nullptr, * att = nullptr, * up = nullptr, * gate = nullptr, * logits_dev = nullptr;
     uint16_t * q16 = nullptr;
-    void * q8a = nullptr, * q8b = nullptr;
-    int32_t * tokens_dev = nullptr, * pos_dev = nullptr; uint32_t * mask_dev = nullptr;
+    void * q8a = nullptr, * q8b = nullptr, * q8c = nullptr;
+    int32_t * tokens_dev = nullptr, * pos_dev = nullptr, * dyn_dev = nullptr; uint32_t * mask_dev = nullptr;
+    struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; };
+    std::map<int, graph_entry> graphs;       // one captured forward pass per n_tokens (kv_head / n_kv come from dyn_dev)
+    bool use_graphs = true;
     int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr;
     size_t mask_cap_words = 0;
 

@@ -203,8 +203,8 @@ void kv_cells::seq_rm_cp_range(int src, int first, int last, int p0, int p1) {
     head_ = 0;
 }
 
-void kv_cells::build_mask(int n_kv, int n_tokens, const int32_t * pos, const int32_t * n_seq_id, int32_t * const * seq_id, uint32_t * out) const {
-    const int words32 = (n_kv + 31) / 32;
+void kv_cells::build_mask(int n_kv, int n_tokens, const int32_t * pos, const int32_t * n_seq_id, int32_t * const * seq_id, uint32_t * out, int words32) const {
+    if (words32 <= 0) words32 = (n_kv + 31) / 32;          // row stride of the bitmap (the engine uses a fixed stride of n_ctx bits)
     memset(out, 0, (size_t) n_tokens * words32 * 4);
     std::vector<uint64_t> tmask((size_t) words_);
     for (int j = 0; j < n_tokens; j++) {

@@ -46,7 +46,7 @@ public:
 
     // attention visibility (KQ_mask rule, llama.cpp:5200-5240): bit c of row j <=> cell c carries ANY seq id of token j
     // and cell.pos <= pos[j].  out: [n_tokens][words32] with words32 = ceil(n_kv / 32)
-    void build_mask(int n_kv, int n_tokens, const int32_t * pos, const int32_t * n_seq_id, int32_t * const * seq_id, uint32_t * out) const;
+    void build_mask(int n_kv, int n_tokens, const int32_t * pos, const int32_t * n_seq_id, int32_t * const * seq_id, uint32_t * out, int words32 = 0) const;
 
     int  token_count() const;                           // llama_get_kv_cache_token_count, llama.cpp:9238-9247
 

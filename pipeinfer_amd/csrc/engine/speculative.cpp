@@ -470,6 +470,8 @@ extern "C" int pipeinfer_speculative(struct llama_context * ctx_tgt, struct llam
     driver d;
     d.tgt = ctx_tgt; d.dft = ctx_dft; d.P = *params;
     if (!ctx_tgt->cparams.logits_all || (params->mode != 2 && !ctx_dft->cparams.logits_all)) { fprintf(stderr, "pipeinfer_speculative: both contexts need logits_all (speculative.cpp:115)\n"); return -1; }
+    ctx_tgt->canceled_batches.clear();                       // batch ids restart at 1 for every call
+    if (ctx_dft) ctx_dft->canceled_batches.clear();
     const int n = d.run(prompt, n_prompt, out_tokens, out_cap);
     if (result) *result = d.R;
     return n;

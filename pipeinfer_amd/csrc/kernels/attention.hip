@@ -25,14 +25,18 @@
 struct att_args {
     const uint16_t * q16; const uint16_t * kc; const uint16_t * vc; const uint32_t * mask;
     float * out;
-    int n_head, n_head_kv, n_tok, n_kv, mask_words;
+    int n_head, n_head_kv, n_tok, n_kv, mask_words;        // n_kv / mask_words: LDS row stride and mask row stride (static)
     const uint16_t * exp_tab;
     float scale;
+    const int32_t * dyn;                                    // optional {kv_head, n_kv} in device memory: lets one captured graph serve every call
 };
 
 template <int HD>
-__global__ void __launch_bounds__(256) k_attention(const att_args g) {
+__global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     extern __shared__ float smem[];
+    att_args g = ga;
+    const int s_stride = ga.n_kv;                           // LDS rows keep the static stride
+    if (ga.dyn) g.n_kv = ga.dyn[1];
     const int hk = blockIdx.x, chunk = blockIdx.y;
     const int r = g.n_head / g.n_head_kv;                   // query heads per kv head (broadcast rule i02 = i12 / r2, ggml.c:9425)
     const int n_rows_total = g.n_tok * r;
@@ -40,7 +44,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args g) {
     const int n_rows = min(ATT_ROWS, n_rows_total - row0);
     const int n_gqa = g.n_head_kv * HD, n_embd = g.n_head * HD;
     float * S  = smem;                                      // [ATT_ROWS][n_kv]
-    float * qf = S + (size_t) ATT_ROWS * g.n_kv;             // [ATT_ROWS][HD]
+    float * qf = S + (size_t) ATT_ROWS * s_stride;           // [ATT_ROWS][HD]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     for (int i = tid; i < n_rows * HD; i += 256) {          // rows are token-major: row = t * r + gq -> query head hk * r + gq
@@ -77,14 +81,14 @@ __global__ void __launch_bounds__(256) k_attention(const att_args g) {
             for (int l = 0; l < 8; l++) s[l] = s[l] + s[8 + l];
             const float t0 = s[0] + s[4], t1 = s[1] + s[5], t2 = s[2] + s[6], t3 = s[3] + s[7];
             const float dot = (t0 + t1) + (t2 + t3);
-            S[(size_t) rr * g.n_kv + c] = vis ? dot * g.scale : -INFINITY;
+            S[(size_t) rr * s_stride + c] = vis ? dot * g.scale : -INFINITY;
         }
     }
     __syncthreads();
 
     // ---- phase 2: soft max, one wave per row ----
     for (int rr = wv; rr < n_rows; rr += 4) {
-        float * s = S + (size_t) rr * g.n_kv;
+        float * s = S + (size_t) rr * s_stride;
         float mx = -INFINITY;
         for (int c = lane; c < g.n_kv; c += 64) mx = fmaxf(mx, s[c]);
         mx = pi_wave_max(mx);
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args g) {
             for (int i = 0; i < RPT; i++) {
                 const int rr = rg + i * NRG;
                 if (rr < n_rows) {
-                    const float p = S[(size_t) rr * g.n_kv + c];
+                    const float p = S[(size_t) rr * s_stride + c];
 #pragma unroll
                     for (int e = 0; e < 8; e++) acc[i][j][e] = fmaf(vf[e], p, acc[i][j][e]);
                 }
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args g) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) sd[e] = (double) res[e];
                 for (int c = np; c < g.n_kv; c++) {                                     // leftovers, sequential, in double
-                    const float p = S[(size_t) rr * g.n_kv + c];
+                    const float p = S[(size_t) rr * s_stride + c];
                     const uint4 v = *(const uint4 *) (g.vc + (int64_t) c * n_gqa + hk * HD + 8 * ev);
                     const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -175,23 +179,32 @@ __global__ void __launch_bounds__(256) k_attention(const att_args g) {
     }
 }
 
+// raises the dynamic-LDS limit of the kernel for contexts longer than ~2000 cells; call once outside any graph capture
+extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
+    const size_t lds = ((size_t) ATT_ROWS * n_kv_max + (size_t) ATT_ROWS * hd) * sizeof(float);
+    if (lds > 160 * 1024) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS (> 160 KiB)", n_kv_max, lds); return -1; }
+    if (lds <= 64 * 1024) return 0;
+    if (hd == 128) PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    else           PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    return 0;
+}
+
 extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
-                               int n_tok, int n_kv, float * out, void * stream) {
+                               int n_tok, int n_kv, float * out, const int32_t * dyn_dev, void * stream) {
     if (n_tok <= 0) return 0;
     att_args g;
     g.q16 = q16; g.kc = kc; g.vc = vc; g.mask = mask; g.out = out;
     g.n_head = n_head; g.n_head_kv = n_head_kv; g.n_tok = n_tok; g.n_kv = n_kv; g.mask_words = (n_kv + 31) / 32;
     g.exp_tab = pi_get_tables().exp_f16;
     g.scale = 1.0f / sqrtf((float) hd);                      // KQ_scale, llama.cpp:5189-5193
+    g.dyn = dyn_dev;
     const int rows = n_tok * (n_head / n_head_kv);
     const dim3 grid(n_head_kv, (rows + ATT_ROWS - 1) / ATT_ROWS);
     const size_t lds = ((size_t) ATT_ROWS * n_kv + (size_t) ATT_ROWS * hd) * sizeof(float);
     if (lds > 160 * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs %zu B of LDS (> 160 KiB)", n_kv, lds); return -1; }
     if (hd == 128) {
-        if (lds > 64 * 1024) PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL(k_attention<128>, grid, dim3(256), lds, (hipStream_t) stream, g);
     } else if (hd == 64) {
-        if (lds > 64 * 1024) PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), lds, (hipStream_t) stream, g);
     } else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }
     PI_CHECK_LAUNCH();

@@ -170,6 +170,147 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__
     if (kk == 0) dd[grp * 4 + bi] = pi_f2h(d);
 }
 
+// ---- per-256 (Q8_K) / per-8x32 (Q8_0) quantisation of four consecutive values held by each lane of a wave ----------------
+// Same arithmetic as k_quantize_q8_K / k_quantize_q8_0 above; `blk` is the index of the 256-value chunk inside the row.
+static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int lane, int64_t row_blk, int8_t * qs, float * dd, int16_t * bsums) {
+    float amax = 0.0f, mx = 0.0f; int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
+    }
+    int q[4] = { 0, 0, 0, 0 };
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.f / mx;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int r = __float2int_rn(iscale * xs[i]); q[i] = r < 127 ? r : 127; }
+        d = 1 / iscale;
+    }
+    ((uint32_t *) (qs + row_blk * 256))[(lane & 7) * 8 + (lane >> 3)] =
+        (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    if ((lane & 3) == 0) bsums[row_blk * 16 + (lane >> 2)] = (int16_t) s;
+    if (lane == 0) dd[row_blk] = d;
+}
+static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int lane, int64_t tok_ng, int64_t e0, uint32_t * qs, uint16_t * dd) {
+    float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.f;
+    const float id = amax != 0.0f ? 127.f / amax : 0.0f;
+    int q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { int r = __float2int_rn(xs[i] * id); q[i] = r > 127 ? 127 : (r < -128 ? -128 : r); }
+    const int64_t blk = e0 >> 5, grp = tok_ng + (blk >> 2); const int bi = (int) (blk & 3), kk = lane & 7;
+    qs[(grp * 8 + kk) * 4 + bi] = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
+    if (kk == 0) dd[grp * 4 + bi] = pi_f2h(d);
+}
+
+// norm (rms / layer) * weight (+ bias) straight into the quantised activation planes; optionally also the fp32 result.
+// One workgroup per token; every wave normalises and quantises whole 256-value chunks (a Q8_K block, or eight Q8_0 blocks).
+__global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ yf,
+                                                      int n, float eps, int rms, int vdt, int64_t ng, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums) {
+    __shared__ double sh[16];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float * xr = x + (int64_t) t * n;
+    auto block_sum = [&](double v) {
+        v = pi_wave_sum_f64(v);
+        __syncthreads();
+        if (lane == 0) sh[wave] = v;
+        __syncthreads();
+        double s = 0.0;
+        for (int i = 0; i < nw; i++) s += sh[i];
+        return s;
+    };
+    float mean = 0.0f;
+    double acc = 0.0;
+    if (rms) {
+        for (int i = tid * 4; i < n; i += blockDim.x * 4) { const float4 v = *(const float4 *) (xr + i); acc += (double) (v.x * v.x); acc += (double) (v.y * v.y); acc += (double) (v.z * v.z); acc += (double) (v.w * v.w); }
+    } else {
+        for (int i = tid * 4; i < n; i += blockDim.x * 4) { const float4 v = *(const float4 *) (xr + i); acc += (double) v.x; acc += (double) v.y; acc += (double) v.z; acc += (double) v.w; }
+        mean = (float) (block_sum(acc) / n);
+        acc = 0.0;
+        for (int i = tid * 4; i < n; i += blockDim.x * 4) {
+            const float4 v = *(const float4 *) (xr + i);
+            const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+            acc += (double) (a0 * a0); acc += (double) (a1 * a1); acc += (double) (a2 * a2); acc += (double) (a3 * a3);
+        }
+    }
+    const float var = (float) (block_sum(acc) / n);
+    const float scale = 1.0f / sqrtf(var + eps);
+    const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
+    for (int64_t c0 = (int64_t) wave * 256; c0 < n_pad; c0 += (int64_t) nw * 256) {          // whole 256-value chunks per wave
+        const int64_t e0 = c0 + lane * 4;
+        float ys[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (e0 < n) {
+            const float4 v = *(const float4 *) (xr + e0);
+            const float xv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float y = (xv[i] - mean) * scale;
+                if (w) y = y * w[e0 + i];
+                if (b) y = y + b[e0 + i];
+                ys[i] = y;
+            }
+            if (yf) *(float4 *) (yf + (int64_t) t * n + e0) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+        }
+        if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, (int64_t) t * (n >> 8) + (c0 >> 8), (int8_t *) qs, (float *) dd, bsums);
+        else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd);
+    }
+}
+
+extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float * b, float * y_f32, int n, int n_tok, float eps, int rms, int vdt, void * q8, void * stream) {
+    if (n_tok <= 0) return 0;
+    if ((vdt == PI_Q8_K && n % 256) || (vdt == PI_Q8_0 && n % 32) || (vdt != PI_Q8_K && vdt != PI_Q8_0)) { pi_set_error("pi_op_norm_quantize: n=%d not valid for activation type %d", n, vdt); return -1; }
+    size_t oq, od, ob;
+    pi_q8_layout(vdt, n, n_tok, &oq, &od, &ob);
+    uint8_t * base = (uint8_t *) q8;
+    const int64_t ng = (n / 32 + 3) / 4;
+    const int chunks = (int) ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
+    const int threads = 64 * (chunks < 16 ? chunks : 16);
+    hipLaunchKernelGGL(k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob));
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
+// act(gate) [* up] straight into the quantised activation planes: which = 0 silu(gate)*up, 1 gelu(gate).  One wave per 256 values.
+__global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g, const float * __restrict__ u, int which, int64_t n, int vdt, int64_t ng,
+                                                    const uint16_t * __restrict__ tab, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums) {
+    const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t) blockIdx.x * 4 + wave) * 256, e0 = c0 + lane * 4;
+    const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
+    if (c0 >= n_pad) return;
+    float ys[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (e0 < n) {
+        const float4 gv = *(const float4 *) (g + (int64_t) t * n + e0);
+        const float gs[4] = { gv.x, gv.y, gv.z, gv.w };
+        float us[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+        if (which == 0) { const float4 uv = *(const float4 *) (u + (int64_t) t * n + e0); us[0] = uv.x; us[1] = uv.y; us[2] = uv.z; us[3] = uv.w; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float a = pi_h2f(tab[pi_f2h(gs[i])]); ys[i] = which == 0 ? a * us[i] : a; }
+    }
+    if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, (int64_t) t * (n >> 8) + (c0 >> 8), (int8_t *) qs, (float *) dd, bsums);
+    else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd);
+}
+
+extern "C" int pi_op_act_quantize(const float * gate, const float * up, int which, int64_t n, int n_tok, int vdt, void * q8, void * stream) {
+    if (n_tok <= 0) return 0;
+    if ((vdt == PI_Q8_K && n % 256) || (vdt == PI_Q8_0 && n % 32) || (vdt != PI_Q8_K && vdt != PI_Q8_0)) { pi_set_error("pi_op_act_quantize: n=%lld not valid for activation type %d", (long long) n, vdt); return -1; }
+    size_t oq, od, ob;
+    pi_q8_layout(vdt, n, n_tok, &oq, &od, &ob);
+    uint8_t * base = (uint8_t *) q8;
+    const int64_t ng = (n / 32 + 3) / 4;
+    const int64_t chunks = ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
+    const pi_tables & tb = pi_get_tables();
+    hipLaunchKernelGGL(k_act_quant, dim3((unsigned) ((chunks + 3) / 4), n_tok), dim3(256), 0, (hipStream_t) stream, gate, up, which, n, vdt, ng,
+                       which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob));
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, void * q8, void * stream) {
     if (n_tok <= 0) return 0;
     size_t oq, od, ob;
@@ -216,8 +357,9 @@ extern "C" void pi_rope_table_free(void * t_) { pi_rope_table * t = (pi_rope_tab
 
 // grid (n_tok, n_head + 2*n_head_kv) — one workgroup of hd/2 threads per head vector
 __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict__ k, const float * __restrict__ v, int64_t qs, int64_t ks, int64_t vs,
-                          const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head,
-                          uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc) {
+                          const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head_,
+                          uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc, const int32_t * __restrict__ dyn) {
+    const int kv_head = dyn ? dyn[0] : kv_head_;
     const int t = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;           // i: pair index
     const int n_embd = n_head * hd, n_gqa = n_head_kv * hd;
     if (hh >= n_head + n_head_kv) {                                         // V: plain f32 -> f16 copy into the cache row
@@ -240,12 +382,13 @@ __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict
 
 extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float * v, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                                    const int32_t * pos, const void * table_, int neox,
-                                   int hd, int n_head, int n_head_kv, int n_tok, int kv_head, uint16_t * q16, uint16_t * kc, uint16_t * vc, void * stream) {
+                                   int hd, int n_head, int n_head_kv, int n_tok, int kv_head, uint16_t * q16, uint16_t * kc, uint16_t * vc,
+                                   const int32_t * dyn_dev, void * stream) {
     if (n_tok <= 0) return 0;
     const pi_rope_table * t = (const pi_rope_table *) table_;
     if (t->head_dim != hd) { pi_set_error("pi_op_rope_kv_store: table head_dim %d != %d", t->head_dim, hd); return -1; }
     hipLaunchKernelGGL(k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
-                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc);
+                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc, dyn_dev);
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -287,16 +430,21 @@ extern "C" int pi_op_add(const float * a, const float * b, float * o, int64_t n,
 // (llama.cpp:7496-7510) and a stable version of the std::sort in llama_sample_softmax (llama.cpp:7019-7046);
 // plus max and sum_i expf(l_i - max) so p_j = expf(l_j - max) / sum on the host.
 // =================================================================================================================
-__global__ void __launch_bounds__(1024) k_topk(const float * __restrict__ logits, int n_vocab, int k, int32_t * __restrict__ ids, float * __restrict__ vals, float * __restrict__ sumexp) {
-    __shared__ float sv[16]; __shared__ int si[16]; __shared__ float sb[2]; __shared__ int sbi;
-    const float * l = logits + (int64_t) blockIdx.x * n_vocab;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// stage 1: grid (n_tok, NCH) — each workgroup finds the k best of its slice of the vocabulary and its partial max / sum-exp
+// stage 2: one workgroup per token merges NCH*k candidates (same ordering) and the partial sums.
+#define TOPK_NCH 32
+__global__ void __launch_bounds__(256) k_topk1(const float * __restrict__ logits, int n_vocab, int k, int32_t * __restrict__ cid, float * __restrict__ cval, float * __restrict__ cmax, float * __restrict__ csum) {
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sb; __shared__ int sbi;
+    const int t = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (n_vocab + TOPK_NCH - 1) / TOPK_NCH, lo = ch * per, hi = min(n_vocab, lo + per);
+    const float * l = logits + (int64_t) t * n_vocab;
     float prev_v = INFINITY; int prev_i = -1;
+    float first = -INFINITY;
     for (int r = 0; r < k; r++) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = tid; i < n_vocab; i += 1024) {
+        for (int i = lo + tid; i < hi; i += 256) {
             const float v = l[i];
-            const bool after = v < prev_v || (v == prev_v && i > prev_i);       // strictly behind the previous winner
+            const bool after = v < prev_v || (v == prev_v && i > prev_i);
             if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -307,27 +455,70 @@ __global__ void __launch_bounds__(1024) k_topk(const float * __restrict__ logits
         if (lane == 0) { sv[wv] = bv; si[wv] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 16; w++) if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-            sb[0] = bv; sbi = bi;
-            ids[blockIdx.x * k + r] = bi; vals[blockIdx.x * k + r] = bv;
+            for (int w2 = 1; w2 < 4; w2++) if (sv[w2] > bv || (sv[w2] == bv && si[w2] < bi)) { bv = sv[w2]; bi = si[w2]; }
+            sb = bv; sbi = bi;
+            cid[((int64_t) t * TOPK_NCH + ch) * k + r] = bi; cval[((int64_t) t * TOPK_NCH + ch) * k + r] = bv;
         }
         __syncthreads();
-        prev_v = sb[0]; prev_i = sbi;
-        if (r == 0) sb[1] = prev_v;
+        prev_v = sb; prev_i = sbi;
+        if (r == 0) first = prev_v;
     }
-    __syncthreads();
-    const float mx = sb[1];
     float s = 0.0f;
-    for (int i = tid; i < n_vocab; i += 1024) s += expf(l[i] - mx);
+    for (int i = lo + tid; i < hi; i += 256) s += expf(l[i] - first);
     s = pi_lanes_sum<64>(s);
     __syncthreads();
     if (lane == 0) sv[wv] = s;
     __syncthreads();
-    if (tid == 0) { float tot = 0.0f; for (int w = 0; w < 16; w++) tot += sv[w]; sumexp[blockIdx.x] = tot; }
+    if (tid == 0) { cmax[t * TOPK_NCH + ch] = first; csum[t * TOPK_NCH + ch] = (sv[0] + sv[1]) + (sv[2] + sv[3]); }
+}
+__global__ void __launch_bounds__(64) k_topk2(int k, const int32_t * __restrict__ cid, const float * __restrict__ cval, const float * __restrict__ cmax, const float * __restrict__ csum,
+                                               int32_t * __restrict__ ids, float * __restrict__ vals, float * __restrict__ sumexp) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int n = TOPK_NCH * k;
+    float prev_v = INFINITY; int prev_i = -1;
+    for (int r = 0; r < k; r++) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const float v = cval[(int64_t) t * n + i]; const int id = cid[(int64_t) t * n + i];
+            const bool after = v < prev_v || (v == prev_v && id > prev_i);
+            if (after && (v > bv || (v == bv && id < bi))) { bv = v; bi = id; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { ids[t * k + r] = bi; vals[t * k + r] = bv; }
+        prev_v = bv; prev_i = bi;
+    }
+    float mx = -INFINITY;
+    for (int i = lane; i < TOPK_NCH; i += 64) mx = fmaxf(mx, cmax[t * TOPK_NCH + i]);
+    mx = pi_wave_max(mx);
+    float s = 0.0f;
+    for (int i = lane; i < TOPK_NCH; i += 64) { const float m = cmax[t * TOPK_NCH + i]; if (m != -INFINITY) s += csum[t * TOPK_NCH + i] * expf(m - mx); }
+    s = pi_lanes_sum<64>(s);
+    if (lane == 0) sumexp[t] = s;
 }
 
+static float * g_topk_scratch = nullptr; static size_t g_topk_cap = 0;
+// sizes the scratch of pi_op_topk for up to n_tok_max rows; call once outside any graph capture
+extern "C" int pi_op_topk_reserve(int n_tok_max) {
+    const size_t need = (size_t) n_tok_max * TOPK_NCH * (2 * 8 + 2) * 4;
+    if (need > g_topk_cap) {
+        PI_CHECK_HIP(hipDeviceSynchronize());
+        if (g_topk_scratch) (void) hipFree(g_topk_scratch);
+        g_topk_cap = need;
+        PI_CHECK_HIP(hipMalloc((void **) &g_topk_scratch, g_topk_cap));
+    }
+    return 0;
+}
 extern "C" int pi_op_topk(const float * logits, int n_vocab, int n_tok, int k, int32_t * ids, float * vals, float * sumexp, void * stream) {
     if (n_tok <= 0) return 0;
-    hipLaunchKernelGGL(k_topk, dim3(n_tok), dim3(1024), 0, (hipStream_t) stream, logits, n_vocab, k, ids, vals, sumexp);
+    if (k > 8) { pi_set_error("pi_op_topk: k=%d > 8", k); return -1; }
+    const size_t need = (size_t) n_tok * TOPK_NCH * (2 * k + 2) * 4;
+    if (need > g_topk_cap) { if (pi_op_topk_reserve(n_tok < 64 ? 64 : n_tok) != 0) return -1; }
+    int32_t * cid = (int32_t *) g_topk_scratch; float * cval = (float *) (cid + (size_t) n_tok * TOPK_NCH * k);
+    float * cmax = cval + (size_t) n_tok * TOPK_NCH * k, * csum = cmax + (size_t) n_tok * TOPK_NCH;
+    hipLaunchKernelGGL(k_topk1, dim3(n_tok, TOPK_NCH), dim3(256), 0, (hipStream_t) stream, logits, n_vocab, k, cid, cval, cmax, csum);
+    hipLaunchKernelGGL(k_topk2, dim3(n_tok), dim3(64), 0, (hipStream_t) stream, k, cid, cval, cmax, csum, ids, vals, sumexp);
     PI_CHECK_LAUNCH(); return 0;
 }

@@ -17,6 +17,8 @@
 // Weights are streamed from HBM exactly once, straight into registers.
 #include "ops_common.h"
 
+#include <cstring>
+
 #define MMVQ_TILE 16            // K-quant super-blocks (or groups of four 32-blocks) staged in LDS per step
 
 struct mmvq_args {
@@ -57,6 +59,7 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
     const int r = lane >> 3, k = lane & 7;
     const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
     const bool live = row < g.M;
+    const int64_t rowc = live ? row : g.M - 1;
     const int nb = g.nb;
 
     float acc[NT], accm[NT];
@@ -65,8 +68,30 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
 
     for (int b0 = 0; b0 < nb; b0 += MMVQ_TILE) {
         const int nbt = min(MMVQ_TILE, nb - b0);
+        // issue every weight load of the tile before the first use: with only M/8 waves in a launch the bytes in flight per
+        // wave, not occupancy, are what keeps HBM busy (16 blocks x 8 rows x 144 B = 18 KB per wave)
+        uint4 w_hdr[MMVQ_TILE], w_q[MMVQ_TILE]; uint2 w_h[MMVQ_TILE]; uint16_t w_d[MMVQ_TILE];
+#pragma unroll
+        for (int bi = 0; bi < MMVQ_TILE; bi++) {
+            {   // unconditional (indices clamped): arrays filled under divergent control flow would be demoted to scratch
+                const int64_t blk = rowc * nb + b0 + (bi < nbt ? bi : nbt - 1);
+                if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
+                    constexpr int BS = TYPE == PI_Q4_K ? 144 : 176, QOFF = TYPE == PI_Q4_K ? 16 : 48;
+                    const uint8_t * p = g.w.p0 + blk * BS;
+                    w_hdr[bi] = *(const uint4 *) p;
+                    w_q[bi] = *(const uint4 *) (p + QOFF + 16 * k);
+                    if constexpr (TYPE == PI_Q5_K) w_h[bi].x = *(const uint32_t *) (p + 16 + 4 * k);
+                } else {
+                    const uint8_t * p = g.w.p0 + blk * 192;
+                    w_q[bi] = *(const uint4 *) (p + 16 * k);
+                    w_h[bi] = *(const uint2 *) (p + 128 + 8 * k);
+                    w_hdr[bi] = *(const uint4 *) (g.w.p1 + blk * 16);
+                    w_d[bi] = ((const uint16_t *) g.w.p2)[blk];
+                }
+            }
+        }
         __syncthreads();
-        // ---- stage the activations of blocks [b0, b0+nbt) for all NT tokens ----
+        // ---- stage the activations of blocks [b0, b0+nbt) for all NT tokens (overlaps the weight loads in flight) ----
         for (int u = tid; u < NT * nbt * 16; u += blockDim.x) {                 // 16-byte units of qs
             const int t = u / (nbt * 16), rem = u % (nbt * 16);
             *(uint4 *) (l_qs + ((size_t) t * MMVQ_TILE * 256) + rem * 16) = *(const uint4 *) (g.aq + ((size_t) t * nb + b0) * 256 + (size_t) rem * 16);
@@ -82,20 +107,17 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
         __syncthreads();
         if (!live) continue;
 
-#pragma unroll 2
-        for (int bi = 0; bi < nbt; bi++) {
-            const int64_t blk = row * nb + b0 + bi;
+#pragma unroll
+        for (int bi = 0; bi < MMVQ_TILE; bi++) {
+          if (bi < nbt) {
             float dx, dminx = 0.0f;
             uint32_t scA = 0, scB = 0, mA = 0, mB = 0;
             int q[4], qx[2] = { 0, 0 };
             uint4 sc6 = { 0, 0, 0, 0 };
+            q[0] = w_q[bi].x; q[1] = w_q[bi].y; q[2] = w_q[bi].z; q[3] = w_q[bi].w;
             if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
-                constexpr int BS = TYPE == PI_Q4_K ? 144 : 176, QOFF = TYPE == PI_Q4_K ? 16 : 48;
-                const uint8_t * p = g.w.p0 + blk * BS;
-                const uint4 hdr = *(const uint4 *) p;
-                const uint4 qv = *(const uint4 *) (p + QOFF + 16 * k);
-                q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
-                if constexpr (TYPE == PI_Q5_K) qx[0] = *(const int *) (p + 16 + 4 * k);
+                const uint4 hdr = w_hdr[bi];
+                if constexpr (TYPE == PI_Q5_K) qx[0] = (int) w_h[bi].x;
                 dx = pi_h2f((uint16_t) (hdr.x & 0xffff)); dminx = pi_h2f((uint16_t) (hdr.x >> 16));
                 // 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:1446-1453) unpacked four at a time like the reference's utmp[]
                 scA = hdr.y & 0x3f3f3f3fu;
@@ -103,13 +125,9 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
                 scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
                 mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
             } else {
-                const uint8_t * p = g.w.p0 + blk * 192;
-                const uint4 qv = *(const uint4 *) (p + 16 * k);
-                q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
-                const uint2 hv = *(const uint2 *) (p + 128 + 8 * k);
-                qx[0] = hv.x; qx[1] = hv.y;
-                sc6 = *(const uint4 *) (g.w.p1 + blk * 16);
-                dx = pi_h2f(((const uint16_t *) g.w.p2)[blk]);
+                qx[0] = (int) w_h[bi].x; qx[1] = (int) w_h[bi].y;
+                sc6 = w_hdr[bi];
+                dx = pi_h2f(w_d[bi]);
             }
             // token-independent unpacking of this lane's 32 weights (8 dwords, in the order the activations are stored)
             int wq[8];
@@ -176,6 +194,7 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
                     }
                 }
             }
+          }
         }
     }
     // ---- fold the eight chains ----
@@ -210,6 +229,7 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     const int r = lane >> 3, k = lane & 7;
     const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
     const bool live = row < g.M;
+    const int64_t rowc = live ? row : g.M - 1;
     const int ng = g.nb;
     float acc[NT];
 #pragma unroll
@@ -217,6 +237,16 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
 
     for (int g0 = 0; g0 < ng; g0 += MMVQ_TILE) {
         const int ngt = min(MMVQ_TILE, ng - g0);
+        uint4 w_x[MMVQ_TILE]; uint2 w_dv[MMVQ_TILE];                      // all weight loads of the tile up front (see k_mmvq_kq)
+#pragma unroll
+        for (int gi = 0; gi < MMVQ_TILE; gi++) {
+            {
+                const int64_t grp = rowc * ng + g0 + (gi < ngt ? gi : ngt - 1);
+                if constexpr (TYPE == PI_Q4_0) w_x[gi] = *(const uint4 *) (g.w.p0 + grp * 64 + 16 * (k & 3));
+                else                           w_x[gi] = *(const uint4 *) (g.w.p0 + grp * 128 + 16 * k);
+                w_dv[gi] = *(const uint2 *) (g.w.p1 + grp * 8);
+            }
+        }
         __syncthreads();
         for (int u = tid; u < NT * ngt * 8; u += blockDim.x) {
             const int t = u / (ngt * 8), rem = u % (ngt * 8);
@@ -228,13 +258,11 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
         }
         __syncthreads();
         if (!live) continue;
-#pragma unroll 2
-        for (int gi = 0; gi < ngt; gi++) {
-            const int64_t grp = row * ng + g0 + gi;
-            uint4 xv;
-            if constexpr (TYPE == PI_Q4_0) xv = *(const uint4 *) (g.w.p0 + grp * 64 + 16 * (k & 3));
-            else                           xv = *(const uint4 *) (g.w.p0 + grp * 128 + 16 * k);
-            const uint2 dv = *(const uint2 *) (g.w.p1 + grp * 8);
+#pragma unroll
+        for (int gi = 0; gi < MMVQ_TILE; gi++) {
+          if (gi < ngt) {
+            const uint4 xv = w_x[gi];
+            const uint2 dv = w_dv[gi];
             const uint32_t x4[4] = { xv.x, xv.y, xv.z, xv.w };
             int xs[4]; float dx[4];
 #pragma unroll
@@ -254,6 +282,7 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
                     acc[t] = fmaf(dx[b] * dy, (float) pi_dot4(xs[b], y4[b], 0), acc[t]);
                 }
             }
+          }
         }
     }
 #pragma unroll
@@ -266,8 +295,73 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     }
 }
 
+// ---- sampled per-launch timing for the roofline report (bench.py): HIP events on the launch stream around every Nth
+//      launch of each kernel instantiation.  Eager launches: samples resolved by pi_kernel_timing_report after a sync.
+//      Captured launches (HIP graphs): the event pair becomes part of the graph and is re-recorded by every replay; the
+//      engine owns the samples of a graph (pi_kt_sink) and folds their elapsed times in after each replay has finished. ----
+#include <mutex>
+#include <vector>
+#include "kernel_timing.h"
+namespace {
+std::mutex g_kt_mu;
+bool g_kt_on = false; int g_kt_every = 8;
+std::vector<pi_kt_sample> g_kt;                      // eager samples
+uint64_t g_kt_launches[16][9];
+double g_kt_us[16][9], g_kt_bytes[16][9]; uint64_t g_kt_n[16][9];
+std::vector<hipEvent_t> g_kt_pool;
+thread_local pi_kt_sink * g_kt_sink = nullptr;
+hipEvent_t kt_event() {
+    if (!g_kt_pool.empty()) { hipEvent_t e = g_kt_pool.back(); g_kt_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void) hipEventCreate(&e); return e;
+}
+void kt_fold(const pi_kt_sample & s) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) return;
+    const int t = s.type & 15, n = s.nt <= 8 ? s.nt : 8;
+    g_kt_us[t][n] += 1e3 * ms; g_kt_bytes[t][n] += s.bytes; g_kt_n[t][n]++;
+}
+}
+void pi_kt_set_sink(pi_kt_sink * sink) { g_kt_sink = sink; }
+bool pi_kt_enabled() { return g_kt_on; }
+void pi_kt_accumulate(pi_kt_sink * sink, uint64_t replays_launches) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    if (!g_kt_on) return;
+    for (auto & s : sink->samples) kt_fold(s);
+    for (auto & c : sink->launches) g_kt_launches[c.type & 15][c.nt <= 8 ? c.nt : 8] += c.count * replays_launches;
+}
+extern "C" void pi_kernel_timing(int on, int sample_every) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    g_kt_on = on != 0; g_kt_every = sample_every > 0 ? sample_every : 1;
+    for (auto & s : g_kt) { g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b); }
+    g_kt.clear();
+    memset(g_kt_launches, 0, sizeof g_kt_launches); memset(g_kt_us, 0, sizeof g_kt_us); memset(g_kt_bytes, 0, sizeof g_kt_bytes); memset(g_kt_n, 0, sizeof g_kt_n);
+}
+// mean duration (us) and mean algorithmic bytes of the sampled launches of k_mmvq<type, nt>; call after a device sync
+extern "C" int pi_kernel_timing_report(int type, int nt, double * avg_us, double * avg_bytes, uint64_t * n_sampled, uint64_t * n_launches) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    for (auto & s : g_kt) { kt_fold(s); g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b); }
+    g_kt.clear();
+    const int t = type & 15, n = nt <= 8 ? nt : 8;
+    *avg_us = g_kt_n[t][n] ? g_kt_us[t][n] / g_kt_n[t][n] : 0.0; *avg_bytes = g_kt_n[t][n] ? g_kt_bytes[t][n] / g_kt_n[t][n] : 0.0;
+    *n_sampled = g_kt_n[t][n]; *n_launches = g_kt_launches[t][n];
+    return 0;
+}
+
 template <int TYPE, int NT>
 static int launch_mmvq(const mmvq_args & g, hipStream_t stream) {
+    bool sample = false; hipEvent_t ea = nullptr, eb = nullptr;
+    pi_kt_sink * sink = g_kt_sink;
+    if (sink) {                                            // being captured into a graph: count per graph, sample a fixed subset
+        bool found = false;
+        for (auto & c : sink->launches) if (c.type == TYPE && c.nt == NT) { sample = (c.count++ % sink->every) == 0; found = true; break; }
+        if (!found) { sink->launches.push_back(pi_kt_count{ TYPE, NT, 1 }); sample = true; }
+        if (sample) { std::lock_guard<std::mutex> lk(g_kt_mu); ea = kt_event(); eb = kt_event(); }
+    } else if (g_kt_on) {
+        std::lock_guard<std::mutex> lk(g_kt_mu);
+        sample = (g_kt_launches[TYPE & 15][NT]++ % g_kt_every) == 0;
+        if (sample) { ea = kt_event(); eb = kt_event(); }
+    }
+    if (sample) (void) hipEventRecord(ea, stream);
     // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
     int wpb = 1;
     while (wpb < 4 && (int64_t) g.M / (8 * wpb * 2) >= 512) wpb *= 2;
@@ -280,6 +374,15 @@ static int launch_mmvq(const mmvq_args & g, hipStream_t stream) {
     } else {
         const size_t lds = (size_t) NT * MMVQ_TILE * (256 + 4 + 32);
         hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+    }
+    if (sample) {
+        (void) hipEventRecord(eb, stream);
+        // algorithmic bytes of this launch: the weight matrix once + quantised activations + fp32 output (+ residual)
+        const double wbytes = (double) g.w.nbytes;
+        const double abytes = (double) NT * ((TYPE == PI_Q4_0 || TYPE == PI_Q8_0) ? (double) g.K / 32 * 34 : (double) g.K / 256 * 292);
+        const double obytes = (double) NT * g.M * 4 * (g.res ? 2 : 1);
+        if (sink) sink->samples.push_back(pi_kt_sample{ ea, eb, TYPE, NT, wbytes + abytes + obytes });
+        else { std::lock_guard<std::mutex> lk(g_kt_mu); g_kt.push_back(pi_kt_sample{ ea, eb, TYPE, NT, wbytes + abytes + obytes }); }
     }
     PI_CHECK_LAUNCH();
     return 0;

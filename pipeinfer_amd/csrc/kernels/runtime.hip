@@ -100,6 +100,7 @@ extern "C" int pi_memcpy_d2h(void * dst, const void * src, size_t n, void * stre
     return 0;
 }
 extern "C" int pi_memset(void * dst, int v, size_t n, void * stream) { PI_CHECK_HIP(hipMemsetAsync(dst, v, n, (hipStream_t) stream)); return 0; }
+extern "C" int pi_device_sync(void) { PI_CHECK_HIP(hipDeviceSynchronize()); return 0; }
 extern "C" int pi_stream_sync(void * stream) { PI_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream)); return 0; }
 
 // ---- weight upload + re-layout ------------------------------------------------------------------------------------

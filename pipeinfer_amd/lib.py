@@ -79,6 +79,8 @@ def _declare(lib):
     lib.pi_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     lib.pi_memset.argtypes = [vp, i32, sz, vp]
     lib.pi_stream_sync.argtypes = [vp]
+    lib.pi_kernel_timing.argtypes = [i32, i32]
+    lib.pi_kernel_timing_report.argtypes = [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pi_weight_upload.restype = vp
     lib.pi_weight_upload.argtypes = [i32, i64, i64, vp, vp]
     lib.pi_weight_free.argtypes = [vp]
@@ -92,13 +94,17 @@ def _declare(lib):
     lib.pi_op_get_rows.argtypes = [vp, vp, i32, vp, vp]
     lib.pi_op_norm.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, vp]
     lib.pi_op_quantize.argtypes = [i32, vp, i64, i32, vp, vp]
+    lib.pi_op_norm_quantize.argtypes = [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp, vp]
+    lib.pi_op_act_quantize.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
     lib.pi_op_mul_mat.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.pi_rope_table_create.restype = vp
     lib.pi_rope_table_create.argtypes = [i32, i32, f32, f32, i32]
     lib.pi_rope_table_free.argtypes = [vp]
-    lib.pi_op_rope_kv_store.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
-    lib.pi_op_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.pi_op_rope_kv_store.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.pi_op_attention.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.pi_op_attention_reserve.argtypes = [i32, i32]
     lib.pi_op_silu_mul.argtypes = [vp, vp, vp, i64, vp]
     lib.pi_op_gelu.argtypes = [vp, vp, i64, vp]
     lib.pi_op_add.argtypes = [vp, vp, vp, i64, vp]
+    lib.pi_op_topk_reserve.argtypes = [i32]
     lib.pi_op_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]

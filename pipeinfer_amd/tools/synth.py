@@ -274,7 +274,7 @@ def _vocab_kv(w, arch, n_vocab, vocab=None):
 
 
 def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random", noise=1.0, quantizer=None, vocab=None,
-                falcon_two_norms=None, pi_seed=1234, signal=1.0):
+                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0):
     """quantizer(ttype, f32 [rows,k]) -> uint8 blocks: when given (tests: the REAL reference quantiser), every weight is
     drawn as N(0,std^2) floats and quantised with it; otherwise blocks are filled directly (see module docstring)."""
     arch, n_layer, n_embd, n_head, n_head_kv, n_ff, n_vocab, n_ctx_train = SPECS[spec_name]
@@ -319,7 +319,7 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
                     mat = e * np.float32(signal)
                 else:
                     mat = np.empty_like(e)
-                    mat[pi] = e * np.float32(std * 4)                      # logits[pi[t]] = <e_t, normed h> is the winner
+                    mat[pi] = e * np.float32(head_gain / np.sqrt(n_embd))   # logit of pi[t] ~ head_gain*sqrt(n_embd)*cos(h, e_t); unrelated logits ~ N(0, head_gain^2)
                 return (quantizer or quantize_simple)(ttype, mat) if quantizer else quantize_simple(ttype, mat)
             s = std * (noise if (structure == "bigram" and role == "out") else 1.0)
             if quantizer is not None:

@@ -39,6 +39,6 @@ for (hd, n_head, n_head_kv, n_kv, n_tok) in [(64, 4, 1, 32, 7), (64, 4, 2, 32, 1
     q16 = O.f32_to_f16_bits(q)
     out = U.Dev(nbytes=4 * n_tok * n_head * hd)
     qd, kd, vd, md = U.Dev(q16), U.Dev(k_rows), U.Dev(v_rows), U.Dev(mask_bits(mask))
-    L.check(lib.pi_op_attention(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None))
+    L.check(lib.pi_op_attention(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None, None))
     got = out.get(np.float32, want.shape)
     print("ATT", hd, n_head, n_head_kv, n_kv, n_tok, "err", np.abs(got - want).max())

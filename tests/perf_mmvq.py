@@ -1,0 +1,32 @@
+"""micro-benchmark of the mat-vec kernel per shape (not a test): python tests/perf_mmvq.py"""
+import os, sys, time, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import gpu_util as U, oracle_lib as O
+from pipeinfer_amd.tools import synth
+from pipeinfer_amd import lib as L
+lib = U.init()
+shapes = [(O.Q4_K, 4096, 4096), (O.Q4_K, 11008, 4096), (O.Q4_K, 4096, 11008), (O.Q6_K, 32000, 4096), (O.Q4_K, 2048, 2048), (O.Q4_K, 5632, 2048), (O.Q4_K, 256, 2048), (O.Q6_K, 4096, 11008), (O.Q4_0, 4096, 4096)]
+if len(sys.argv) > 1:
+    shapes = shapes[:int(sys.argv[1])]
+for t, rows, k in shapes:
+    rng = np.random.default_rng(1)
+    blocks = synth.random_blocks(t, rows * k, rng, 0.05)
+    w = lib.pi_weight_upload(t, k, rows, blocks.ctypes.data_as(C.c_void_p), None)
+    for nt in (1, 4, 8):
+        act = rng.standard_normal((nt, k)).astype(np.float32)
+        vdt = O.VEC_DOT_TYPE[t]
+        xd = U.Dev(act); q8 = U.Dev(nbytes=lib.pi_q8_nbytes(vdt, k, nt)); out = U.Dev(nbytes=4 * nt * rows)
+        L.check(lib.pi_op_quantize(vdt, xd.ptr, k, nt, q8.ptr, None))
+        for _ in range(5):
+            lib.pi_op_mul_mat(w, q8.ptr, nt, out.ptr, None, None)
+        lib.pi_device_sync()
+        n = 200
+        t0 = time.perf_counter()
+        for _ in range(n):
+            lib.pi_op_mul_mat(w, q8.ptr, nt, out.ptr, None, None)
+        lib.pi_device_sync()
+        dt = (time.perf_counter() - t0) / n
+        nbytes = lib.pi_weight_nbytes(w)
+        print(f"{O.TYPE_NAMES[t]:5s} M={rows:6d} K={k:6d} NT={nt}: {dt*1e6:7.2f} us/launch  {nbytes/dt/1e9:8.1f} GB/s  ({nbytes/1e6:.1f} MB)")
+    lib.pi_weight_free(w)

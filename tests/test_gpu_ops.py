@@ -211,7 +211,7 @@ def test_rope_kv_store_exact(gpu, neox, hd, n_head, n_head_kv):
     q16, kc, vc = U.Dev(nbytes=2 * q.size), U.Dev(nbytes=2 * n_ctx * g), U.Dev(nbytes=2 * n_ctx * g)
     qd, kd, vd, pd = U.Dev(q), U.Dev(k), U.Dev(v), U.Dev(pos)      # keep the buffers alive across the launch
     L.check(lib.pi_op_rope_kv_store(qd.ptr, kd.ptr, vd.ptr, n_head * hd, n_head_kv * hd, n_head_kv * hd, pd.ptr, table, neox, hd, n_head, n_head_kv, n_tok, kv_head,
-                                    q16.ptr, kc.ptr, vc.ptr, None))
+                                    q16.ptr, kc.ptr, vc.ptr, None, None))
     mode = 2 if neox else 0
     assert np.array_equal(q16.get(np.uint16, q.shape), O.f32_to_f16_bits(o.rope(q, pos, mode)))
     kc_h = kc.get(np.uint16, (n_ctx, g))
@@ -254,7 +254,8 @@ def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
     q16 = O.f32_to_f16_bits(q)
     out = U.Dev(nbytes=4 * n_tok * n_head * hd)
     qd, kd, vd, md = U.Dev(q16), U.Dev(k_rows), U.Dev(v_rows), U.Dev(mask_bits(mask))
-    L.check(lib.pi_op_attention(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None))
+    L.check(lib.pi_op_attention_reserve(hd, n_kv))
+    L.check(lib.pi_op_attention(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None, None))
     got = out.get(np.float32, want.shape)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()      # vec_dot_f16 order + exact soft-max sum
 
@@ -303,3 +304,36 @@ def test_topk(gpu, n_vocab):
         want = np.exp((logits[t] - logits[t].max()).astype(np.float64)).sum()
         assert abs(gs[t] - want) / want < 1e-5
     assert gi[1, 0] == 7 and gi[1, 1] == 100
+
+
+@pytest.mark.parametrize("vdt,n", [(O.Q8_K, 256), (O.Q8_K, 4096), (O.Q8_K, 8192), (O.Q8_K, 11008), (O.Q8_0, 4544), (O.Q8_0, 256), (O.Q8_0, 18176)])
+def test_fused_norm_and_activation_quantisers(gpu, vdt, n):
+    """norm+quantise and act+quantise launches == the separate operators (same bytes as the oracle's quantiser on the oracle's op output)"""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    n_tok = 3
+    x = np.stack([signal(n, s) for s in range(n_tok)])
+    rng = np.random.default_rng(n)
+    w = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    xd, wd, bd = U.Dev(x), U.Dev(w), U.Dev(b)
+    for rms in (1, 0):
+        q8 = U.Dev(nbytes=lib.pi_q8_nbytes(vdt, n, n_tok))
+        yf = U.Dev(nbytes=x.nbytes)
+        L.check(lib.pi_op_norm_quantize(xd.ptr, wd.ptr, bd.ptr if not rms else None, yf.ptr, n, n_tok, 1e-5, rms, vdt, q8.ptr, None))
+        want_y = (o.rms_norm(x, 1e-5) * w) if rms else (o.norm(x, 1e-5) * w + b)
+        got_y = yf.get(np.float32, x.shape)
+        assert np.abs(got_y - want_y).max() <= 4e-7 * np.abs(want_y).max()
+        got = U.q8_as_ref_blocks(vdt, *U.q8_planes(lib, vdt, n, n_tok, q8))
+        for t in range(n_tok):
+            assert np.array_equal(got[t], o.quantize_act(vdt, got_y[t]))
+    g = np.stack([signal(n, 10 + s) for s in range(n_tok)]); u = np.stack([signal(n, 20 + s) for s in range(n_tok)])
+    gd, ud = U.Dev(g), U.Dev(u)
+    for which in (0, 1):
+        q8 = U.Dev(nbytes=lib.pi_q8_nbytes(vdt, n, n_tok))
+        L.check(lib.pi_op_act_quantize(gd.ptr, ud.ptr if which == 0 else None, which, n, n_tok, vdt, q8.ptr, None))
+        h = o.silu(g) * u if which == 0 else o.gelu(g)
+        got = U.q8_as_ref_blocks(vdt, *U.q8_planes(lib, vdt, n, n_tok, q8))
+        for t in range(n_tok):
+            assert np.array_equal(got[t], o.quantize_act(vdt, h[t]))
