@@ -92,8 +92,8 @@ PI_API int pi_op_silu_mul(const float * gate_dev, const float * up_dev, float * 
 PI_API int pi_op_gelu(const float * x_dev, float * out_dev, int64_t n, void * stream);
 PI_API int pi_op_add(const float * a_dev, const float * b_dev, float * out_dev, int64_t n, void * stream);
 /* per token: ids/logits of the k largest (logit desc, id asc), max logit and sum_i expf(l_i - max) over the full vocab */
-PI_API int pi_op_topk_reserve(int n_tok_max);                       /* once, outside graph capture */
-PI_API int pi_op_topk(const float * logits_dev, int n_vocab, int n_tok, int k, int32_t * ids_dev, float * vals_dev, float * sumexp_dev, void * stream);
+PI_API size_t pi_op_topk_scratch_bytes(int n_tok);                  /* caller-owned scratch, one per stream */
+PI_API int pi_op_topk(const float * logits_dev, int n_vocab, int n_tok, int k, int32_t * ids_dev, float * vals_dev, float * sumexp_dev, void * scratch_dev, void * stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ llama_context::~llama_context() {
         delete r;
     }
     for (auto & kv : graphs) if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
-    void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, q8c, tokens_dev, pos_dev, dyn_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev };
+    void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, q8c, tokens_dev, pos_dev, dyn_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev, topk_scratch_dev };
     for (void * b : bufs) pi_free(b);
     if (rope) pi_rope_table_free(rope);
     if (stream) (void) hipStreamDestroy(stream);
@@ -75,12 +75,13 @@ bool context_prepare(llama_context * ctx, std::string & err) {
         !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev(64)))
         return false;
     ctx->use_graphs = getenv("PI_NO_GRAPHS") == nullptr;
-    if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0 || pi_op_topk_reserve(nb) != 0) { err = pi_last_error(); return false; }
+    if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0) { err = pi_last_error(); return false; }
     ctx->mask_cap_words = (size_t) nb * ((ctx->n_ctx + 31) / 32);
     if (!(ctx->mask_dev = (uint32_t *) dev(ctx->mask_cap_words * 4))) return false;
     if (ctx->is_last) {
         if (!(ctx->logits_dev = (float *) dev((size_t) 4 * nb * hp.n_vocab)) || !(ctx->topk_ids_dev = (int32_t *) dev((size_t) 4 * nb * 8)) ||
-            !(ctx->topk_vals_dev = (float *) dev((size_t) 4 * nb * 8)) || !(ctx->topk_sum_dev = (float *) dev((size_t) 4 * nb)))
+            !(ctx->topk_vals_dev = (float *) dev((size_t) 4 * nb * 8)) || !(ctx->topk_sum_dev = (float *) dev((size_t) 4 * nb)) ||
+            !(ctx->topk_scratch_dev = dev(pi_op_topk_scratch_bytes(nb))))
             return false;
     }
     if (hipDeviceSynchronize() != hipSuccess) { err = "hipDeviceSynchronize failed after allocation"; return false; }
@@ -197,7 +198,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
         if (hp.arch == PI_ARCH_LLAMA) { if (!norm_for(ctx, x, m->output_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vo, ctx->q8a)) return false; }
         else                          { if (!norm_for(ctx, x, m->output_norm, m->output_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vo, ctx->q8a)) return false; }
         OP_OK(pi_op_mul_mat(m->output, ctx->q8a, n_tok, ctx->logits_dev, nullptr, s));
-        OP_OK(pi_op_topk(ctx->logits_dev, hp.n_vocab, n_tok, 8, ctx->topk_ids_dev, ctx->topk_vals_dev, ctx->topk_sum_dev, s));
+        OP_OK(pi_op_topk(ctx->logits_dev, hp.n_vocab, n_tok, 8, ctx->topk_ids_dev, ctx->topk_vals_dev, ctx->topk_sum_dev, ctx->topk_scratch_dev, s));
     }
     return true;
 }

@@ -93,7 +93,7 @@ struct llama_context {
     struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; };
     std::map<int, graph_entry> graphs;       // one captured forward pass per n_tokens (kv_head / n_kv come from dyn_dev)
     bool use_graphs = true;
-    int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr;
+    int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr; void * topk_scratch_dev = nullptr;
     size_t mask_cap_words = 0;
 
     std::deque<pi_run *> inflight;            // oldest at front

@@ -121,6 +121,11 @@ struct driver {
         if (!is_spec) pipeinfer_kv_cache_seq_rm_range(ctx, 0, max_seq, n_past, n_past + 1);
         else          pipeinfer_kv_cache_seq_rm_range(ctx, seq_offset, seq_offset + n_seq_dft - 1, n_past, n_past + 1);
         run->ticket = llama_start_async_decode(ctx, run->batch.view());
+        if (P.verbose) {
+            fprintf(stderr, "[spec] launch %s batch=%d ctx=%s off=%d n_past=%d n_past_max=%d prefix=%d tokens:", is_spec ? "SPEC" : "nonspec", batch_id, ctx == tgt ? "tgt" : "dft", seq_offset, n_past, n_past_max, prefix_n_past);
+            for (int i = 0; i < run->batch.n_tokens(); i++) { fprintf(stderr, " %d@%d{", run->batch.token[i], run->batch.pos[i]); for (auto q : run->batch.seq[i]) fprintf(stderr, "%d,", q); fprintf(stderr, "}"); }
+            fprintf(stderr, "\n");
+        }
         runs.push_front(run);
         if (!is_spec) pipeinfer_kv_cache_seq_cp_range(ctx, 0, 1, max_seq, n_past, n_past + 1);
         if (is_spec) R.n_runs_spec++; else if (ctx == tgt) R.n_runs_nonspec++;
@@ -165,6 +170,7 @@ struct driver {
             if (run.n_past_max < n_past_tgt || !correct_prefix) {
                 if (run.speculative) canceled.push_back(run.batch.batch_id);
                 run.canceled = true;
+                if (P.verbose) fprintf(stderr, "[spec] cancel batch=%d spec=%d n_past_max=%d n_past_tgt=%d correct_prefix=%d\n", run.batch.batch_id, run.speculative, run.n_past_max, n_past_tgt, correct_prefix);
                 R.n_runs_canceled++;
             }
         }
@@ -346,6 +352,7 @@ struct driver {
             if (!tgt_runs.empty() && is_waiting) {
                 check_for_cancel();
                 std::shared_ptr<async_run> run = tgt_runs.back();
+                if (P.verbose) fprintf(stderr, "[spec] finish batch=%d spec=%d canceled=%d s_keep=%d n_past_tgt=%d\n", run->batch.batch_id, run->speculative, run->canceled, run->s_keep, n_past_tgt);
                 if (!run->canceled) {
                     drafts = run->drafts;
                     current.speculative = run->speculative; current.n_past_max = run->n_past_max; current.n_past_tgt = run->n_past_tgt;
@@ -384,6 +391,7 @@ struct driver {
                         itt_start = pi::time_us();
                     }
                     generated.push_back(id);
+                    if (P.verbose) fprintf(stderr, "[spec] ACCEPT %d at gen index %zu (i_dft=%d idx=%d cur.n_past_tgt=%d spec=%d)\n", id, generated.size() - 1, i_dft, drafts[keeps[0]].i_batch_tgt[i_dft], current.n_past_tgt, current.speculative);
                     if (n_out < out_cap) out[n_out++] = id;
                 }
                 if (id == eos) has_eos = true;

@@ -499,24 +499,13 @@ __global__ void __launch_bounds__(64) k_topk2(int k, const int32_t * __restrict_
     if (lane == 0) sumexp[t] = s;
 }
 
-static float * g_topk_scratch = nullptr; static size_t g_topk_cap = 0;
-// sizes the scratch of pi_op_topk for up to n_tok_max rows; call once outside any graph capture
-extern "C" int pi_op_topk_reserve(int n_tok_max) {
-    const size_t need = (size_t) n_tok_max * TOPK_NCH * (2 * 8 + 2) * 4;
-    if (need > g_topk_cap) {
-        PI_CHECK_HIP(hipDeviceSynchronize());
-        if (g_topk_scratch) (void) hipFree(g_topk_scratch);
-        g_topk_cap = need;
-        PI_CHECK_HIP(hipMalloc((void **) &g_topk_scratch, g_topk_cap));
-    }
-    return 0;
-}
-extern "C" int pi_op_topk(const float * logits, int n_vocab, int n_tok, int k, int32_t * ids, float * vals, float * sumexp, void * stream) {
+// bytes of caller-owned scratch pi_op_topk needs for n_tok rows (one buffer per stream: contexts decode concurrently)
+extern "C" size_t pi_op_topk_scratch_bytes(int n_tok) { return (size_t) n_tok * TOPK_NCH * (2 * 8 + 2) * 4; }
+extern "C" int pi_op_topk(const float * logits, int n_vocab, int n_tok, int k, int32_t * ids, float * vals, float * sumexp, void * scratch, void * stream) {
     if (n_tok <= 0) return 0;
     if (k > 8) { pi_set_error("pi_op_topk: k=%d > 8", k); return -1; }
-    const size_t need = (size_t) n_tok * TOPK_NCH * (2 * k + 2) * 4;
-    if (need > g_topk_cap) { if (pi_op_topk_reserve(n_tok < 64 ? 64 : n_tok) != 0) return -1; }
-    int32_t * cid = (int32_t *) g_topk_scratch; float * cval = (float *) (cid + (size_t) n_tok * TOPK_NCH * k);
+    if (!scratch) { pi_set_error("pi_op_topk: scratch is NULL (needs pi_op_topk_scratch_bytes(n_tok) bytes)"); return -1; }
+    int32_t * cid = (int32_t *) scratch; float * cval = (float *) (cid + (size_t) n_tok * TOPK_NCH * k);
     float * cmax = cval + (size_t) n_tok * TOPK_NCH * k, * csum = cmax + (size_t) n_tok * TOPK_NCH;
     hipLaunchKernelGGL(k_topk1, dim3(n_tok, TOPK_NCH), dim3(256), 0, (hipStream_t) stream, logits, n_vocab, k, cid, cval, cmax, csum);
     hipLaunchKernelGGL(k_topk2, dim3(n_tok), dim3(64), 0, (hipStream_t) stream, k, cid, cval, cmax, csum, ids, vals, sumexp);

@@ -106,5 +106,5 @@ def _declare(lib):
     lib.pi_op_silu_mul.argtypes = [vp, vp, vp, i64, vp]
     lib.pi_op_gelu.argtypes = [vp, vp, i64, vp]
     lib.pi_op_add.argtypes = [vp, vp, vp, i64, vp]
-    lib.pi_op_topk_reserve.argtypes = [i32]
-    lib.pi_op_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.pi_op_topk_scratch_bytes.argtypes = [i32]; lib.pi_op_topk_scratch_bytes.restype = C.c_size_t
+    lib.pi_op_topk.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -130,6 +130,20 @@ def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split
         m.free()
 
 
+def test_pipeinfer_driver_lossless_under_timing_jitter(LL):
+    """the driver's control flow depends on which run finishes first, so repeat one configuration with fresh contexts
+    (this caught target and draft contexts racing on a shared top-k scratch buffer)."""
+    tgt, dft = "tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"
+    prompt, want = greedy_reference(tgt, 8, 24)
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    for trial in range(25):
+        ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
+        out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=3, n_parallel=3, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=trial % 3)
+        assert out[:24] == want, (trial, out, want, res)
+        ct.free(); cd.free()
+    mt.free(); md.free()
+
+
 def test_target_only_mode_matches(LL):
     prompt, want = greedy_reference("tiny_llama_q4_k_m", 8, 24)
     mt = LL.Model(os.path.join(GOLD, "tiny_llama_q4_k_m.gguf"))

@@ -295,7 +295,8 @@ def test_topk(gpu, n_vocab):
     logits[2, 5] = -np.inf
     ids, vals, se = U.Dev(nbytes=4 * 3 * 8), U.Dev(nbytes=4 * 3 * 8), U.Dev(nbytes=4 * 3)
     ld = U.Dev(logits)
-    L.check(lib.pi_op_topk(ld.ptr, n_vocab, 3, 8, ids.ptr, vals.ptr, se.ptr, None))
+    scr = U.Dev(nbytes=lib.pi_op_topk_scratch_bytes(3))
+    L.check(lib.pi_op_topk(ld.ptr, n_vocab, 3, 8, ids.ptr, vals.ptr, se.ptr, scr.ptr, None))
     gi, gv, gs = ids.get(np.int32, (3, 8)), vals.get(np.float32, (3, 8)), se.get(np.float32)
     for t in range(3):
         order = np.lexsort((np.arange(n_vocab), -logits[t]))[:8]
