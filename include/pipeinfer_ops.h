@@ -71,6 +71,8 @@ PI_API int pi_op_norm_quantize(const float * x_dev, const float * w_dev, const f
 PI_API int pi_op_act_quantize(const float * gate_dev, const float * up_dev, int which, int64_t n, int n_tok, int vdt, void * q8_dev, void * stream);
 /* out[t][row] = (residual ? residual[t][row] : 0) + W[row] . act[t]      out/residual: f32 [n_tok][ne1] */
 PI_API int pi_op_mul_mat(const pi_weight * w, const void * q8_dev, int n_tok, float * out_dev, const float * residual_dev, void * stream);
+/* up to 3 weights of one type and width applied to the same activations in ONE launch (wq/wk/wv, ffn_up/ffn_gate); same results as separate calls */
+PI_API int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void * q8_dev, int n_tok, float * const * outs_dev, const float * const * residuals_dev, void * stream);
 
 /* RoPE tables as the reference iterates them: cos/sin [n_pos][head_dim/2] f32, built on the host (theta *= theta_scale) */
 PI_API void *  pi_rope_table_create(int n_pos, int head_dim, float freq_base, float freq_scale, int neox);

@@ -135,6 +135,19 @@ static bool norm_for(llama_context * ctx, const float * x, const float * w, cons
     return true;
 }
 
+// weights of the same type that read the same quantised activations go out as one launch (pi_op_mul_mat_multi)
+static bool mul_mat_grouped(int n, const pi_weight * const * ws, const void * const * ins, float * const * outs, int n_tok, hipStream_t s) {
+    bool done[3] = { false, false, false };
+    for (int i = 0; i < n; i++) {
+        if (done[i]) continue;
+        const pi_weight * gw[3]; float * go[3]; int ng = 0;
+        for (int j = i; j < n; j++)
+            if (!done[j] && pi_weight_type(ws[j]) == pi_weight_type(ws[i]) && ins[j] == ins[i]) { gw[ng] = ws[j]; go[ng] = outs[j]; ng++; done[j] = true; }
+        if (pi_op_mul_mat_multi(ng, gw, ins[i], n_tok, go, nullptr, s) != 0) return false;
+    }
+    return true;
+}
+
 static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
     llama_model * m = ctx->model;
     const pi_hparams & hp = m->hparams;
@@ -150,11 +163,14 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             float * q = ctx->qkv, * k = q + (size_t) n_tok * n_embd, * v = k + (size_t) n_tok * n_gqa;
             const int vq = vdt_of(L.wq);
             if (!norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vq, ctx->q8a)) return false;
-            OP_OK(pi_op_mul_mat(L.wq, ctx->q8a, n_tok, q, nullptr, s));
             if (vdt_of(L.wk) != vq && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wk), ctx->q8c)) return false;
-            OP_OK(pi_op_mul_mat(L.wk, vdt_of(L.wk) == vq ? ctx->q8a : ctx->q8c, n_tok, k, nullptr, s));
             if (vdt_of(L.wv) != vq && vdt_of(L.wv) != vdt_of(L.wk) && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wv), ctx->q8c)) return false;
-            OP_OK(pi_op_mul_mat(L.wv, vdt_of(L.wv) == vq ? ctx->q8a : ctx->q8c, n_tok, v, nullptr, s));
+            {   // projections of the same type share one launch
+                const pi_weight * ws[3] = { L.wq, L.wk, L.wv };
+                const void * ins[3] = { ctx->q8a, vdt_of(L.wk) == vq ? ctx->q8a : ctx->q8c, vdt_of(L.wv) == vq ? ctx->q8a : ctx->q8c };
+                float * outs[3] = { q, k, v };
+                if (!mul_mat_grouped(3, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
+            }
             trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
             OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, s));
@@ -163,9 +179,13 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, x, s));                                                   // ffn_inp = wo.att + inpSA
             const int vu = vdt_of(L.ffn_up);
             if (!norm_for(ctx, x2, L.ffn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vu, ctx->q8a)) return false;
-            OP_OK(pi_op_mul_mat(L.ffn_up, ctx->q8a, n_tok, ctx->up, nullptr, s));
             if (vdt_of(L.ffn_gate) != vu && !norm_for(ctx, x2, L.ffn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.ffn_gate), ctx->q8c)) return false;
-            OP_OK(pi_op_mul_mat(L.ffn_gate, vdt_of(L.ffn_gate) == vu ? ctx->q8a : ctx->q8c, n_tok, ctx->gate, nullptr, s));
+            {
+                const pi_weight * ws[2] = { L.ffn_up, L.ffn_gate };
+                const void * ins[2] = { ctx->q8a, vdt_of(L.ffn_gate) == vu ? ctx->q8a : ctx->q8c };
+                float * outs[2] = { ctx->up, ctx->gate };
+                if (!mul_mat_grouped(2, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
+            }
             OP_OK(pi_op_act_quantize(ctx->gate, ctx->up, 0, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));        // silu(gate) * up
             OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, x2, s));                                             // l_out = down(..) + ffn_inp
             trace(ctx, "lout", il, x, n_embd, n_tok);

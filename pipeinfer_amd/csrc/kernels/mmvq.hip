@@ -17,18 +17,28 @@
 // Weights are streamed from HBM exactly once, straight into registers.
 #include "ops_common.h"
 
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
-#define MMVQ_TILE 16            // K-quant super-blocks (or groups of four 32-blocks) staged in LDS per step
+#define MMVQ_TILE 16            // groups of four 32-blocks staged in LDS per step (Q4_0/Q8_0 kernel)
 
+// up to three weight matrices of one type and width share a launch (wq/wk/wv, ffn_up/ffn_gate): one activation, more bytes
+// per kernel — at decode sizes a launch costs ~3.5 us before HBM is streaming, so fewer, larger launches matter.
+#define MMVQ_MAX_SEG 3
+struct mmvq_seg {
+    const uint8_t * p0, * p1, * p2;
+    float *         out;        // [n_tok][M]
+    const float *   res;        // nullable
+    int             M;
+    int             wave0;      // first wave (K-quant kernel) of this segment
+};
 struct mmvq_args {
-    pi_weight w;
+    mmvq_seg seg[MMVQ_MAX_SEG];
     const uint8_t * aq;         // activation planes (pi_q8_layout)
     const uint8_t * ad;
     const uint8_t * abs_;
-    float *         out;        // [n_tok][M]
-    const float *   res;        // nullable
-    int M, K, nb;               // nb: super-blocks (K-quants) or groups of 4 blocks (Q4_0/Q8_0) per row
+    int K, nb;                  // nb: super-blocks (K-quants) or groups of 4 blocks (Q4_0/Q8_0) per row
 };
 
 static __device__ __forceinline__ int bytes_sub(int v, int c) {            // per-byte v - c for bytes whose result fits int8 (no borrow across bytes)
@@ -46,172 +56,254 @@ static __device__ __forceinline__ float hsum8_lanes(float a) {
 
 // ================================================================================================================
 // K-quants x Q8_K
+//
+// The integer part of a block's dot product is exact in any order; only the fp32 accumulation (eight chains per row and
+// token, one fma per block in block order) is ordered.  The kernel separates the two:
+//
+//   produce  work item = (row r, block b) handled by a quad of lanes; lane c of the quad owns accumulator lanes k = 2c and
+//            2c+1 (two 16-byte k-records of the block = 64 weights), unpacks the 6-bit scales once for both, and leaves
+//            (float) sumi[k] and the block scale product d_x * d_y in a per-wave LDS exchange buffer.  A wave takes 16
+//            items at a time — with 4096-wide rows that is one whole row per step — and R rows per tile of 16 blocks;
+//            weights stream from HBM exactly once with the next item's loads issued before the current item is touched.
+//   chain    lane (p, k), p = (row, token) pair, extends chain k of pair p by the tile's blocks in order:
+//            acc = fma(d, sumi, acc) — 16 dependent fmas per tile for up to 8 pairs at once.
+//
+// Waves never synchronise with each other (the exchange buffer is wave-private), so a launch is M/R independent waves.
+// VALU work per 16 weight bytes is what bounds this kernel once HBM is streaming (v_dot4 + scale multiply + nibble
+// unpack ~ 60 instructions); see DESIGN.md for the count against the HBM rate.
 // ================================================================================================================
-template <int TYPE, int NT>
+#define KQ_TB 16                // blocks per tile
+template <int TYPE> struct kq_raw { uint4 hdr, qa, qb, h; uint32_t d; };     // one lane's share of a block (k = 2c, 2c+1)
+
+template <int TYPE>
+static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk, int c, kq_raw<TYPE> & o) {
+    if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
+        constexpr int BS = TYPE == PI_Q4_K ? 144 : 176, QOFF = TYPE == PI_Q4_K ? 16 : 48;
+        const uint8_t * p = w.p0 + (size_t) blk * BS;
+        o.hdr = *(const uint4 *) p;
+        o.qa  = *(const uint4 *) (p + QOFF + 32 * c);
+        o.qb  = *(const uint4 *) (p + QOFF + 32 * c + 16);
+        if constexpr (TYPE == PI_Q5_K) { const uint2 hh = *(const uint2 *) (p + 16 + 8 * c); o.h.x = hh.x; o.h.y = hh.y; }
+    } else {
+        const uint8_t * p = w.p0 + (size_t) blk * 192;
+        o.qa  = *(const uint4 *) (p + 32 * c);
+        o.qb  = *(const uint4 *) (p + 32 * c + 16);
+        o.h   = *(const uint4 *) (p + 128 + 16 * c);
+        o.hdr = *(const uint4 *) (w.p1 + (size_t) blk * 16);
+        o.d   = ((const uint16_t *) w.p2)[blk];
+    }
+}
+
+// 32 weights of accumulator lane k as 8 dwords in activation order (dword i pairs with sub-block / group i)
+template <int TYPE>
+static __device__ __forceinline__ void kq_unpack_w(const uint4 qv, uint32_t h0, uint32_t h1, int * wq) {
+    const int q[4] = { (int) qv.x, (int) qv.y, (int) qv.z, (int) qv.w };
+    if constexpr (TYPE == PI_Q4_K) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { wq[2 * j] = q[j] & 0x0F0F0F0F; wq[2 * j + 1] = (q[j] >> 4) & 0x0F0F0F0F; }
+    } else if constexpr (TYPE == PI_Q5_K) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t h = h0 >> (2 * j);
+            wq[2 * j]     = (q[j] & 0x0F0F0F0F)        | (int) ((h & 0x01010101u) << 4);
+            wq[2 * j + 1] = ((q[j] >> 4) & 0x0F0F0F0F) | (int) ((h & 0x02020202u) << 3);
+        }
+    } else {
+        const uint32_t hh[2] = { h0, h1 };
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const uint32_t h = hh[n];
+            const int la = q[2 * n], lb = q[2 * n + 1];
+            wq[4 * n + 0] = bytes_sub((la & 0x0F0F0F0F)        | (int) ((h & 0x03030303u) << 4),        0x20202020);
+            wq[4 * n + 1] = bytes_sub((lb & 0x0F0F0F0F)        | (int) (((h >> 2) & 0x03030303u) << 4), 0x20202020);
+            wq[4 * n + 2] = bytes_sub(((la >> 4) & 0x0F0F0F0F) | (int) (((h >> 4) & 0x03030303u) << 4), 0x20202020);
+            wq[4 * n + 3] = bytes_sub(((lb >> 4) & 0x0F0F0F0F) | (int) (((h >> 6) & 0x03030303u) << 4), 0x20202020);
+        }
+    }
+}
+
+template <int TYPE, int NP> struct kq_lds {                                  // floats per wave
+    static constexpr int SSTR = KQ_TB * 8 + 8, PSTR = KQ_TB + 1, MSTR = KQ_TB * 4 + 4;      // strides padded to spread banks
+    static constexpr int S = 0, P = S + NP * SSTR, SM = P + NP * PSTR,
+                         PM = SM + (TYPE == PI_Q4_K ? NP * MSTR : TYPE == PI_Q5_K ? NP * PSTR : 0),
+                         FLOATS = (PM + (TYPE == PI_Q6_K ? 0 : NP * PSTR) + 3) & ~3;
+};
+
+static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int TYPE> struct kq_act { int y[2][8]; float dy; int bsA, bsB; };      // one token's share of a block for lanes 2c, 2c+1
+
+template <int TYPE>
+static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t ab, int c, kq_act<TYPE> & a) {
+    const uint4 * yp = (const uint4 *) (g.aq + ab * 256 + 64 * c);
+    const uint4 y0 = yp[0], y1 = yp[1], y2 = yp[2], y3 = yp[3];
+    a.y[0][0] = (int) y0.x; a.y[0][1] = (int) y0.y; a.y[0][2] = (int) y0.z; a.y[0][3] = (int) y0.w;
+    a.y[0][4] = (int) y1.x; a.y[0][5] = (int) y1.y; a.y[0][6] = (int) y1.z; a.y[0][7] = (int) y1.w;
+    a.y[1][0] = (int) y2.x; a.y[1][1] = (int) y2.y; a.y[1][2] = (int) y2.z; a.y[1][3] = (int) y2.w;
+    a.y[1][4] = (int) y3.x; a.y[1][5] = (int) y3.y; a.y[1][6] = (int) y3.z; a.y[1][7] = (int) y3.w;
+    a.dy = ((const float *) g.ad)[ab];
+    a.bsA = a.bsB = 0;
+    if constexpr (TYPE != PI_Q6_K) {                                         // int16 pair sums like _mm_hadd_epi16
+        const short4 bs = *(const short4 *) (g.abs_ + ab * 32 + 8 * c);
+        a.bsA = (int) (short) (bs.x + bs.y); a.bsB = (int) (short) (bs.z + bs.w);
+    }
+}
+
+template <int TYPE, int NT, int R>
 __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    // LDS tile: qs [NT][TILE][256] | d [NT][TILE] f32 | bsums [NT][TILE][16] i16
-    uint8_t * l_qs = lds;
-    float   * l_d  = (float *) (lds + (size_t) NT * MMVQ_TILE * 256);
-    int16_t * l_bs = (int16_t *) ((uint8_t *) l_d + (size_t) NT * MMVQ_TILE * 4);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane >> 3, k = lane & 7;
-    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
-    const bool live = row < g.M;
-    const int64_t rowc = live ? row : g.M - 1;
+    constexpr int NP = R * NT, NIT = (NP + 7) / 8;
+    constexpr int TG = 4;                                                    // tokens whose activations are held in registers at once
+    using L = kq_lds<TYPE, NP>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float * xs = (float *) lds + (size_t) wave * L::FLOATS;
+    const int q = lane >> 2, c = lane & 3;                                   // producer role: quad q, accumulator lanes 2c, 2c+1
+    const int s = lane >> 3, k = lane & 7;                                   // chain role: pair slot s, accumulator lane k
+    const int wave_id = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int si = (wave_id >= g.seg[1].wave0) + (wave_id >= g.seg[2].wave0);
+    const mmvq_seg & sg = g.seg[si];
+    const int64_t row0 = (int64_t) (wave_id - sg.wave0) * R;
+    if (row0 >= sg.M) return;                                                // waves never synchronise with each other
     const int nb = g.nb;
+    const int rows = sg.M - row0 < R ? (int) (sg.M - row0) : R;
 
-    float acc[NT], accm[NT];
+    float acc[NIT], accm[NIT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) { acc[t] = 0.0f; accm[t] = 0.0f; }
+    for (int ci = 0; ci < NIT; ci++) { acc[ci] = 0.0f; accm[ci] = 0.0f; }
 
-    for (int b0 = 0; b0 < nb; b0 += MMVQ_TILE) {
-        const int nbt = min(MMVQ_TILE, nb - b0);
-        // issue every weight load of the tile before the first use: with only M/8 waves in a launch the bytes in flight per
-        // wave, not occupancy, are what keeps HBM busy (16 blocks x 8 rows x 144 B = 18 KB per wave)
-        uint4 w_hdr[MMVQ_TILE], w_q[MMVQ_TILE]; uint2 w_h[MMVQ_TILE]; uint16_t w_d[MMVQ_TILE];
+    // quad q -> (row offset, block) of a tile; the block is the same for every step of the tile, so the activations are too
+    auto tile_map = [&](int b0, int & nbt, int & rpi, int & r_off, int & b) {
+        nbt = nb - b0 < KQ_TB ? nb - b0 : KQ_TB;
+        rpi = nbt == KQ_TB ? 1 : KQ_TB / nbt;                                // rows per step
+        r_off = nbt == KQ_TB ? 0 : q / nbt;
+        b = nbt == KQ_TB ? q : q - r_off * nbt;
+    };
+    // every weight load of a tile (R items) is issued before the previous tile is consumed: loads are unconditional, indices clamped
+    auto tile_load = [&](int b0, kq_raw<TYPE> * raw) {
+        int nbt, rpi, r_off, b;
+        tile_map(b0 < nb ? b0 : 0, nbt, rpi, r_off, b);
 #pragma unroll
-        for (int bi = 0; bi < MMVQ_TILE; bi++) {
-            {   // unconditional (indices clamped): arrays filled under divergent control flow would be demoted to scratch
-                const int64_t blk = rowc * nb + b0 + (bi < nbt ? bi : nbt - 1);
-                if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
-                    constexpr int BS = TYPE == PI_Q4_K ? 144 : 176, QOFF = TYPE == PI_Q4_K ? 16 : 48;
-                    const uint8_t * p = g.w.p0 + blk * BS;
-                    w_hdr[bi] = *(const uint4 *) p;
-                    w_q[bi] = *(const uint4 *) (p + QOFF + 16 * k);
-                    if constexpr (TYPE == PI_Q5_K) w_h[bi].x = *(const uint32_t *) (p + 16 + 4 * k);
-                } else {
-                    const uint8_t * p = g.w.p0 + blk * 192;
-                    w_q[bi] = *(const uint4 *) (p + 16 * k);
-                    w_h[bi] = *(const uint2 *) (p + 128 + 8 * k);
-                    w_hdr[bi] = *(const uint4 *) (g.w.p1 + blk * 16);
-                    w_d[bi] = ((const uint16_t *) g.w.p2)[blk];
-                }
-            }
+        for (int i = 0; i < R; i++) {
+            const int r = r_off + i * rpi;
+            kq_load<TYPE>(sg, (uint32_t) ((row0 + (r < rows ? r : rows - 1)) * nb + (b0 < nb ? b0 : 0) + b), c, raw[i]);
         }
-        __syncthreads();
-        // ---- stage the activations of blocks [b0, b0+nbt) for all NT tokens (overlaps the weight loads in flight) ----
-        for (int u = tid; u < NT * nbt * 16; u += blockDim.x) {                 // 16-byte units of qs
-            const int t = u / (nbt * 16), rem = u % (nbt * 16);
-            *(uint4 *) (l_qs + ((size_t) t * MMVQ_TILE * 256) + rem * 16) = *(const uint4 *) (g.aq + ((size_t) t * nb + b0) * 256 + (size_t) rem * 16);
-        }
-        for (int u = tid; u < NT * nbt; u += blockDim.x) {
-            const int t = u / nbt, b = u % nbt;
-            l_d[t * MMVQ_TILE + b] = ((const float *) g.ad)[(size_t) t * nb + b0 + b];
-        }
-        for (int u = tid; u < NT * nbt * 2; u += blockDim.x) {                  // 16-byte units of bsums (32 B per block)
-            const int t = u / (nbt * 2), rem = u % (nbt * 2);
-            *(uint4 *) ((uint8_t *) l_bs + ((size_t) t * MMVQ_TILE * 32) + rem * 16) = *(const uint4 *) (g.abs_ + ((size_t) t * nb + b0) * 32 + (size_t) rem * 16);
-        }
-        __syncthreads();
-        if (!live) continue;
-
+    };
+    kq_raw<TYPE> raw[R], nxt[R];
+    tile_load(0, raw);
+    for (int b0 = 0; b0 < nb; b0 += KQ_TB) {
+        int nbt, rpi, r_off, b;
+        tile_map(b0, nbt, rpi, r_off, b);
+        const bool quad_on = r_off < rpi;
+        if (nb > KQ_TB) tile_load(b0 + KQ_TB, nxt);
 #pragma unroll
-        for (int bi = 0; bi < MMVQ_TILE; bi++) {
-          if (bi < nbt) {
-            float dx, dminx = 0.0f;
-            uint32_t scA = 0, scB = 0, mA = 0, mB = 0;
-            int q[4], qx[2] = { 0, 0 };
-            uint4 sc6 = { 0, 0, 0, 0 };
-            q[0] = w_q[bi].x; q[1] = w_q[bi].y; q[2] = w_q[bi].z; q[3] = w_q[bi].w;
-            if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
-                const uint4 hdr = w_hdr[bi];
-                if constexpr (TYPE == PI_Q5_K) qx[0] = (int) w_h[bi].x;
-                dx = pi_h2f((uint16_t) (hdr.x & 0xffff)); dminx = pi_h2f((uint16_t) (hdr.x >> 16));
-                // 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:1446-1453) unpacked four at a time like the reference's utmp[]
-                scA = hdr.y & 0x3f3f3f3fu;
-                mA  = hdr.z & 0x3f3f3f3fu;
-                scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
-                mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
-            } else {
-                qx[0] = (int) w_h[bi].x; qx[1] = (int) w_h[bi].y;
-                sc6 = w_hdr[bi];
-                dx = pi_h2f(w_d[bi]);
-            }
-            // token-independent unpacking of this lane's 32 weights (8 dwords, in the order the activations are stored)
-            int wq[8];
-            if constexpr (TYPE == PI_Q4_K) {
+        for (int t0 = 0; t0 < NT; t0 += TG) {                                // token groups: activations stay in registers across rows
+            constexpr int NG_MAX = NT < TG ? NT : TG;
+            kq_act<TYPE> act[NG_MAX];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { wq[2 * j] = q[j] & 0x0F0F0F0F; wq[2 * j + 1] = (q[j] >> 4) & 0x0F0F0F0F; }
-            } else if constexpr (TYPE == PI_Q5_K) {
+            for (int tt = 0; tt < NG_MAX; tt++) if (t0 + tt < NT) kq_load_act<TYPE>(g, (size_t) (t0 + tt) * nb + b0 + b, c, act[tt]);
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t h = (uint32_t) qx[0] >> (2 * j);
-                    wq[2 * j]     = (q[j] & 0x0F0F0F0F)        | (int) ((h & 0x01010101u) << 4);
-                    wq[2 * j + 1] = ((q[j] >> 4) & 0x0F0F0F0F) | (int) (((h >> 1) & 0x01010101u) << 4);
-                }
-            } else {
+            for (int i = 0; i < R; i++) {
+                const int r = r_off + i * rpi;
+                if (i * rpi < rows) {                                        // uniform: some quad still has a row in this step
+                    const bool valid = quad_on && r < rows;
+                    // ---- block-level unpack, shared by this lane's two accumulator lanes ----
+                    int wq[2][8], sc[8], m0 = 0, m1 = 0;
+                    float dx, dminx = 0.0f;
+                    if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
+                        const uint4 hdr = raw[i].hdr;
+                        dx = pi_h2f((uint16_t) (hdr.x & 0xffff)); dminx = pi_h2f((uint16_t) (hdr.x >> 16));
+                        // 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:1446-1453) unpacked four at a time like the reference's utmp[]
+                        const uint32_t scA = hdr.y & 0x3f3f3f3fu, mA = hdr.z & 0x3f3f3f3fu;
+                        const uint32_t scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
+                        const uint32_t mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
 #pragma unroll
-                for (int n = 0; n < 2; n++) {
-                    const uint32_t h = (uint32_t) qx[n];
-                    const int la = q[2 * n], lb = q[2 * n + 1];
-                    wq[4 * n + 0] = bytes_sub((la & 0x0F0F0F0F)        | (int) ((h & 0x03030303u) << 4),        0x20202020);
-                    wq[4 * n + 1] = bytes_sub((lb & 0x0F0F0F0F)        | (int) (((h >> 2) & 0x03030303u) << 4), 0x20202020);
-                    wq[4 * n + 2] = bytes_sub(((la >> 4) & 0x0F0F0F0F) | (int) (((h >> 4) & 0x03030303u) << 4), 0x20202020);
-                    wq[4 * n + 3] = bytes_sub(((lb >> 4) & 0x0F0F0F0F) | (int) (((h >> 6) & 0x03030303u) << 4), 0x20202020);
-                }
-            }
-            int sc[8];
-            if constexpr (TYPE == PI_Q6_K) {
-                const uint32_t s4[4] = { sc6.x, sc6.y, sc6.z, sc6.w };
-                const int hi = k >> 2;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {                                   // i = 4n + g: scale index 8n + 2g + hi
-                    const int idx = 8 * (i >> 2) + 2 * (i & 3);
-                    sc[i] = (int) (int8_t) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xff);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) { sc[i] = ub(scA, i); sc[4 + i] = ub(scB, i); }
-            }
-            int m0 = 0, m1 = 0;
-            if constexpr (TYPE != PI_Q6_K) {
-                const uint32_t mw = (k & 2) ? mB : mA;
-                const int sh = (k & 1) * 16;
-                m0 = (int) ((mw >> sh) & 0xff); m1 = (int) ((mw >> (sh + 8)) & 0xff);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const uint4 y0 = *(const uint4 *) (l_qs + ((size_t) t * MMVQ_TILE + bi) * 256 + 32 * k);
-                const uint4 y1 = *(const uint4 *) (l_qs + ((size_t) t * MMVQ_TILE + bi) * 256 + 32 * k + 16);
-                const int y[8] = { (int) y0.x, (int) y0.y, (int) y0.z, (int) y0.w, (int) y1.x, (int) y1.y, (int) y1.z, (int) y1.w };
-                const float dy = l_d[t * MMVQ_TILE + bi];
-                int sumi = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) sumi += sc[i] * pi_dot4(wq[i], y[i], 0);
-                acc[t] = fmaf(dy * dx, (float) sumi, acc[t]);
-                if constexpr (TYPE != PI_Q6_K) {
-                    // mins: lanes 0..3 own prod[k] = m[2k]*(bsums[4k]+bsums[4k+1]) + m[2k+1]*(bsums[4k+2]+bsums[4k+3])   (int16 pair sums like _mm_hadd_epi16)
-                    const short4 bs = *(const short4 *) (l_bs + ((size_t) t * MMVQ_TILE + bi) * 16 + 4 * (k & 3));
-                    int prod = m0 * (int) (short) (bs.x + bs.y) + m1 * (int) (short) (bs.z + bs.w);
-                    const float dmin = -dy * dminx;
-                    if constexpr (TYPE == PI_Q4_K) {
-                        accm[t] = fmaf(dmin, (float) prod, accm[t]);           // used from lanes 0..3 only
+                        for (int j = 0; j < 4; j++) { sc[j] = ub(scA, j); sc[4 + j] = ub(scB, j); }
+                        const uint32_t mw = (c & 2) ? mB : mA;               // this lane is mins lane c: m[2c], m[2c+1]
+                        const int sh = (c & 1) * 16;
+                        m0 = (int) ((mw >> sh) & 0xff); m1 = (int) ((mw >> (sh + 8)) & 0xff);
                     } else {
-                        prod += __shfl_xor(prod, 1, 64); prod += __shfl_xor(prod, 2, 64);      // lanes 0..3 of the row hold the total
-                        accm[t] = accm[t] + dmin * (float) prod;               // summs += dmin * hsum (mul, then add)
+                        dx = pi_h2f((uint16_t) raw[i].d);
+                        const uint32_t s4[4] = { raw[i].hdr.x, raw[i].hdr.y, raw[i].hdr.z, raw[i].hdr.w };
+                        const int hi = c >> 1;                               // k = 2c, 2c+1 share k >> 2
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {                        // j = 4n + g: scale index 8n + 2g + hi
+                            const int idx = 8 * (j >> 2) + 2 * (j & 3);
+                            sc[j] = (int) (int8_t) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xff);
+                        }
+                    }
+                    kq_unpack_w<TYPE>(raw[i].qa, raw[i].h.x, TYPE == PI_Q6_K ? raw[i].h.y : 0u, wq[0]);
+                    kq_unpack_w<TYPE>(raw[i].qb, TYPE == PI_Q6_K ? raw[i].h.z : raw[i].h.y, TYPE == PI_Q6_K ? raw[i].h.w : 0u, wq[1]);
+#pragma unroll
+                    for (int tt = 0; tt < NG_MAX; tt++) {
+                        if (t0 + tt < NT) {
+                            const kq_act<TYPE> & a = act[tt];
+                            int sumi0 = 0, sumi1 = 0;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) { sumi0 += __mul24(sc[j], pi_dot4(wq[0][j], a.y[0][j], 0)); sumi1 += __mul24(sc[j], pi_dot4(wq[1][j], a.y[1][j], 0)); }
+                            const int p = r * NT + t0 + tt;
+                            if (valid) {
+                                *(float2 *) (xs + L::S + p * L::SSTR + b * 8 + 2 * c) = make_float2((float) sumi0, (float) sumi1);
+                                if (c == 0) xs[L::P + p * L::PSTR + b] = a.dy * dx;
+                            }
+                            if constexpr (TYPE != PI_Q6_K) {
+                                // mins: prod[c] = m[2c]*(bsums[4c]+bsums[4c+1]) + m[2c+1]*(bsums[4c+2]+bsums[4c+3])
+                                int prod = __mul24(m0, a.bsA) + __mul24(m1, a.bsB);
+                                if constexpr (TYPE == PI_Q4_K) {
+                                    if (valid) xs[L::SM + p * L::MSTR + b * 4 + c] = (float) prod;
+                                } else {
+                                    prod += __shfl_xor(prod, 1, 64); prod += __shfl_xor(prod, 2, 64);
+                                    if (valid && c == 0) xs[L::SM + p * L::PSTR + b] = (float) prod;
+                                }
+                                if (valid && c == 0) xs[L::PM + p * L::PSTR + b] = -a.dy * dminx;
+                            }
+                        }
                     }
                 }
             }
-          }
+        }
+        wave_lds_sync();
+        // ---- ordered part: lane (p, k) extends chain k of pair p by this tile's blocks, in block order ----
+#pragma unroll
+        for (int bb = 0; bb < KQ_TB; bb++) {
+            if (bb < nbt) {
+#pragma unroll
+                for (int ci = 0; ci < NIT; ci++) {
+                    const int p = ci * 8 + s;
+                    if (NP % 8 == 0 || p < NP) {
+                        acc[ci] = fmaf(xs[L::P + p * L::PSTR + bb], xs[L::S + p * L::SSTR + bb * 8 + k], acc[ci]);
+                        if constexpr (TYPE == PI_Q4_K)      accm[ci] = fmaf(xs[L::PM + p * L::PSTR + bb], xs[L::SM + p * L::MSTR + bb * 4 + (k & 3)], accm[ci]);
+                        else if constexpr (TYPE == PI_Q5_K) accm[ci] = accm[ci] + xs[L::PM + p * L::PSTR + bb] * xs[L::SM + p * L::PSTR + bb];   // summs += dmin * hsum (mul, then add)
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        if (nb > KQ_TB) {
+#pragma unroll
+            for (int i = 0; i < R; i++) raw[i] = nxt[i];
         }
     }
-    // ---- fold the eight chains ----
+    // ---- fold the eight chains of each pair ----
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        float v = hsum8_lanes(acc[t]);
+    for (int ci = 0; ci < NIT; ci++) {
+        const int p = ci * 8 + s;
+        float v = hsum8_lanes(acc[ci]);
         if constexpr (TYPE == PI_Q4_K) {
-            float mv = (k < 4) ? accm[t] : 0.0f;
+            float mv = (k < 4) ? accm[ci] : 0.0f;
             mv = mv + __shfl_xor(mv, 2, 64);                                    // (m0+m2, m1+m3)
             mv = mv + __shfl_xor(mv, 1, 64);                                    // (m0+m2) + (m1+m3)
             v = v + mv;
         } else if constexpr (TYPE == PI_Q5_K) {
-            v = v + accm[t];
+            v = v + accm[ci];
         }
-        if (live && k == 0) {
-            const int64_t o = (int64_t) t * g.M + row;
-            g.out[o] = g.res ? g.res[o] + v : v;
+        const int r = p / NT, t = p % NT;
+        if (p < NP && k == 0 && r < rows) {
+            const int64_t o = (int64_t) t * sg.M + row0 + r;
+            sg.out[o] = sg.res ? sg.res[o] + v : v;
         }
     }
 }
@@ -221,6 +313,7 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
 // ================================================================================================================
 template <int TYPE, int NT>
 __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
+    const mmvq_seg & sg = g.seg[0];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // LDS tile: qs [NT][TILE groups][128] | d [NT][TILE][4] f16
     uint8_t * l_qs = lds;
@@ -228,8 +321,8 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, k = lane & 7;
     const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
-    const bool live = row < g.M;
-    const int64_t rowc = live ? row : g.M - 1;
+    const bool live = row < sg.M;
+    const int64_t rowc = live ? row : sg.M - 1;
     const int ng = g.nb;
     float acc[NT];
 #pragma unroll
@@ -242,9 +335,9 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
         for (int gi = 0; gi < MMVQ_TILE; gi++) {
             {
                 const int64_t grp = rowc * ng + g0 + (gi < ngt ? gi : ngt - 1);
-                if constexpr (TYPE == PI_Q4_0) w_x[gi] = *(const uint4 *) (g.w.p0 + grp * 64 + 16 * (k & 3));
-                else                           w_x[gi] = *(const uint4 *) (g.w.p0 + grp * 128 + 16 * k);
-                w_dv[gi] = *(const uint2 *) (g.w.p1 + grp * 8);
+                if constexpr (TYPE == PI_Q4_0) w_x[gi] = *(const uint4 *) (sg.p0 + grp * 64 + 16 * (k & 3));
+                else                           w_x[gi] = *(const uint4 *) (sg.p0 + grp * 128 + 16 * k);
+                w_dv[gi] = *(const uint2 *) (sg.p1 + grp * 8);
             }
         }
         __syncthreads();
@@ -289,8 +382,8 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     for (int t = 0; t < NT; t++) {
         const float v = hsum8_lanes(acc[t]);
         if (live && k == 0) {
-            const int64_t o = (int64_t) t * g.M + row;
-            g.out[o] = g.res ? g.res[o] + v : v;
+            const int64_t o = (int64_t) t * sg.M + row;
+            sg.out[o] = sg.res ? sg.res[o] + v : v;
         }
     }
 }
@@ -347,8 +440,12 @@ extern "C" int pi_kernel_timing_report(int type, int nt, double * avg_us, double
     return 0;
 }
 
+// host-side description of one launch: segments + bytes for the roofline report
+struct mmvq_launch { mmvq_args g; int nseg; int64_t m_total, m_min; double wbytes; bool any_res; };
+
 template <int TYPE, int NT>
-static int launch_mmvq(const mmvq_args & g, hipStream_t stream) {
+static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
+    mmvq_args & g = L.g;
     bool sample = false; hipEvent_t ea = nullptr, eb = nullptr;
     pi_kt_sink * sink = g_kt_sink;
     if (sink) {                                            // being captured into a graph: count per graph, sample a fixed subset
@@ -362,78 +459,117 @@ static int launch_mmvq(const mmvq_args & g, hipStream_t stream) {
         if (sample) { ea = kt_event(); eb = kt_event(); }
     }
     if (sample) (void) hipEventRecord(ea, stream);
-    // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
-    int wpb = 1;
-    while (wpb < 4 && (int64_t) g.M / (8 * wpb * 2) >= 512) wpb *= 2;
-    const unsigned grid = (unsigned) ((g.M + 8 * wpb - 1) / (8 * wpb));
-    const int tile = g.nb < MMVQ_TILE ? g.nb : MMVQ_TILE;
-    (void) tile;
     if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
+        // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
+        const int64_t M = g.seg[0].M;
+        int wpb = 1;
+        while (wpb < 4 && M / (8 * wpb * 2) >= 512) wpb *= 2;
+        const unsigned grid = (unsigned) ((M + 8 * wpb - 1) / (8 * wpb));
         const size_t lds = (size_t) NT * MMVQ_TILE * (128 + 8);
         hipLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
     } else {
-        const size_t lds = (size_t) NT * MMVQ_TILE * (256 + 4 + 32);
-        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+        // rows per wave: pairs (row, token) share the chain phase (8 per pass) and the activation registers, so more rows
+        // amortise them; fewer rows give more waves.  Keep >= ~2048 waves when the matrices allow.  PI_MMVQ_R overrides.
+        static const int r_env = getenv("PI_MMVQ_R") ? atoi(getenv("PI_MMVQ_R")) : 0;
+        constexpr int RMAX = NT <= 2 ? 4 : 2;
+        int R = RMAX;
+        while (R > 1 && L.m_total / R < 2048) R >>= 1;
+        if (r_env) R = r_env < RMAX ? r_env : RMAX;
+        int waves = 0;
+        for (int i = 0; i < MMVQ_MAX_SEG; i++) {
+            if (i < L.nseg) { g.seg[i].wave0 = waves; waves += (g.seg[i].M + R - 1) / R; }
+            else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
+        }
+        auto go = [&](auto rc) {
+            constexpr int RR = decltype(rc)::value;
+            if constexpr (RR <= RMAX) {
+                constexpr int wpb = RR * NT > 8 ? 2 : 4;
+                const unsigned grid = (unsigned) ((waves + wpb - 1) / wpb);
+                const size_t lds = (size_t) wpb * kq_lds<TYPE, RR * NT>::FLOATS * 4;
+                hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+            }
+        };
+        if (R == 1) go(std::integral_constant<int, 1>{}); else if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
     }
     if (sample) {
         (void) hipEventRecord(eb, stream);
-        // algorithmic bytes of this launch: the weight matrix once + quantised activations + fp32 output (+ residual)
-        const double wbytes = (double) g.w.nbytes;
+        // algorithmic bytes of this launch: the weight matrices once + quantised activations + fp32 output (+ residual)
         const double abytes = (double) NT * ((TYPE == PI_Q4_0 || TYPE == PI_Q8_0) ? (double) g.K / 32 * 34 : (double) g.K / 256 * 292);
-        const double obytes = (double) NT * g.M * 4 * (g.res ? 2 : 1);
-        if (sink) sink->samples.push_back(pi_kt_sample{ ea, eb, TYPE, NT, wbytes + abytes + obytes });
-        else { std::lock_guard<std::mutex> lk(g_kt_mu); g_kt.push_back(pi_kt_sample{ ea, eb, TYPE, NT, wbytes + abytes + obytes }); }
+        const double obytes = (double) NT * L.m_total * 4 * (L.any_res ? 2 : 1);
+        if (sink) sink->samples.push_back(pi_kt_sample{ ea, eb, TYPE, NT, L.wbytes + abytes + obytes });
+        else { std::lock_guard<std::mutex> lk(g_kt_mu); g_kt.push_back(pi_kt_sample{ ea, eb, TYPE, NT, L.wbytes + abytes + obytes }); }
     }
     PI_CHECK_LAUNCH();
     return 0;
 }
 
 template <int TYPE>
-static int dispatch_nt(const mmvq_args & g, int nt, hipStream_t stream) {
+static int dispatch_nt(mmvq_launch & L, int nt, hipStream_t stream) {
     switch (nt) {
-        case 1: return launch_mmvq<TYPE, 1>(g, stream);
-        case 2: return launch_mmvq<TYPE, 2>(g, stream);
-        case 3: return launch_mmvq<TYPE, 3>(g, stream);
-        case 4: return launch_mmvq<TYPE, 4>(g, stream);
-        case 5: return launch_mmvq<TYPE, 5>(g, stream);
-        case 6: return launch_mmvq<TYPE, 6>(g, stream);
-        case 7: return launch_mmvq<TYPE, 7>(g, stream);
-        case 8: return launch_mmvq<TYPE, 8>(g, stream);
+        case 1: return launch_mmvq<TYPE, 1>(L, stream);
+        case 2: return launch_mmvq<TYPE, 2>(L, stream);
+        case 3: return launch_mmvq<TYPE, 3>(L, stream);
+        case 4: return launch_mmvq<TYPE, 4>(L, stream);
+        case 5: return launch_mmvq<TYPE, 5>(L, stream);
+        case 6: return launch_mmvq<TYPE, 6>(L, stream);
+        case 7: return launch_mmvq<TYPE, 7>(L, stream);
+        case 8: return launch_mmvq<TYPE, 8>(L, stream);
     }
     return -1;
 }
 
-extern "C" int pi_op_mul_mat(const pi_weight * w, const void * q8, int n_tok, float * out, const float * res, void * stream_) {
+// out[i][t][row] = residual[i][t][row] + vec_dot(W_i[row], act[t]) for n_w (<= 3) weight matrices of the same type and width
+// sharing one quantised activation.  Q4_0/Q8_0 weights are launched one by one.
+extern "C" int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void * q8, int n_tok, float * const * outs, const float * const * ress, void * stream_) {
     hipStream_t stream = (hipStream_t) stream_;
-    if (n_tok <= 0) return 0;
-    const int vdt = pi_vec_dot_type(w->type);
-    if (vdt != PI_Q8_K && vdt != PI_Q8_0) { pi_set_error("pi_op_mul_mat: weight type %d has no quantised mat-vec", w->type); return -1; }
+    if (n_tok <= 0 || n_w <= 0) return 0;
+    if (n_w > MMVQ_MAX_SEG) { pi_set_error("pi_op_mul_mat_multi: n_w=%d > %d", n_w, MMVQ_MAX_SEG); return -1; }
+    const pi_weight * w0 = ws[0];
+    const int vdt = pi_vec_dot_type(w0->type);
+    if (vdt != PI_Q8_K && vdt != PI_Q8_0) { pi_set_error("pi_op_mul_mat: weight type %d has no quantised mat-vec", w0->type); return -1; }
+    for (int i = 1; i < n_w; i++)
+        if (ws[i]->type != w0->type || ws[i]->ne0 != w0->ne0) { pi_set_error("pi_op_mul_mat_multi: weights differ in type or width"); return -1; }
+    if (vdt == PI_Q8_0 && n_w > 1) {
+        for (int i = 0; i < n_w; i++) { const int rc = pi_op_mul_mat_multi(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, stream_); if (rc) return rc; }
+        return 0;
+    }
     size_t oq, od, ob;
-    pi_q8_layout(vdt, w->ne0, n_tok, &oq, &od, &ob);
+    pi_q8_layout(vdt, w0->ne0, n_tok, &oq, &od, &ob);
     const uint8_t * base = (const uint8_t *) q8;
-    const int64_t K = w->ne0, M = w->ne1;
-    const int64_t nbq = vdt == PI_Q8_K ? K / 256 : w->ng;
+    const int64_t K = w0->ne0;
+    const int64_t nbq = vdt == PI_Q8_K ? K / 256 : w0->ng;
     for (int t0 = 0; t0 < n_tok; t0 += 8) {                   // verify batches are <= 8 wide; prompts loop over chunks of 8
         const int nt = n_tok - t0 < 8 ? n_tok - t0 : 8;
-        mmvq_args g;
-        g.w = *w;
-        g.M = (int) M; g.K = (int) K; g.nb = (int) nbq;
-        if (vdt == PI_Q8_K) {
-            g.aq = base + oq + (size_t) t0 * nbq * 256; g.ad = base + od + (size_t) t0 * nbq * 4; g.abs_ = base + ob + (size_t) t0 * nbq * 32;
-        } else {
-            g.aq = base + oq + (size_t) t0 * nbq * 128; g.ad = base + od + (size_t) t0 * nbq * 8; g.abs_ = nullptr;
+        mmvq_launch L;
+        L.nseg = n_w; L.m_total = 0; L.m_min = 1 << 30; L.wbytes = 0.0; L.any_res = false;
+        L.g.K = (int) K; L.g.nb = (int) nbq;
+        for (int i = 0; i < n_w; i++) {
+            const pi_weight * w = ws[i];
+            mmvq_seg & sg = L.g.seg[i];
+            sg.p0 = w->p0; sg.p1 = w->p1; sg.p2 = w->p2; sg.M = (int) w->ne1; sg.wave0 = 0;
+            sg.out = outs[i] + (int64_t) t0 * w->ne1;
+            sg.res = ress && ress[i] ? ress[i] + (int64_t) t0 * w->ne1 : nullptr;
+            L.m_total += w->ne1; L.wbytes += (double) w->nbytes; L.any_res |= sg.res != nullptr;
         }
-        g.out = out + (int64_t) t0 * M;
-        g.res = res ? res + (int64_t) t0 * M : nullptr;
+        for (int i = n_w; i < MMVQ_MAX_SEG; i++) { L.g.seg[i] = L.g.seg[0]; L.g.seg[i].wave0 = 0x7fffffff; }
+        if (vdt == PI_Q8_K) {
+            L.g.aq = base + oq + (size_t) t0 * nbq * 256; L.g.ad = base + od + (size_t) t0 * nbq * 4; L.g.abs_ = base + ob + (size_t) t0 * nbq * 32;
+        } else {
+            L.g.aq = base + oq + (size_t) t0 * nbq * 128; L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr;
+        }
         int rc = -1;
-        switch (w->type) {
-            case PI_Q4_K: rc = dispatch_nt<PI_Q4_K>(g, nt, stream); break;
-            case PI_Q5_K: rc = dispatch_nt<PI_Q5_K>(g, nt, stream); break;
-            case PI_Q6_K: rc = dispatch_nt<PI_Q6_K>(g, nt, stream); break;
-            case PI_Q4_0: rc = dispatch_nt<PI_Q4_0>(g, nt, stream); break;
-            case PI_Q8_0: rc = dispatch_nt<PI_Q8_0>(g, nt, stream); break;
+        switch (w0->type) {
+            case PI_Q4_K: rc = dispatch_nt<PI_Q4_K>(L, nt, stream); break;
+            case PI_Q5_K: rc = dispatch_nt<PI_Q5_K>(L, nt, stream); break;
+            case PI_Q6_K: rc = dispatch_nt<PI_Q6_K>(L, nt, stream); break;
+            case PI_Q4_0: rc = dispatch_nt<PI_Q4_0>(L, nt, stream); break;
+            case PI_Q8_0: rc = dispatch_nt<PI_Q8_0>(L, nt, stream); break;
         }
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int pi_op_mul_mat(const pi_weight * w, const void * q8, int n_tok, float * out, const float * res, void * stream) {
+    return pi_op_mul_mat_multi(1, &w, q8, n_tok, &out, &res, stream);
 }

@@ -338,3 +338,34 @@ def test_fused_norm_and_activation_quantisers(gpu, vdt, n):
         got = U.q8_as_ref_blocks(vdt, *U.q8_planes(lib, vdt, n, n_tok, q8))
         for t in range(n_tok):
             assert np.array_equal(got[t], o.quantize_act(vdt, h[t]))
+
+
+@pytest.mark.parametrize("wtype", [O.Q4_K, O.Q6_K, O.Q4_0])
+@pytest.mark.parametrize("n_tok", [1, 3, 8])
+def test_mul_mat_multi_equals_single_launches(gpu, wtype, n_tok):
+    """grouped launch (wq/wk/wv, up/gate) == one launch per weight, bit for bit"""
+    import ctypes as C
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    from pipeinfer_amd.tools import synth
+    rng = np.random.default_rng(77)
+    k, ms = 1024, [512, 129, 256]
+    vdt = O.VEC_DOT_TYPE[wtype]
+    ws = []
+    for m in ms:
+        blocks = synth.random_blocks(wtype, m * k, rng, 0.05)
+        ws.append(lib.pi_weight_upload(wtype, k, m, blocks.ctypes.data_as(C.c_void_p), None))
+    act = rng.standard_normal((n_tok, k)).astype(np.float32)
+    xd = U.Dev(act); q8 = U.Dev(nbytes=lib.pi_q8_nbytes(vdt, k, n_tok))
+    L.check(lib.pi_op_quantize(vdt, xd.ptr, k, n_tok, q8.ptr, None))
+    singles = [U.Dev(nbytes=4 * n_tok * m) for m in ms]
+    multis = [U.Dev(nbytes=4 * n_tok * m) for m in ms]
+    for w, o in zip(ws, singles):
+        L.check(lib.pi_op_mul_mat(w, q8.ptr, n_tok, o.ptr, None, None))
+    warr = (C.c_void_p * 3)(*ws); oarr = (C.c_void_p * 3)(*[o.ptr for o in multis])
+    L.check(lib.pi_op_mul_mat_multi(3, warr, q8.ptr, n_tok, oarr, None, None))
+    lib.pi_device_sync()
+    for m, a, b in zip(ms, singles, multis):
+        assert np.array_equal(a.get(np.float32, (n_tok, m)).view(np.uint32), b.get(np.float32, (n_tok, m)).view(np.uint32))
+    for w in ws:
+        lib.pi_weight_free(w)
