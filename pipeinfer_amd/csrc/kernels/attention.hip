@@ -12,13 +12,17 @@
 // f16 rounding of P and the Q8 quantisation of the attention output turn a 1-ulp score difference into 1e-2 logit
 // differences, so these accumulation orders are part of the contract.
 //
-// One workgroup (256 threads) per (kv head, chunk of <= 8 query rows); a row is one (token, query head of the GQA group),
-// so K/V are read once per chunk for all query heads and verify tokens that share them.
-//   phase 1  thread per cell: K row -> registers, the 32-accumulator dot with every query row (q in LDS), scale, mask -> S in LDS
-//   phase 2  wave per row: max, table exp, exact integer sum, P = f16-rounded probability (kept as f32 in LDS)
+// One workgroup (256 threads) per (kv head, chunk of RW query rows); a row is one (token, query head of the GQA group), so
+// K/V are read once per chunk for all query heads and verify tokens that share them.  RW is chosen so that a launch has
+// enough workgroups (decode has few rows: one workgroup per (kv head, row)).
+//   phase 1  16 lanes per cell: lane a owns accumulators a and a+16 of the reference's 32 (its q values stay in registers),
+//            folds them in the reference's order (in-lane, then DPP row shifts 8, 4 and the two hadd steps), scale, mask -> S
+//   phase 2  all threads: row max, table exp, exact integer sum, P = f16-rounded probability (kept as f32 in LDS)
 //   phase 3  lane (l, ev) owns cells c % 8 == l and dims 8ev..8ev+7: four accumulator sets j = (c / 8) % 4 per row, folded
 //            in the reference's order with lane shuffles; tail cells in double by lane l == 0
 #include "ops_common.h"
+
+#include <cstdlib>
 
 #define ATT_ROWS 8
 
@@ -29,71 +33,103 @@ struct att_args {
     const uint16_t * exp_tab;
     float scale;
     const int32_t * dyn;                                    // optional {kv_head, n_kv} in device memory: lets one captured graph serve every call
+    float * dbg;                                            // test probe: scores (phase 1) and probabilities (phase 2), [2][n_head][n_tok][n_kv]
 };
 
-template <int HD>
+// x[i] + x[i + n] inside a row of 16 lanes (lanes whose partner is outside read 0 and are not used)
+template <int CTRL> static __device__ __forceinline__ float dpp_add(float x) {
+#ifdef PI_ATT_NO_DPP
+    const int lane = threadIdx.x & 63;
+    const int src = CTRL == 0x108 ? lane + 8 : CTRL == 0x104 ? lane + 4 : CTRL == 0xB1 ? (lane ^ 1) : (lane ^ 2);
+    return x + __shfl(x, src & 63, 64);
+#else
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+#endif
+}
+
+template <int HD, int RW>
 __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     extern __shared__ float smem[];
+    __shared__ float redf[RW][4];
+    __shared__ unsigned long long redu[RW][4];
     att_args g = ga;
     const int s_stride = ga.n_kv;                           // LDS rows keep the static stride
     if (ga.dyn) g.n_kv = ga.dyn[1];
     const int hk = blockIdx.x, chunk = blockIdx.y;
     const int r = g.n_head / g.n_head_kv;                   // query heads per kv head (broadcast rule i02 = i12 / r2, ggml.c:9425)
     const int n_rows_total = g.n_tok * r;
-    const int row0 = chunk * ATT_ROWS;
-    const int n_rows = min(ATT_ROWS, n_rows_total - row0);
+    const int row0 = chunk * RW;
+    const int n_rows = min(RW, n_rows_total - row0);
     const int n_gqa = g.n_head_kv * HD, n_embd = g.n_head * HD;
-    float * S  = smem;                                      // [ATT_ROWS][n_kv]
-    float * qf = S + (size_t) ATT_ROWS * s_stride;           // [ATT_ROWS][HD]
+    float * S = smem;                                       // [RW][n_kv]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    for (int i = tid; i < n_rows * HD; i += 256) {          // rows are token-major: row = t * r + gq -> query head hk * r + gq
-        const int rr = i / HD, e = i % HD, row = row0 + rr, t = row / r, gq = row % r;
-        qf[rr * HD + e] = pi_h2f(g.q16[(int64_t) t * n_embd + (hk * r + gq) * HD + e]);
-    }
-    __syncthreads();
-
     // ---- phase 1: scores, ggml_vec_dot_f16 order ----
-    for (int c = tid; c < g.n_kv; c += 256) {
-        float kf[HD];
-        const uint4 * kp = (const uint4 *) (g.kc + (int64_t) c * n_gqa + hk * HD);
+    {
+        constexpr int NS = HD / 32;                         // 32-element steps
+        const int a = lane & 15, cg = lane >> 4;
+        float q[RW][2 * NS];                                // rows are token-major: row = t * r + gq -> query head hk * r + gq
 #pragma unroll
-        for (int i = 0; i < HD / 8; i++) {
-            const uint4 v = kp[i];
-            const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+        for (int rr = 0; rr < RW; rr++) {
+            const int row = row0 + (rr < n_rows ? rr : 0), t = row / r, gq = row % r;
+            const uint16_t * qp = g.q16 + (int64_t) t * n_embd + (hk * r + gq) * HD;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { kf[8 * i + 2 * j] = pi_h2f((uint16_t) (w4[j] & 0xffff)); kf[8 * i + 2 * j + 1] = pi_h2f((uint16_t) (w4[j] >> 16)); }
+            for (int st = 0; st < NS; st++) { q[rr][2 * st] = pi_h2f(qp[32 * st + a]); q[rr][2 * st + 1] = pi_h2f(qp[32 * st + 16 + a]); }
         }
-        for (int rr = 0; rr < n_rows; rr++) {
-            const int t = (row0 + rr) / r;
-            const bool vis = (g.mask[(int64_t) t * g.mask_words + (c >> 5)] >> (c & 31)) & 1;
-            const float * q = qf + rr * HD;
-            float s[32];
+        constexpr int U = 4;                                // cells in flight per 16-lane group
+        for (int c0 = 0; c0 < g.n_kv; c0 += 16 * U) {
+            uint16_t kr[U][2 * NS];
 #pragma unroll
-            for (int a = 0; a < 32; a++) s[a] = 0.0f;
+            for (int u = 0; u < U; u++) {
+                const int c = c0 + 16 * u + wv * 4 + cg, cc = c < g.n_kv ? c : g.n_kv - 1;
+                const uint16_t * kp = g.kc + (int64_t) cc * n_gqa + hk * HD;
 #pragma unroll
-            for (int st = 0; st < HD / 32; st++)
+                for (int st = 0; st < NS; st++) { kr[u][2 * st] = kp[32 * st + a]; kr[u][2 * st + 1] = kp[32 * st + 16 + a]; }
+            }
 #pragma unroll
-                for (int a = 0; a < 32; a++) s[a] = fmaf(kf[32 * st + a], q[32 * st + a], s[a]);
+            for (int u = 0; u < U; u++) {
+                const int c = c0 + 16 * u + wv * 4 + cg;
+                float kf[2 * NS];
 #pragma unroll
-            for (int l = 0; l < 8; l++) { s[l] = s[l] + s[16 + l]; s[8 + l] = s[8 + l] + s[24 + l]; }
+                for (int i = 0; i < 2 * NS; i++) kf[i] = pi_h2f(kr[u][i]);
 #pragma unroll
-            for (int l = 0; l < 8; l++) s[l] = s[l] + s[8 + l];
-            const float t0 = s[0] + s[4], t1 = s[1] + s[5], t2 = s[2] + s[6], t3 = s[3] + s[7];
-            const float dot = (t0 + t1) + (t2 + t3);
-            S[(size_t) rr * s_stride + c] = vis ? dot * g.scale : -INFINITY;
+                for (int rr = 0; rr < RW; rr++) {
+                    if (rr < n_rows) {
+                        float x0 = 0.0f, x1 = 0.0f;
+#pragma unroll
+                        for (int st = 0; st < NS; st++) { x0 = fmaf(kf[2 * st], q[rr][2 * st], x0); x1 = fmaf(kf[2 * st + 1], q[rr][2 * st + 1], x1); }
+                        float x = x0 + x1;                  // s[l] += s[16+l], s[8+l] += s[24+l]
+                        x = dpp_add<0x108>(x);              // s[l] += s[8+l]                      row_shl:8
+                        x = dpp_add<0x104>(x);              // t[l] = s[l] + s[l+4]                row_shl:4
+                        x = dpp_add<0xB1>(x);               // t0+t1, t2+t3                        quad_perm [1,0,3,2]
+                        x = dpp_add<0x4E>(x);               // (t0+t1) + (t2+t3)                   quad_perm [2,3,0,1]
+                        if (a == 0 && c < g.n_kv) {
+                            const int t = (row0 + rr) / r;
+                            const bool vis = (g.mask[(int64_t) t * g.mask_words + (c >> 5)] >> (c & 31)) & 1;
+                            S[(size_t) rr * s_stride + c] = vis ? x * g.scale : -INFINITY;
+                        }
+                    }
+                }
+            }
         }
     }
     __syncthreads();
+    if (g.dbg) for (int rr = 0; rr < n_rows; rr++) { const int row = row0 + rr, t = row / r, gq = row % r;
+        for (int c = tid; c < g.n_kv; c += 256) g.dbg[((int64_t) (hk * r + gq) * g.n_tok + t) * g.n_kv + c] = S[(size_t) rr * s_stride + c]; }
 
-    // ---- phase 2: soft max, one wave per row ----
-    for (int rr = wv; rr < n_rows; rr += 4) {
-        float * s = S + (size_t) rr * s_stride;
+    // ---- phase 2: soft max ----
+    for (int rr = 0; rr < n_rows; rr++) {
         float mx = -INFINITY;
-        for (int c = lane; c < g.n_kv; c += 64) mx = fmaxf(mx, s[c]);
+        for (int c = tid; c < g.n_kv; c += 256) mx = fmaxf(mx, S[(size_t) rr * s_stride + c]);
         mx = pi_wave_max(mx);
+        if (lane == 0) redf[rr][wv] = mx;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < n_rows; rr++) {
+        float * s = S + (size_t) rr * s_stride;
+        const float mx = fmaxf(fmaxf(redf[rr][0], redf[rr][1]), fmaxf(redf[rr][2], redf[rr][3]));
         unsigned long long isum = 0;                          // in units of 2^-24: exact
-        for (int c = lane; c < g.n_kv; c += 64) {
+        for (int c = tid; c < g.n_kv; c += 256) {
             const float x = s[c];
             float v = 0.0f;
             if (x != -INFINITY) { v = pi_h2f(g.exp_tab[pi_f2h(x - mx)]); isum += (unsigned long long) (v * 16777216.0f); }
@@ -101,16 +137,26 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o, 64);
+        if (lane == 0) redu[rr][wv] = isum;
+    }
+    __syncthreads();
+    for (int rr = 0; rr < n_rows; rr++) {
+        float * s = S + (size_t) rr * s_stride;
+        const unsigned long long isum = (redu[rr][0] + redu[rr][1]) + (redu[rr][2] + redu[rr][3]);
         const double sum = (double) isum * (1.0 / 16777216.0);
         const float inv = (float) (1.0 / sum);
-        for (int c = lane; c < g.n_kv; c += 64) s[c] = pi_h2f(pi_f2h(s[c] * inv));        // P rounded to f16 as the V.P mul_mat does
+        if (g.dbg && tid == 0) { const int row = row0 + rr, t = row / r, gq = row % r; float * d = g.dbg + (int64_t) 2 * g.n_head * g.n_tok * g.n_kv + ((int64_t) (hk * r + gq) * g.n_tok + t) * 4;
+            d[0] = inv; d[1] = (float) (isum >> 24); d[2] = (float) (isum & 0xffffff); d[3] = fmaxf(fmaxf(redf[rr][0], redf[rr][1]), fmaxf(redf[rr][2], redf[rr][3])); }
+        for (int c = tid; c < g.n_kv; c += 256) s[c] = pi_h2f(pi_f2h(s[c] * inv));          // P rounded to f16 as the V.P mul_mat does
     }
     __syncthreads();
 
+    if (g.dbg) for (int rr = 0; rr < n_rows; rr++) { const int row = row0 + rr, t = row / r, gq = row % r;
+        for (int c = tid; c < g.n_kv; c += 256) g.dbg[(((int64_t) g.n_head + hk * r + gq) * g.n_tok + t) * g.n_kv + c] = S[(size_t) rr * s_stride + c]; }
     // ---- phase 3: out[row][e] = ggml_vec_dot_f16(n_kv, V[:, e], P[row, :]) ----
     constexpr int TPC = HD / 8;                              // lanes along the head dimension
     constexpr int NRG = 256 / (8 * TPC);                     // row groups in the workgroup: 4 (HD 64) or 2 (HD 128)
-    constexpr int RPT = ATT_ROWS / NRG;                      // rows per thread
+    constexpr int RPT = (RW + NRG - 1) / NRG;                // rows per thread
     const int l = tid & 7, ev = (tid >> 3) % TPC, rg = tid / (8 * TPC);
     const int np = g.n_kv & ~31;
     float acc[RPT][4][8];
@@ -120,12 +166,17 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[i][j][e] = 0.0f;
+    const uint16_t * vbase = g.vc + hk * HD + 8 * ev;
+    uint4 vcur[4], vnxt[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int c = 8 * j + l; vcur[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
     for (int c0 = 0; c0 < np; c0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int c = c0 + 32 + 8 * j + l; vnxt[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int c = c0 + 8 * j + l;
-            const uint4 v = *(const uint4 *) (g.vc + (int64_t) c * n_gqa + hk * HD + 8 * ev);
-            const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+            const uint32_t w4[4] = { vcur[j].x, vcur[j].y, vcur[j].z, vcur[j].w };
             float vf[8];
 #pragma unroll
             for (int u = 0; u < 4; u++) { vf[2 * u] = pi_h2f((uint16_t) (w4[u] & 0xffff)); vf[2 * u + 1] = pi_h2f((uint16_t) (w4[u] >> 16)); }
@@ -139,6 +190,8 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) vcur[j] = vnxt[j];
     }
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
@@ -180,13 +233,33 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
 }
 
 // raises the dynamic-LDS limit of the kernel for contexts longer than ~2000 cells; call once outside any graph capture
-extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
-    const size_t lds = ((size_t) ATT_ROWS * n_kv_max + (size_t) ATT_ROWS * hd) * sizeof(float);
-    if (lds > 160 * 1024) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS (> 160 KiB)", n_kv_max, lds); return -1; }
-    if (lds <= 64 * 1024) return 0;
-    if (hd == 128) PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    else           PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+template <int HD, int RW> static int att_set_lds(size_t lds) {
+    PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<HD, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     return 0;
+}
+extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
+    const size_t lds = (size_t) ATT_ROWS * n_kv_max * sizeof(float);
+    if (lds > 156 * 1024) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS (> 156 KiB)", n_kv_max, lds); return -1; }
+    if (lds <= 60 * 1024) return 0;
+    int rc = 0;
+    if (hd == 128) rc = att_set_lds<128, 1>(lds / 8) | att_set_lds<128, 2>(lds / 4) | att_set_lds<128, 4>(lds / 2) | att_set_lds<128, 8>(lds);
+    else           rc = att_set_lds<64, 1>(lds / 8) | att_set_lds<64, 2>(lds / 4) | att_set_lds<64, 4>(lds / 2) | att_set_lds<64, 8>(lds);
+    return rc;
+}
+
+static float * g_att_probe = nullptr;
+extern "C" __attribute__((visibility("default"))) void pi_debug_attention_probe(float * dev) { g_att_probe = dev; }
+
+template <int HD>
+static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream) {
+    const dim3 grid(g.n_head_kv, (rows + rw - 1) / rw);
+    const size_t lds = (size_t) rw * g.n_kv * sizeof(float);
+    switch (rw) {
+        case 1: hipLaunchKernelGGL((k_attention<HD, 1>), grid, dim3(256), lds, stream, g); break;
+        case 2: hipLaunchKernelGGL((k_attention<HD, 2>), grid, dim3(256), lds, stream, g); break;
+        case 4: hipLaunchKernelGGL((k_attention<HD, 4>), grid, dim3(256), lds, stream, g); break;
+        default: hipLaunchKernelGGL((k_attention<HD, 8>), grid, dim3(256), lds, stream, g); break;
+    }
 }
 
 extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
@@ -197,16 +270,18 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     g.n_head = n_head; g.n_head_kv = n_head_kv; g.n_tok = n_tok; g.n_kv = n_kv; g.mask_words = (n_kv + 31) / 32;
     g.exp_tab = pi_get_tables().exp_f16;
     g.scale = 1.0f / sqrtf((float) hd);                      // KQ_scale, llama.cpp:5189-5193
-    g.dyn = dyn_dev;
+    g.dyn = dyn_dev; g.dbg = g_att_probe;
     const int rows = n_tok * (n_head / n_head_kv);
-    const dim3 grid(n_head_kv, (rows + ATT_ROWS - 1) / ATT_ROWS);
-    const size_t lds = ((size_t) ATT_ROWS * n_kv + (size_t) ATT_ROWS * hd) * sizeof(float);
-    if (lds > 160 * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs %zu B of LDS (> 160 KiB)", n_kv, lds); return -1; }
-    if (hd == 128) {
-        hipLaunchKernelGGL(k_attention<128>, grid, dim3(256), lds, (hipStream_t) stream, g);
-    } else if (hd == 64) {
-        hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), lds, (hipStream_t) stream, g);
-    } else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }
+    // rows per workgroup: K/V are re-read (from L2) by every chunk of a kv head, so chunks stay as large as the launch can
+    // afford while still putting >= ~128 workgroups on the 256 CUs
+    int rw = 1;
+    while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > 128) rw *= 2;
+    static const int rw_env = getenv("PI_ATT_RW") ? atoi(getenv("PI_ATT_RW")) : 0;      // tuning / tests
+    if (rw_env == 1 || rw_env == 2 || rw_env == 4 || rw_env == 8) rw = rw_env;
+    if ((size_t) rw * n_kv * sizeof(float) > 156 * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs more than 156 KiB of LDS", n_kv); return -1; }
+    if (hd == 128) att_launch<128>(g, rows, rw, (hipStream_t) stream);
+    else if (hd == 64) att_launch<64>(g, rows, rw, (hipStream_t) stream);
+    else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }
     PI_CHECK_LAUNCH();
     return 0;
 }

@@ -8,7 +8,10 @@
 #define PI_WAVE 64
 
 static __device__ __forceinline__ float pi_h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-static __device__ __forceinline__ uint16_t pi_f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }   // RNE, as _cvtss_sh(x,0)
+// RNE, as _cvtss_sh(x, 0).  The empty asm keeps the conversion a separate instruction: the backend otherwise folds
+// f16(a * b) into v_fma_mixlo_f16 (ONE rounding) even with -ffp-contract=off, while the reference rounds the fp32 product
+// first — the two differ when the fp32 product lands exactly on an f16 tie.
+static __device__ __forceinline__ uint16_t pi_f2h(float f) { asm volatile("" : "+v"(f)); return __half_as_ushort(__float2half_rn(f)); }
 
 // butterfly sum over W consecutive lanes (W power of two <= 64); every lane ends with the total
 template <int W>
