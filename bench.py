@@ -145,7 +145,6 @@ def main():
     for i in range(args.warmup):
         generation(1 + i)
 
-    lib.pi_kernel_timing(1, 8)
     ct.reset_stats(); cd.reset_stats()
     L.check(lib.pi_device_sync())
     t_start = time.time()
@@ -155,7 +154,6 @@ def main():
         results.append(r)
     L.check(lib.pi_device_sync())
     t_total = time.time() - t_start
-    lib.pi_kernel_timing(0, 8) if False else None
 
     n_tok = sum(r["n_predict"] for r in results)
     t_dec = sum(r["t_dec_s"] for r in results)
@@ -164,11 +162,18 @@ def main():
     acc_clean = sum(r["n_accept_clean"] for r in results)
     acc_ref = 100.0 * sum(r["n_accept"] for r in results) / max(1, sum(r["n_drafted"] for r in results))
 
-    # roofline of the dominant kernel: the Q4_K single-token mat-vec (k_mmvq_kq<Q4_K, NT=1>), sampled with HIP events on its stream
+    st_t, st_d = ct.stats(), cd.stats()
+    # roofline of the dominant kernel: the Q4_K single-token mat-vec (k_mmvq_kq<Q4_K, NT=1>), every 4th launch bracketed by HIP
+    # events on its own stream.  Events recorded inside a captured graph cannot be read back on ROCm 7.2, so the sampling
+    # pass replays the same decode step kernel by kernel (graphs off) right after the timed region, on the same context.
+    ct.set_graphs(0)
+    lib.pi_kernel_timing(1, 4)
+    generation(1 + args.warmup, mode=2, n_predict=min(32, args.n_predict))
+    L.check(lib.pi_device_sync())
+    ct.set_graphs(1)
     avg_us, avg_bytes, n_s, n_l = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
     lib.pi_kernel_timing_report(12, 1, C.byref(avg_us), C.byref(avg_bytes), C.byref(n_s), C.byref(n_l))
     achieved = (avg_bytes.value / (avg_us.value * 1e-6) / 1e9) if avg_us.value > 0 else 0.0
-    st_t, st_d = ct.stats(), cd.stats()
     roofline = {"bound": "hbm", "kernel": "k_mmvq_kq<Q4_K,NT=1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_us.value, 3), "alg_bytes_per_launch": round(avg_bytes.value), "launches": int(n_l.value), "sampled": int(n_s.value),

@@ -19,9 +19,37 @@ LLAMA_API void pipeinfer_kv_cache_seq_rm_cp_range(struct llama_context * ctx, ll
 
 /* uploads this process's stage weights and allocates KV cache + scratch now (otherwise done by the first decode) */
 LLAMA_API int  pipeinfer_context_prepare(struct llama_context * ctx);
+/* 0: launch the decode kernels one by one instead of replaying the captured HIP graph (profiling / per-kernel event timing) */
+LLAMA_API void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable);
 LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
 
 /* device-side top-8 of row i of the last finished run: ids/logits sorted (logit desc, id asc), sumexp = sum_j expf(l_j - max) */
+/* ---- multi-process pipeline (one process per GPU) -------------------------------------------------------------------------
+ * Replaces the reference's MPI plumbing (ggml-mpi.c:186-310 pipelined sync, :541-557 layer ranges; llama.cpp:5588-5760 phases):
+ * the HEAD process owns the driver and the KV-cell bookkeeping of the target context; it ships one metadata block per run
+ *     int32 tokens[n] | int32 pos[n] | int32 {kv_head, n_kv, n_tokens, 0} | uint32 mask[n][ceil(n_ctx/32)]
+ * through `start`; STAGE processes own layer ranges and run pipeinfer_stage_run on that block, passing activations
+ * [n_tokens][n_embd] fp32 from stage to stage (RCCL send/recv in pipeinfer_amd/pipeline.py).  The transport lives outside
+ * this library: the callbacks below are all it needs. */
+struct pipeinfer_remote_ops {
+    void * user;
+    int  (*start)(void * user, int32_t run_seq, int32_t batch_id, int32_t n_tokens, const void * meta, size_t meta_bytes);
+    int  (*poll)(void * user);                      /* 1 when the oldest outstanding run's result has arrived (llama_mpi_iprobe) */
+    /* blocks for run_seq (runs finish in start order): 1 = computed, 0 = skipped (cancelled), < 0 error */
+    int  (*wait)(void * user, int32_t run_seq, float * logits, int32_t * topk_ids, float * topk_vals, float * topk_sum);
+    void (*cancel)(void * user, int32_t batch_id);  /* llama_cancel_run; batch_id -2: a new generation starts, batch ids restart */
+};
+/* turns ctx into the head-side proxy of a remote pipeline: no weights, no device memory */
+LLAMA_API void pipeinfer_context_set_remote(struct llama_context * ctx, const struct pipeinfer_remote_ops * ops);
+/* before the first decode: this process owns layers [l0, l1), the embedding if is_first, final norm + output if is_last */
+LLAMA_API int  pipeinfer_context_set_stage(struct llama_context * ctx, int32_t l0, int32_t l1, int32_t is_first, int32_t is_last);
+/* layer ranges of the reference's --mpi-layer-split (ggml-mpi.c:541-557): ranges[2*i], ranges[2*i+1] = [start, end) of stage i */
+LLAMA_API void pipeinfer_split_layers(int32_t n_layer, const float * weights, int32_t n_stage, int32_t * ranges);
+/* one run on this stage; x_in_dev / x_out_dev: device fp32 [n_tokens][n_embd] (ignored on the first / last stage); the last
+ * stage fills the host buffers.  Returns after the stage's stream is idle. */
+LLAMA_API int  pipeinfer_stage_run(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
+                                   float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum);
+
 LLAMA_API int  pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp);
 
 struct pipeinfer_stats {

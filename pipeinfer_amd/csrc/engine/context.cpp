@@ -20,9 +20,8 @@ llama_context::~llama_context() {
     for (pi_run * r : pool) {
         if (r->done) (void) hipEventDestroy(r->done);
         if (r->begin) (void) hipEventDestroy(r->begin);
-        if (r->logits_host) (void) hipHostFree(r->logits_host);
-        if (r->topk_ids) (void) hipHostFree(r->topk_ids);
-        if (r->meta_host) (void) hipHostFree(r->meta_host);
+        void * hb[] = { r->logits_host, r->topk_ids, r->meta_host };
+        for (void * b : hb) if (b) { if (r->host_plain) free(b); else (void) hipHostFree(b); }
         delete r;
     }
     for (auto & kv : graphs) if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
@@ -49,7 +48,7 @@ size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv) {
 }
 
 bool context_prepare(llama_context * ctx, std::string & err) {
-    if (ctx->x) return true;
+    if (ctx->x || ctx->remote) return true;                                  // the head of a remote pipeline owns no device state
     llama_model * m = ctx->model;
     const pi_hparams & hp = m->hparams;
     if (pi_device_init(m->device) != 0) { err = pi_last_error(); return false; }
@@ -91,22 +90,27 @@ bool context_prepare(llama_context * ctx, std::string & err) {
 static pi_run * acquire_run(llama_context * ctx, int n_tokens, size_t meta_bytes) {
     pi_run * r = nullptr;
     if (!ctx->pool.empty()) { r = ctx->pool.back(); ctx->pool.pop_back(); }
-    else { r = new pi_run(); if (hipEventCreate(&r->done) != hipSuccess || hipEventCreate(&r->begin) != hipSuccess) { delete r; return nullptr; } }
+    else {
+        r = new pi_run(); r->host_plain = ctx->remote;
+        if (!ctx->remote && (hipEventCreate(&r->done) != hipSuccess || hipEventCreate(&r->begin) != hipSuccess)) { delete r; return nullptr; }
+    }
+    auto host_alloc = [&](void ** p, size_t bytes) { if (r->host_plain) { *p = malloc(bytes); return *p != nullptr; } return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess; };
+    auto host_free = [&](void * p) { if (r->host_plain) free(p); else (void) hipHostFree(p); };
     const size_t need = ctx->is_last ? (size_t) n_tokens * ctx->model->hparams.n_vocab : 0;
     if (need > r->logits_cap) {
-        if (r->logits_host) (void) hipHostFree(r->logits_host);
-        if (r->topk_ids) (void) hipHostFree(r->topk_ids);
+        if (r->logits_host) host_free(r->logits_host);
+        if (r->topk_ids) host_free(r->topk_ids);
         r->logits_cap = std::max(need, (size_t) 16 * ctx->model->hparams.n_vocab);
         const size_t rows = r->logits_cap / ctx->model->hparams.n_vocab;
-        if (hipHostMalloc((void **) &r->logits_host, r->logits_cap * 4, hipHostMallocDefault) != hipSuccess) return nullptr;
-        if (hipHostMalloc((void **) &r->topk_ids, rows * (8 * 4 + 8 * 4 + 4), hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (!host_alloc((void **) &r->logits_host, r->logits_cap * 4)) return nullptr;
+        if (!host_alloc((void **) &r->topk_ids, rows * (8 * 4 + 8 * 4 + 4))) return nullptr;
         r->topk_vals = (float *) (r->topk_ids + rows * 8);
         r->topk_sum  = r->topk_vals + rows * 8;
     }
     if (meta_bytes > r->meta_cap) {
-        if (r->meta_host) (void) hipHostFree(r->meta_host);
+        if (r->meta_host) host_free(r->meta_host);
         r->meta_cap = std::max(meta_bytes, (size_t) 4096);
-        if (hipHostMalloc((void **) &r->meta_host, r->meta_cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (!host_alloc((void **) &r->meta_host, r->meta_cap)) return nullptr;
     }
     r->canceled = r->launched = r->finished = false;
     return r;
@@ -223,6 +227,44 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
     return true;
 }
 
+// metadata block -> device, then the stage's forward pass: replay of the captured graph for this batch width, or eager launches.
+// x_in (device, [n_tokens][n_embd]) replaces the embedding lookup on stages after the first.
+static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta, const float * x_in, pi_kt_sink ** sink_out) {
+    const int words = (ctx->n_ctx + 31) / 32;
+    const int32_t * h_tok = (const int32_t *) meta, * h_pos = h_tok + n_tokens, * h_dyn = h_pos + n_tokens; const uint32_t * h_mask = (const uint32_t *) (h_dyn + 4);
+    const int kv_head = h_dyn[0];
+    hipStream_t s = ctx->stream;
+    bool ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (ok && x_in) ok = hipMemcpyAsync(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (!ok) { ctx->last_error = "H2D of batch metadata failed"; return false; }
+    if (ctx->use_graphs && !getenv("PI_TRACE")) {
+        // one HIP graph per batch width: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device
+        // memory that the copies above refresh, so replaying the graph IS this call's forward pass
+        llama_context::graph_entry & ge = ctx->graphs[n_tokens];
+        if (!ge.exec) {
+            hipGraph_t graph = nullptr;
+            ge.sink.every = 16;
+            ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                pi_kt_set_sink(&ge.sink);                          // sample points are part of the graph; they are only read while timing is on
+                const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx);
+                pi_kt_set_sink(nullptr);
+                ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void) hipGraphDestroy(graph);
+            if (!ok) { ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error; ge.exec = nullptr; }
+        }
+        if (ok) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
+        if (ok && sink_out) *sink_out = &ge.sink;
+        return ok;
+    }
+    return forward(ctx, n_tokens, kv_head, ctx->n_ctx);
+}
+
 pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & rc) {
     rc = -1;
     std::string err;
@@ -251,7 +293,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     pi_run * run = acquire_run(ctx, n_tokens, meta_bytes);
     if (!run) { ctx->last_error = "out of pinned host memory"; return nullptr; }
     run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us(); run->sink = nullptr;
-    if (hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
+    if (!ctx->remote && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
     // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
     run->want_logits.assign(n_tokens, 1);
     run->last_only = false;
@@ -266,36 +308,22 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
 
     run->canceled = ctx->canceled_batches.count(run->batch_id) > 0;
     bool ok = true;
+    if (ctx->remote) {                                                        // the layers live in other processes: ship the metadata block
+        if (!run->canceled) {
+            run->run_seq = ctx->remote_seq++;
+            ok = ctx->remote_ops.start(ctx->remote_ops.user, run->run_seq, run->batch_id, n_tokens, run->meta_host, meta_bytes) == 0;
+            if (!ok) ctx->last_error = "remote start failed";
+            run->launched = ok;
+            ctx->stat_calls++;
+        }
+        if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); ctx->pool.push_back(run); return nullptr; }
+        ctx->inflight.push_back(run);
+        rc = 0;
+        return run;
+    }
     if (!run->canceled) {                                                     // a cancelled run still occupies its cells and completes "empty" (llama.cpp:5627-5716)
         hipStream_t s = ctx->stream;
-        ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
-             hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
-             hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16, hipMemcpyHostToDevice, s) == hipSuccess &&
-             hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
-        if (!ok) ctx->last_error = "H2D of batch metadata failed";
-        if (ok && ctx->use_graphs && !getenv("PI_TRACE")) {
-            // one HIP graph per batch width: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device
-            // memory that the copies above refresh, so replaying the graph IS this call's forward pass
-            llama_context::graph_entry & ge = ctx->graphs[n_tokens];
-            if (!ge.exec) {
-                hipGraph_t graph = nullptr;
-                ge.sink.every = 16;
-                ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-                if (ok) {
-                    pi_kt_set_sink(&ge.sink);                      // sample points are part of the graph; they are only read while timing is on
-                    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx);
-                    pi_kt_set_sink(nullptr);
-                    ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
-                }
-                if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
-                if (graph) (void) hipGraphDestroy(graph);
-                if (!ok) { ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error; ge.exec = nullptr; }
-            }
-            if (ok) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
-            if (ok) run->sink = &ge.sink;
-        } else if (ok) {
-            ok = forward(ctx, n_tokens, kv_head, ctx->n_ctx);
-        }
+        ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
         if (ok && ctx->is_last) {
             const size_t nv = ctx->model->hparams.n_vocab;
             ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -317,12 +345,57 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
 
 bool context_poll_oldest(llama_context * ctx) {
     if (ctx->inflight.empty()) return false;
+    if (ctx->remote) return !ctx->inflight.front()->launched || ctx->remote_ops.poll(ctx->remote_ops.user) != 0;
     return hipEventQuery(ctx->inflight.front()->done) == hipSuccess;
+}
+
+bool context_wait(llama_context * ctx, pi_run * run) {
+    if (ctx->remote) return true;                                             // context_finish blocks in the transport's wait()
+    return hipEventSynchronize(run->done) == hipSuccess;
+}
+
+// One run on a pipeline stage (a process that owns layers [l0, l1)).  Mirrors the worker side of llama_decode_internal
+// (llama.cpp:5588-5760): receive activations, compute the local graph, hand the result on; here the transport is the caller's.
+int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
+              float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum) {
+    std::string err;
+    if (!context_prepare(ctx, err)) { ctx->last_error = err; return -1; }
+    const int words = (ctx->n_ctx + 31) / 32;
+    if (n_tokens <= 0 || n_tokens > ctx->n_batch || meta_bytes < (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4) { ctx->last_error = "stage_run: bad metadata block"; return -1; }
+    if (!ctx->is_first && !x_in) { ctx->last_error = "stage_run: activations missing"; return -1; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    (void) hipEventRecord(e0, ctx->stream);
+    bool ok = launch_forward(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in, nullptr);
+    hipStream_t s = ctx->stream;
+    const size_t nv = ctx->model->hparams.n_vocab;
+    if (ok && !ctx->is_last) ok = hipMemcpyAsync(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (ok && ctx->is_last)
+        ok = hipMemcpyAsync(logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipMemcpyAsync(topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
+    (void) hipEventRecord(e1, s);
+    if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
+    float ms = 0.0f;
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->stat_gpu_ms += ms;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "stage_run failed"; return -1; }
+    const int32_t * h_dyn = (const int32_t *) meta + 2 * n_tokens;
+    ctx->stat_calls++;
+    ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, h_dyn[1]);
+    return 0;
 }
 
 int context_finish(llama_context * ctx, pi_run * run) {
     if (!run) return -1;
-    if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; return -1; }
+    if (ctx->remote) {
+        if (run->launched) {
+            const int rc = ctx->remote_ops.wait(ctx->remote_ops.user, run->run_seq, run->logits_host, run->topk_ids, run->topk_vals, run->topk_sum);
+            if (rc < 0) { ctx->last_error = "remote wait failed"; return -1; }
+            run->launched = rc == 1;                                          // 0: a stage skipped the run after a cancel
+        }
+    } else if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; return -1; }
     const size_t nv = ctx->model->hparams.n_vocab;
     const int n = run->n_tokens;
     if (ctx->is_last) {
@@ -338,7 +411,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
             ctx->last_n_tokens = 0;
         }
     }
-    if (run->launched) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_gpu_ms += ms; }
+    if (run->launched && !ctx->remote) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_gpu_ms += ms; }
     if (run->launched && run->sink && pi_kt_enabled()) pi_kt_accumulate(run->sink, 1);
     const int64_t dt = time_us() - run->t_start_us;
     if (n == 1) { ctx->t_eval_us += dt; ctx->n_eval++; } else { ctx->t_p_eval_us += dt; ctx->n_p_eval += n; }     // llama.cpp:5807-5815

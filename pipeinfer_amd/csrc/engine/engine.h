@@ -70,6 +70,8 @@ struct pi_run {                                // one llama_start_async_decode .
     uint8_t * meta_host = nullptr; size_t meta_cap = 0;                                       // pinned staging for tokens/pos/mask
     int64_t t_start_us = 0;
     pi_kt_sink * sink = nullptr;            // kernel-timing samples of the graph this run replayed
+    int32_t run_seq = 0;                    // remote contexts: sequence number of the run on the wire
+    bool host_plain = false;                // buffers come from malloc (remote contexts never touch the GPU)
 };
 
 struct llama_context {
@@ -79,6 +81,9 @@ struct llama_context {
     // pipeline stage owned by this process (single process: the whole model)
     int l0 = 0, l1 = 0; bool is_first = true, is_last = true;
     int node_id = 0; bool comm_swapped = false; int comm_color = 0, comm_color_alt = 0;
+    // head of a multi-process pipeline: this context only keeps the KV-cell table and ships each run's metadata through
+    // the callbacks (include/pipeinfer.h); the layers run in other processes (pipeinfer_stage_run)
+    bool remote = false; pipeinfer_remote_ops remote_ops{}; int32_t remote_seq = 0;
 
     std::unique_ptr<pi::kv_cells> cells;
     uint16_t * k_cache = nullptr, * v_cache = nullptr;        // [n_layer_local][n_ctx][n_embd_gqa] f16 each
@@ -118,5 +123,8 @@ bool context_prepare(llama_context * ctx, std::string & err);          // upload
 pi_run * context_start(llama_context * ctx, const llama_batch & batch, int & rc);   // rc: 0 ok, 1 no slot, <0 error
 int  context_finish(llama_context * ctx, pi_run * run);
 bool context_poll_oldest(llama_context * ctx);
+bool context_wait(llama_context * ctx, pi_run * run);                    // blocks until the run's results are in host memory
+int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
+               float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum);
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

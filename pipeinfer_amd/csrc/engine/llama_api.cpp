@@ -70,7 +70,10 @@ extern "C" void llama_split_layers_weighted(struct llama_context *, float *, siz
 extern "C" bool llama_mpi_iprobe(struct llama_context * ctx) { return pi::context_poll_oldest(ctx); }
 
 extern "C" void llama_cancel_run(struct llama_context * ctx, int32_t * canceled, int count) {
-    for (int i = 0; i < count; i++) ctx->canceled_batches.insert(canceled[i]);                     // llama.cpp:9981-9993
+    for (int i = 0; i < count; i++) {
+        ctx->canceled_batches.insert(canceled[i]);                                                     // llama.cpp:9981-9993
+        if (ctx->remote && ctx->remote_ops.cancel) ctx->remote_ops.cancel(ctx->remote_ops.user, canceled[i]);
+    }
 }
 
 extern "C" struct ggml_cgraph * llama_start_async_decode(struct llama_context * ctx, struct llama_batch batch) {
@@ -224,6 +227,38 @@ extern "C" void llama_reset_timings(struct llama_context * ctx) {
 }
 
 // ---- extensions ------------------------------------------------------------------------------------------------------------------
+extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }
+
+extern "C" void pipeinfer_context_set_remote(struct llama_context * ctx, const struct pipeinfer_remote_ops * ops) {
+    ctx->remote = ops != nullptr;
+    if (ops) ctx->remote_ops = *ops;
+}
+
+extern "C" int pipeinfer_context_set_stage(struct llama_context * ctx, int32_t l0, int32_t l1, int32_t is_first, int32_t is_last) {
+    if (ctx->x) { ctx->last_error = "pipeinfer_context_set_stage: context already prepared"; return -1; }
+    if (l0 < 0 || l1 < l0 || l1 > ctx->model->hparams.n_layer) { ctx->last_error = "pipeinfer_context_set_stage: bad layer range"; return -1; }
+    ctx->l0 = l0; ctx->l1 = l1; ctx->is_first = is_first != 0; ctx->is_last = is_last != 0;
+    return 0;
+}
+
+// ggml_mpi_split_layers (ggml-mpi.c:541-557): stage i gets [next, min(n_layer - 1, next + w_i * n_layer)] as a closed pair in the
+// reference's encoding, consumed as the half-open [start, end) of ggml_mpi_graph_creation_post (:640-700); the last stage
+// takes whatever is left
+extern "C" void pipeinfer_split_layers(int32_t n_layer, const float * weights, int32_t n_stage, int32_t * ranges) {
+    int next = 0;
+    for (int i = 0; i < n_stage; i++) {
+        int end = i == n_stage - 1 ? n_layer : std::min(n_layer, next + (int) (weights[i] * n_layer));
+        if (end < next) end = next;
+        ranges[2 * i] = next; ranges[2 * i + 1] = end;
+        next = end;
+    }
+}
+
+extern "C" int pipeinfer_stage_run(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
+                                   float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum) {
+    return pi::stage_run(ctx, n_tokens, meta, meta_bytes, x_in_dev, x_out_dev, logits_host, topk_ids, topk_vals, topk_sum);
+}
+
 extern "C" int pipeinfer_context_prepare(struct llama_context * ctx) {
     std::string err;
     if (!pi::context_prepare(ctx, err)) { ctx->last_error = err; return -1; }

@@ -371,7 +371,7 @@ struct driver {
                 spec_past_tgt = n_past_tgt; spec_past_dft = n_past_dft;
                 first_run = true;
             } else if (!tgt_runs.empty()) {
-                if (P.mode == 2) { hipEventSynchronize(((pi_run *) tgt_runs.back()->ticket)->done); continue; }      // target only: just wait
+                if (P.mode == 2) { pi::context_wait(tgt, (pi_run *) tgt_runs.back()->ticket); if (tgt->remote) { while (!llama_mpi_iprobe(tgt)) {} } continue; }      // target only: just wait
                 run_speculation_loop();
                 continue;
             }
@@ -480,6 +480,8 @@ extern "C" int pipeinfer_speculative(struct llama_context * ctx_tgt, struct llam
     if (!ctx_tgt->cparams.logits_all || (params->mode != 2 && !ctx_dft->cparams.logits_all)) { fprintf(stderr, "pipeinfer_speculative: both contexts need logits_all (speculative.cpp:115)\n"); return -1; }
     ctx_tgt->canceled_batches.clear();                       // batch ids restart at 1 for every call
     if (ctx_dft) ctx_dft->canceled_batches.clear();
+    for (llama_context * c : { ctx_tgt, ctx_dft })           // remote stages key their cancel notes by generation: -2 opens a new one
+        if (c && c->remote && c->remote_ops.cancel) c->remote_ops.cancel(c->remote_ops.user, -2);
     const int n = d.run(prompt, n_prompt, out_tokens, out_cap);
     if (result) *result = d.R;
     return n;

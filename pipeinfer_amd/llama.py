@@ -184,6 +184,11 @@ class Context:
             raise L.PipeInferError("llama_new_context_with_model failed")
         self.n_vocab = model.n_vocab
 
+    def set_graphs(self, enable):
+        self.lib.pipeinfer_context_set_graphs.argtypes = [C.c_void_p, C.c_int]
+        self.lib.pipeinfer_context_set_graphs.restype = None
+        self.lib.pipeinfer_context_set_graphs(self.h, int(enable))
+
     def prepare(self):
         if self.lib.pipeinfer_context_prepare(self.h) != 0:
             raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())

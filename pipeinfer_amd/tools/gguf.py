@@ -52,7 +52,8 @@ class GGUFWriter:
         self.kv.append((key, vtype, payload))
 
     def add_tensor(self, name, ne, ttype, data):
-        """ne: ggml order (ne[0] = contiguous dim). data: bytes-like / ndarray, or a callable returning one (lazy)."""
+        """ne: ggml order (ne[0] = contiguous dim). data: bytes-like / ndarray, a callable returning one (lazy), or None:
+        the tensor keeps its place in the file but its bytes are a hole (pipeline stages materialise only their own layers)."""
         self.tensors.append((name, tuple(int(x) for x in ne), ttype, data))
 
     def write(self):
@@ -68,12 +69,16 @@ class GGUFWriter:
             pad = (-f.tell()) % ALIGN
             f.write(b"\0" * pad)
             for name, ne, ttype, data in self.tensors:
+                if data is None:
+                    f.seek((nbytes(ttype, ne) + ALIGN - 1) // ALIGN * ALIGN, 1)      # sparse: never read by this process
+                    continue
                 if callable(data):
                     data = data()
                 buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
                 assert buf.size == nbytes(ttype, ne), (name, buf.size, nbytes(ttype, ne))
                 buf.tofile(f)
                 f.write(b"\0" * ((-buf.size) % ALIGN))
+            f.truncate(f.tell())                 # a trailing hole still counts towards the file size
 
 
 def read_gguf(path):

@@ -274,9 +274,11 @@ def _vocab_kv(w, arch, n_vocab, vocab=None):
 
 
 def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random", noise=1.0, quantizer=None, vocab=None,
-                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0):
+                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0, only=None):
     """quantizer(ttype, f32 [rows,k]) -> uint8 blocks: when given (tests: the REAL reference quantiser), every weight is
-    drawn as N(0,std^2) floats and quantised with it; otherwise blocks are filled directly (see module docstring)."""
+    drawn as N(0,std^2) floats and quantised with it; otherwise blocks are filled directly (see module docstring).
+    only(name) -> bool: tensors for which it is False become holes in the file (every tensor has its own seed, so a pipeline
+    stage that writes just its layers gets the same bytes as a full file)."""
     arch, n_layer, n_embd, n_head, n_head_kv, n_ff, n_vocab, n_ctx_train = SPECS[spec_name]
     w = G.GGUFWriter(path)
     w.add("general.architecture", G.STR, arch)
@@ -325,7 +327,7 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
             if quantizer is not None:
                 return quantizer(ttype, rng.standard_normal((rows, k), dtype=np.float32) * np.float32(s))
             return random_blocks(ttype, n, rng, s)
-        w.add_tensor(name, ne, ttype, make)
+        w.add_tensor(name, ne, ttype, make if (only is None or only(name)) else None)
     w.write()
     emb_cache.clear()
     return {"arch": arch, "n_layer": n_layer, "n_embd": n_embd, "n_head": n_head, "n_head_kv": n_head_kv, "n_ff": n_ff,

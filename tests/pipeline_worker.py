@@ -1,0 +1,126 @@
+"""world_size-2 worker for tests/test_pipeline_gloo.py (launched by torch.distributed.run, gloo, no GPU).
+
+rank 0  the C++ PipeInfer driver (pipeinfer_speculative) with the TARGET context as the proxy of a remote pipeline
+        (pipeinfer_amd.pipeline.RemoteTarget over gloo) and the DRAFT context served in-process
+rank 1  pipeinfer_amd.pipeline.stage_loop — the whole target model as one stage
+
+The layers themselves are computed by the ORACLE (oracle/model.c o_model_forward) on both sides: this is test infrastructure
+standing in for pipeinfer_stage_run, so that the transport, the metadata block, early cancellation and the driver are
+exercised without a GPU.  Writes its verdict as JSON to argv[1] (rank 0 only)."""
+import collections
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pipeinfer_amd import llama as LL, pipeline as P          # noqa: E402
+from tests import oracle_lib as O, scenarios as S             # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+N_CTX = 256
+
+
+class OracleCompute:
+    """metadata block -> (top-8 ids, logits of those, sum exp, full logits) through the oracle's forward pass"""
+
+    def __init__(self, stem):
+        self.o = O.oracle()
+        self.h = self.o.o_model_load(os.path.join(GOLD, stem + ".gguf").encode(), N_CTX, 8)
+        assert self.h
+        self.n_vocab = self.o.o_model_info(self.h, 0)
+
+    def run(self, n, meta, x_in=None, x_out=None):
+        meta = np.ascontiguousarray(meta, np.int32)
+        words = (N_CTX + 31) // 32
+        tok, pos, dyn = meta[:n], meta[n:2 * n], meta[2 * n:2 * n + 4]
+        kv_head, n_kv = int(dyn[0]), int(dyn[1])
+        bits = meta[2 * n + 4:2 * n + 4 + n * words].view(np.uint32).reshape(n, words)
+        vis = np.unpackbits(bits.view(np.uint8).reshape(n, -1), axis=1, bitorder="little")[:, :n_kv]
+        mask = np.where(vis == 1, 0.0, -np.inf).astype(np.float32)
+        logits = np.zeros((n, self.n_vocab), np.float32)
+        rc = self.o.o_model_forward(self.h, np.ascontiguousarray(tok).ctypes.data, np.ascontiguousarray(pos).ctypes.data, n, kv_head, n_kv,
+                                    np.ascontiguousarray(mask).ctypes.data, logits.ctypes.data)
+        assert rc == 0
+        ids = np.zeros((n, 8), np.int32); vals = np.zeros((n, 8), np.float32); sums = np.zeros(n, np.float32)
+        for i in range(n):
+            order = np.lexsort((np.arange(self.n_vocab), -logits[i]))[:8]           # logit descending, lower id first on ties
+            ids[i], vals[i] = order, logits[i][order]
+            sums[i] = np.exp(logits[i] - logits[i].max(), dtype=np.float32).sum(dtype=np.float32)
+        return ids, vals, sums, logits
+
+
+class LocalOps:
+    """struct pipeinfer_remote_ops served in-process (the draft context of the head)"""
+
+    def __init__(self, compute):
+        self.compute, self.done = compute, collections.OrderedDict()
+        self.ops = P.RemoteOps(None, P.START_FN(self._start), P.POLL_FN(self._poll), P.WAIT_FN(self._wait), P.CANCEL_FN(self._cancel))
+
+    def attach(self, ctx):
+        ctx.lib.pipeinfer_context_set_remote.argtypes = [C.c_void_p, C.c_void_p]
+        ctx.lib.pipeinfer_context_set_remote.restype = None
+        ctx.lib.pipeinfer_context_set_remote(ctx.h, C.byref(self.ops))
+
+    def _start(self, user, run_seq, batch_id, n, meta, nbytes):
+        block = np.frombuffer(C.string_at(meta, (nbytes + 3) // 4 * 4), dtype=np.int32).copy()
+        self.done[run_seq] = (n, self.compute.run(n, block))
+        return 0
+
+    def _poll(self, user):
+        return 1 if self.done else 0
+
+    def _wait(self, user, run_seq, logits, ids, vals, sums):
+        n, (i8, v8, s, lg) = self.done.pop(run_seq)
+        C.memmove(ids, i8.ctypes.data, i8.nbytes); C.memmove(vals, v8.ctypes.data, v8.nbytes)
+        C.memmove(sums, s.ctypes.data, s.nbytes); C.memmove(logits, lg.ctypes.data, lg.nbytes)
+        return 1
+
+    def _cancel(self, user, batch_id):
+        pass
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("PI_TEST_WATCHDOG", "100")), exit=True)
+    out_path, tgt, dft = sys.argv[1], sys.argv[2], sys.argv[3]
+    links = P.init_links()
+    rank = dist.get_rank()
+    assert dist.get_world_size() == 2 and links.device == "cpu"
+    if rank == 1:
+        comp = OracleCompute(tgt)
+        n_embd = comp.o.o_model_info(comp.h, 1)
+        st = P.stage_loop(links, comp, head=0, prev=0, nxt=None, n_embd=n_embd, n_vocab=comp.n_vocab, n_batch=64)
+        dist.barrier()
+        print("stage served", st, file=sys.stderr)
+        return
+    g = np.load(os.path.join(GOLD, tgt + ".npz"))
+    prompt, _ = S.scenario_greedy(512, seed=int(sys.argv[4]), n_prompt=8)
+    want = [int(x) for x in g["greedy_tokens"][:24]]
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    verdict = {"trials": []}
+    remote = None
+    for trial, (n_draft, n_parallel, min_spec) in enumerate(((3, 3, 1), (4, 2, 2), (2, 1, 0))):
+        ct, cd = LL.Context(mt, n_ctx=N_CTX, n_batch=64), LL.Context(md, n_ctx=N_CTX, n_batch=64)
+        remote = remote if trial else P.RemoteTarget(links, 1, 1, [1], mt.n_vocab)     # one transport, several generations
+        remote.attach(ct)
+        local = LocalOps(OracleCompute(dft))
+        local.attach(cd)
+        out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec, verbose=int(os.environ.get("V", "0")))
+        verdict["trials"].append({"out": [int(x) for x in out[:24]], "want": want, "n_runs_spec": res["n_runs_spec"], "n_runs_canceled": res["n_runs_canceled"],
+                                  "n_accept_clean": res["n_accept_clean"], "started": remote.n_started, "results": remote.n_results, "skipped": remote.n_skipped,
+                                  "cancel_msgs": remote.n_cancel_msgs})
+        ct.free(); cd.free()
+    remote.shutdown()
+    dist.barrier()
+    with open(out_path, "w") as f:
+        json.dump(verdict, f)
+
+
+if __name__ == "__main__":
+    main()
