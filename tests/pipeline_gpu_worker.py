@@ -1,0 +1,87 @@
+"""GPU worker of test_pipeline_stages_reproduce_the_single_process_path: python tests/pipeline_gpu_worker.py <fixture> <l0-l1,l0-l1,...>"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+assert torch.cuda.is_available()                    # torch first: it must own the HIP runtime before libpipeinfer_amd.so is loaded
+torch.zeros(1, device="cuda")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pipeinfer_amd import llama as LL, pipeline as P          # noqa: E402
+from tests import scenarios as S                              # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15}
+
+
+class InProcessPipeline:
+    """struct pipeinfer_remote_ops served by pipeline stages living in THIS process (no torch.distributed): the head's
+    metadata block goes through pipeinfer_stage_run on each stage in turn, activations in device tensors"""
+
+    def __init__(self, P, path, ranges, n_ctx, n_batch):
+        self.P = P
+        self.stages = [P.HipStage(path, l0, l1, i == 0, i == len(ranges) - 1, n_ctx, n_batch) for i, (l0, l1) in enumerate(ranges)]
+        self.x = [torch.empty((n_batch, self.stages[0].n_embd), dtype=torch.float32, device="cuda") for _ in ranges]
+        self.done = {}
+        self.ops = P.RemoteOps(None, P.START_FN(self._start), P.POLL_FN(lambda u: 1 if self.done else 0), P.WAIT_FN(self._wait), P.CANCEL_FN(lambda u, b: None))
+
+    def attach(self, ctx):
+        ctx.lib.pipeinfer_context_set_remote.argtypes = [C.c_void_p, C.c_void_p]
+        ctx.lib.pipeinfer_context_set_remote.restype = None
+        ctx.lib.pipeinfer_context_set_remote(ctx.h, C.byref(self.ops))
+
+    def _start(self, user, run_seq, batch_id, n, meta, nbytes):
+        block = np.frombuffer(C.string_at(meta, (nbytes + 3) // 4 * 4), dtype=np.int32).copy()
+        res = None
+        for i, st in enumerate(self.stages):
+            res = st.run(n, block, None if i == 0 else self.x[i - 1][:n], None if i == len(self.stages) - 1 else self.x[i][:n])
+        self.done[run_seq] = tuple(np.array(a) for a in res)
+        return 0
+
+    def _wait(self, user, run_seq, logits, ids, vals, sums):
+        i8, v8, s, lg = self.done.pop(run_seq)
+        for dst, a in ((ids, i8), (vals, v8), (sums, s), (logits, lg)):
+            a = np.ascontiguousarray(a)
+            C.memmove(dst, a.ctypes.data, a.nbytes)
+        return 1
+
+    def close(self):
+        for st in self.stages:
+            st.close()
+
+
+
+def main():
+    stem = sys.argv[1]
+    ranges = [tuple(int(v) for v in r.split("-")) for r in sys.argv[2].split(",")]
+    path = os.path.join(GOLD, stem + ".gguf")
+    g = np.load(os.path.join(GOLD, stem + ".npz"))
+    prompt, _ = S.scenario_greedy(512, seed=SEEDS[stem], n_prompt=8)
+    want = [int(x) for x in g["greedy_tokens"][:24]]
+    model = LL.Model(path)
+    pipe = InProcessPipeline(P, path, ranges, 256, 64)
+    head, full = LL.Context(model, n_ctx=256, n_batch=64), LL.Context(model, n_ctx=256, n_batch=64)
+    pipe.attach(head)
+    toks, pos = prompt, list(range(len(prompt)))
+    a = head.decode(toks, pos, [[0]] * len(toks))
+    b = full.decode(toks, pos, [[0]] * len(toks))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
+    a = head.decode([want[0], want[1]], [8, 9], [[0], [0, 1]])                   # a later batch: cells, mask and kv_head travel in the block
+    b = full.decode([want[0], want[1]], [8, 9], [[0], [0, 1]])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), np.abs(a - b).max()
+    head.kv_clear()
+    dft = LL.Context(model, n_ctx=256, n_batch=64)
+    out, res = LL.speculative(head, dft, prompt, n_predict=23, n_draft=3, n_parallel=2, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=1)
+    assert [int(x) for x in out[:24]] == want, (out, want, res)
+    for c in (head, full, dft):
+        c.free()
+    pipe.close()
+    model.free()
+    print("PIPELINE-OK", stem, ranges, {k: res[k] for k in ("n_runs_spec", "n_runs_canceled", "n_accept_clean")})
+
+
+if __name__ == "__main__":
+    main()
