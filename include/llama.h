@@ -185,5 +185,9 @@ LLAMA_API const char * llama_print_system_info(void);
 
 #ifdef __cplusplus
 }
+/* The reference declares these with C++ references (llama.h:285-290); callers written against it keep compiling.
+ * Same machine ABI: a reference is passed as the object's address. */
+static inline struct ggml_cgraph * llama_start_async_decode(struct llama_context & lctx, struct llama_batch batch) { return llama_start_async_decode(&lctx, batch); }
+static inline int llama_finish_async_decode(struct llama_context & lctx, struct llama_batch batch, struct ggml_cgraph * cgraph) { return llama_finish_async_decode(&lctx, batch, cgraph); }
 #endif
 #endif
