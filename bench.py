@@ -125,6 +125,10 @@ def main():
     t0 = time.time()
     mt, md = LL.Model(tgt_path), LL.Model(dft_path)
     ct, cd = LL.Context(mt, n_ctx=args.n_ctx, n_batch=512), LL.Context(md, n_ctx=args.n_ctx, n_batch=512)
+    cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "1")))
+    n_draft_cus = int(os.environ.get("PIPEINFER_DRAFT_CUS", "0"))
+    if n_draft_cus > 0 and args.mode == 0:
+        cd.set_cu_range(0, n_draft_cus); ct.set_cu_range(n_draft_cus, 256)
     ct.prepare(); cd.prepare()
     print(f"[bench] models resident in HBM after {time.time() - t0:.1f}s", file=sys.stderr)
 

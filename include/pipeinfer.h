@@ -19,6 +19,12 @@ LLAMA_API void pipeinfer_kv_cache_seq_rm_cp_range(struct llama_context * ctx, ll
 
 /* uploads this process's stage weights and allocates KV cache + scratch now (otherwise done by the first decode) */
 LLAMA_API int  pipeinfer_context_prepare(struct llama_context * ctx);
+/* queue priority of the context's HIP stream (> 0 high, 0 default, < 0 low); call before the first decode.  The draft context of a
+ * single-GPU run wants high: its tokens gate speculation while the target's runs keep the GPU full. */
+LLAMA_API int  pipeinfer_context_set_priority(struct llama_context * ctx, int priority);
+/* restricts the context's stream to compute units [cu_lo, cu_hi) of the 256 (hipExtStreamCreateWithCUMask); before the first decode.
+ * Draft and target contexts on one GPU get disjoint slices so that their kernels overlap instead of alternating. */
+LLAMA_API int  pipeinfer_context_set_cu_range(struct llama_context * ctx, int cu_lo, int cu_hi);
 /* 0: launch the decode kernels one by one instead of replaying the captured HIP graph (profiling / per-kernel event timing) */
 LLAMA_API void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable);
 LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);

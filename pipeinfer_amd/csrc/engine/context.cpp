@@ -56,7 +56,20 @@ bool context_prepare(llama_context * ctx, std::string & err) {
     if (!m->ensure_loaded(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, err)) return false;
     ctx->t_load_us += time_us() - t0;
     const int nb = ctx->n_batch, n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, n_layer_local = ctx->l1 - ctx->l0;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+    {   // the draft context asks for the high-priority queue: its kernels are small and on the critical path of speculation, the
+        // target's verify runs fill the GPU for milliseconds — without priority a draft token waits behind a whole target run
+        int lo = 0, hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int prio = ctx->stream_priority > 0 ? hi : ctx->stream_priority < 0 ? lo : (lo + hi) / 2;
+        if (ctx->cu_hi > ctx->cu_lo) {
+            // a private slice of the compute units: two contexts on one GPU then run side by side instead of taking turns kernel
+            // by kernel (a small draft kernel otherwise waits for the target kernel that currently fills all 256 CUs — 242 times
+            // per draft token)
+            std::vector<uint32_t> mask((size_t) (ctx->cu_hi + 31) / 32, 0u);
+            for (int i = ctx->cu_lo; i < ctx->cu_hi; i++) mask[(size_t) i >> 5] |= 1u << (i & 31);
+            if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t) mask.size(), mask.data()) != hipSuccess) { err = "hipExtStreamCreateWithCUMask failed"; return false; }
+        } else if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+    }
     auto dev = [&](size_t bytes) -> void * { void * p = pi_malloc(bytes); if (!p) err = pi_last_error(); return p; };
     const size_t kv_elems = (size_t) n_layer_local * ctx->n_ctx * n_gqa;
     if (!(ctx->k_cache = (uint16_t *) dev(kv_elems * 2)) || !(ctx->v_cache = (uint16_t *) dev(kv_elems * 2))) return false;

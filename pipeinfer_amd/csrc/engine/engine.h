@@ -89,6 +89,8 @@ struct llama_context {
     uint16_t * k_cache = nullptr, * v_cache = nullptr;        // [n_layer_local][n_ctx][n_embd_gqa] f16 each
     void * rope = nullptr;
     hipStream_t stream = nullptr;
+    int stream_priority = 0;                 // > 0 high, < 0 low (pipeinfer_context_set_priority, before the first decode)
+    int cu_lo = 0, cu_hi = 0;                // compute units [cu_lo, cu_hi) reserved for this context's stream (0,0: all)
 
     // device scratch, sized for n_batch tokens
     float * x = nullptr, * x2 = nullptr, * nx = nullptr, * nx2 = nullptr, * qkv = nullptr, * att = nullptr, * up = nullptr, * gate = nullptr, * logits_dev = nullptr;

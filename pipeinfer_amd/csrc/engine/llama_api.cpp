@@ -227,6 +227,19 @@ extern "C" void llama_reset_timings(struct llama_context * ctx) {
 }
 
 // ---- extensions ------------------------------------------------------------------------------------------------------------------
+extern "C" int pipeinfer_context_set_priority(struct llama_context * ctx, int priority) {
+    if (ctx->stream) { ctx->last_error = "pipeinfer_context_set_priority: the stream already exists"; return -1; }
+    ctx->stream_priority = priority;
+    return 0;
+}
+
+extern "C" int pipeinfer_context_set_cu_range(struct llama_context * ctx, int cu_lo, int cu_hi) {
+    if (ctx->stream) { ctx->last_error = "pipeinfer_context_set_cu_range: the stream already exists"; return -1; }
+    if (cu_lo < 0 || cu_hi < cu_lo || cu_hi > 1024) { ctx->last_error = "pipeinfer_context_set_cu_range: bad range"; return -1; }
+    ctx->cu_lo = cu_lo; ctx->cu_hi = cu_hi;
+    return 0;
+}
+
 extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }
 
 extern "C" void pipeinfer_context_set_remote(struct llama_context * ctx, const struct pipeinfer_remote_ops * ops) {

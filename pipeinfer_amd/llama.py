@@ -184,6 +184,16 @@ class Context:
             raise L.PipeInferError("llama_new_context_with_model failed")
         self.n_vocab = model.n_vocab
 
+    def set_priority(self, priority):
+        self.lib.pipeinfer_context_set_priority.argtypes = [C.c_void_p, C.c_int]
+        if self.lib.pipeinfer_context_set_priority(self.h, int(priority)) != 0:
+            raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
+
+    def set_cu_range(self, lo, hi):
+        self.lib.pipeinfer_context_set_cu_range.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if self.lib.pipeinfer_context_set_cu_range(self.h, int(lo), int(hi)) != 0:
+            raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
+
     def set_graphs(self, enable):
         self.lib.pipeinfer_context_set_graphs.argtypes = [C.c_void_p, C.c_int]
         self.lib.pipeinfer_context_set_graphs.restype = None
