@@ -68,8 +68,8 @@ class Links:
     """the two process groups of a run: `ctrl` carries host tensors (gloo), `data` device tensors (nccl = RCCL) — on a CPU-only
     box both are the same gloo group and activations are host tensors"""
 
-    def __init__(self, ctrl=None, data=None, device="cpu"):
-        self.ctrl, self.data, self.device = ctrl, data, device
+    def __init__(self, ctrl=None, data=None, device="cpu", via_host=False):
+        self.ctrl, self.data, self.device, self.via_host = ctrl, data, device, via_host
 
     def send_ctrl(self, t, dst, tag):
         dist.send(t, dst, group=self.ctrl, tag=tag)
@@ -81,14 +81,21 @@ class Links:
         return dist.irecv(t, src, group=self.ctrl, tag=tag)
 
     def send_data(self, t, dst):
-        if t.is_cuda:
+        if t.is_cuda and self.via_host:                 # several ranks on one GPU (RCCL needs one GPU per rank): stage through the host
+            dist.send(t.cpu(), dst, group=self.ctrl, tag=TAG_ACT)
+        elif t.is_cuda:
             dist.send(t, dst, group=self.data)
             torch.cuda.current_stream().synchronize()
         else:
             dist.send(t, dst, group=self.ctrl, tag=TAG_ACT)
 
     def recv_data(self, t, src):
-        if t.is_cuda:
+        if t.is_cuda and self.via_host:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(h, src, group=self.ctrl, tag=TAG_ACT)
+            t.copy_(h)
+            torch.cuda.current_stream().synchronize()
+        elif t.is_cuda:
             dist.recv(t, src, group=self.data)
             torch.cuda.current_stream().synchronize()       # the stage kernels run on the library's own stream
         else:
@@ -98,11 +105,16 @@ class Links:
 def init_links():
     """process groups from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)"""
     use_gpu = torch.cuda.is_available()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # more ranks than GPUs (single-GPU dry runs of the N > 1 path): everything over gloo, activations staged through the host
+    shared_gpu = use_gpu and (world > torch.cuda.device_count() or os.environ.get("PIPEINFER_FORCE_GLOO"))
     if not dist.is_initialized():
-        dist.init_process_group("nccl" if use_gpu else "gloo")
+        dist.init_process_group("nccl" if use_gpu and not shared_gpu else "gloo")
     if use_gpu:
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
         torch.cuda.set_device(local)
+        if shared_gpu:
+            return Links(ctrl=None, data=None, device=f"cuda:{local}", via_host=True)
         return Links(ctrl=dist.new_group(backend="gloo"), data=None, device=f"cuda:{local}")
     return Links(ctrl=None, data=None, device="cpu")
 
@@ -327,7 +339,7 @@ def bench_main(args, rank, world):
     import bench as B
 
     links = init_links()
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank))) % max(1, torch.cuda.device_count())
     lib = L.load()
     L.check(lib.pi_device_init(local), "pi_device_init")
     tspec, tft, dspec, dft = B.WORKLOADS[args.workload if args.workload != "7b" else "70b"]
