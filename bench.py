@@ -88,6 +88,20 @@ def cpu_baseline(tgt_path, n_tokens, n_prompt):
             "sample": f"target-only greedy decode of {n_tokens} tokens after a {n_prompt}-token prompt, same synthetic GGUF, n_threads={cores}"}
 
 
+def lossless_diagnostic(ct, prompt, ref_tokens, spec_tokens, n_predict):
+    """Speculative and target-only output differ: report where, and how close the call was.  Every run of the engine equals the
+    reference arithmetic bit for bit (tests/debug_trace_compare.py), but that arithmetic depends on the KV-cell layout (attention
+    sums run in cell order), and f16 / Q8 re-quantisation amplifies the last-bit differences; on random-weight models a different
+    layout can flip a close argmax.  The logits below are those of the common prefix evaluated as one batch."""
+    bad = next(i for i in range(n_predict) if ref_tokens[i] != spec_tokens[i])
+    ct.kv_clear()
+    seq = list(prompt) + [int(t) for t in ref_tokens[:bad]]
+    lg = ct.decode(seq, list(range(len(seq))), [[0]] * len(seq))[-1]
+    a, b = int(ref_tokens[bad]), int(spec_tokens[bad])
+    return {"token_index": bad, "target_only": a, "speculative": b, "logit_target_only": round(float(lg[a]), 6), "logit_speculative": round(float(lg[b]), 6),
+            "gap": round(float(abs(lg[a] - lg[b])), 6)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,7 +116,7 @@ def main():
     ap.add_argument("--p-split", type=float, default=0.9)
     ap.add_argument("--n-ctx", type=int, default=1024)
     ap.add_argument("--signal", type=float, default=float(os.environ.get("PIPEINFER_SIGNAL", "1.0")))
-    ap.add_argument("--noise", type=float, default=float(os.environ.get("PIPEINFER_NOISE", "1.0")))
+    ap.add_argument("--noise", type=float, default=float(os.environ.get("PIPEINFER_NOISE", "0.85")))
     ap.add_argument("--cache", default=os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
@@ -146,6 +160,7 @@ def main():
     ref_tokens, _ = generation(0, mode=2)
     spec_tokens, _ = generation(0)
     lossless = ref_tokens[:args.n_predict] == spec_tokens[:args.n_predict]
+    first_diff = None if lossless else lossless_diagnostic(ct, prompts[0], ref_tokens, spec_tokens, args.n_predict)
     for i in range(args.warmup):
         generation(1 + i)
 
@@ -197,7 +212,7 @@ def main():
            "acceptance": {"accepted_draft_tokens": acc_clean, "drafted_tokens": drafted, "rate": round(acc_clean / max(1, drafted), 4),
                           "reference_formula_pct": round(acc_ref, 2), "spec_runs": sum(r["n_runs_spec"] for r in results),
                           "canceled_runs": sum(r["n_runs_canceled"] for r in results)},
-           "lossless_vs_target_only": bool(lossless), "ttft_s": round(float(np.mean([r["ttft_s"] for r in results])), 5),
+           "lossless_vs_target_only": bool(lossless), "first_difference": first_diff, "ttft_s": round(float(np.mean([r["ttft_s"] for r in results])), 5),
            "itl_s": round(float(np.mean([r["itl_s"] for r in results])), 6), "encode_tps": round(float(np.mean([r["encode_tps"] for r in results])), 1),
            "roofline": roofline}
     if not args.no_cpu_baseline:

@@ -359,6 +359,8 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
 bool context_poll_oldest(llama_context * ctx) {
     if (ctx->inflight.empty()) return false;
     if (ctx->remote) return !ctx->inflight.front()->launched || ctx->remote_ops.poll(ctx->remote_ops.user) != 0;
+    static const int64_t dbg_delay_us = getenv("PI_DEBUG_RUN_LATENCY_US") ? atoll(getenv("PI_DEBUG_RUN_LATENCY_US")) : 0;   // tests: pretend every run takes at least this long
+    if (dbg_delay_us > 0 && time_us() - ctx->inflight.front()->t_start_us < dbg_delay_us) return false;
     return hipEventQuery(ctx->inflight.front()->done) == hipSuccess;
 }
 

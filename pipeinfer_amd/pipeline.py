@@ -298,7 +298,7 @@ def stage_loop(links, backend, head, prev, nxt, n_embd, n_vocab, n_batch):
         if not is_first and not skipped:
             links.recv_data(x_in[:n], prev)
         with clock:
-            if (gen, batch_id) in cancelled:
+            if (gen, batch_id) in cancelled and not os.environ.get("PIPEINFER_NO_SKIP"):
                 skipped = True
         res = None
         if not skipped:
@@ -342,7 +342,8 @@ def bench_main(args, rank, world):
     local = int(os.environ.get("LOCAL_RANK", str(rank))) % max(1, torch.cuda.device_count())
     lib = L.load()
     L.check(lib.pi_device_init(local), "pi_device_init")
-    tspec, tft, dspec, dft = B.WORKLOADS[args.workload if args.workload != "7b" else "70b"]
+    # the default workload of N > 1 is BASELINE configs[2] (70B target); PIPEINFER_KEEP_WORKLOAD=1 keeps an explicit --workload 7b
+    tspec, tft, dspec, dft = B.WORKLOADS[args.workload if (args.workload != "7b" or os.environ.get("PIPEINFER_KEEP_WORKLOAD")) else "70b"]
     n_layer = synth.SPECS[tspec][1]
     n_stage = world - 1
     ranges = split_layers(n_layer, n_stage)
@@ -389,7 +390,7 @@ def bench_main(args, rank, world):
         return
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
-                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters)
+                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")))
     rng = np.random.default_rng(0xBEEF)
     prompts = [[int(x) for x in rng.integers(3, mt.n_vocab, args.n_prompt)] for _ in range(args.warmup + args.steps + 1)]
 
@@ -401,6 +402,7 @@ def bench_main(args, rank, world):
     ref_tokens, _ = generation(0, mode=2)
     spec_tokens, _ = generation(0)
     lossless = ref_tokens[:args.n_predict] == spec_tokens[:args.n_predict]
+    first_diff = None if lossless else B.lossless_diagnostic(ct, prompts[0], ref_tokens, spec_tokens, args.n_predict)
     for i in range(args.warmup):
         generation(1 + i)
     L.check(lib.pi_device_sync())
@@ -429,7 +431,7 @@ def bench_main(args, rank, world):
            "acceptance": {"accepted_draft_tokens": acc_clean, "drafted_tokens": drafted, "rate": round(acc_clean / max(1, drafted), 4),
                           "spec_runs": sum(r["n_runs_spec"] for r in results), "canceled_runs": sum(r["n_runs_canceled"] for r in results),
                           "runs_skipped_by_stages": remote.n_skipped},
-           "lossless_vs_target_only": bool(lossless),
+           "lossless_vs_target_only": bool(lossless), "first_difference": first_diff,
            "roofline": {"bound": "hbm", "kernel": "stage forward pass (slowest stage)", "achieved": slow["GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(slow["GBps"] / B.HBM_PEAK_GBS, 4), "traffic": None, "stages": stage_stats},
            "cpu_baseline": None}

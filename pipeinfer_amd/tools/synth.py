@@ -298,6 +298,7 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
     _vocab_kv(w, arch, n_vocab, vocab)
 
     pi = np.random.default_rng(pi_seed).permutation(n_vocab) if structure == "bigram" else None
+    depth_scale = min(1.0, float(np.sqrt((11008.0 * 4096.0 * 32.0) / (float(n_ff) * n_embd * n_layer))))
     emb_cache = {}
 
     def embedding_matrix():
@@ -323,7 +324,10 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
                     mat = np.empty_like(e)
                     mat[pi] = e * np.float32(head_gain / np.sqrt(n_embd))   # logit of pi[t] ~ head_gain*sqrt(n_embd)*cos(h, e_t); unrelated logits ~ N(0, head_gain^2)
                 return (quantizer or quantize_simple)(ttype, mat) if quantizer else quantize_simple(ttype, mat)
-            s = std * (noise if (structure == "bigram" and role == "out") else 1.0)
+            # "bigram": the residual-writing tensors (wo, ffn_down) carry the noise.  What a layer adds to the stream grows like
+            # sqrt(n_ff * n_embd) and accumulates over n_layer, so the knob is normalised to the Llama-2-7B shape (never upwards:
+            # small draft models stay quiet) — the same `noise` then means a similar next-token margin for 7B and 70B targets
+            s = std * (noise * depth_scale if (structure == "bigram" and role == "out") else 1.0)
             if quantizer is not None:
                 return quantizer(ttype, rng.standard_normal((rows, k), dtype=np.float32) * np.float32(s))
             return random_blocks(ttype, n, rng, s)

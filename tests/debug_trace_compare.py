@@ -1,0 +1,90 @@
+"""GPU debug: run the PipeInfer driver on the real 7B-shaped model with the target behind a proxy context; every run's
+metadata block goes to the HIP stage AND to the oracle (CPU restatement), logits are compared bit for bit.  Tells an engine
+bug from the arithmetic's own sensitivity to KV-cell layout when speculative output differs from target-only output."""
+import collections, ctypes as C, os, sys, time
+import numpy as np
+import torch
+assert torch.cuda.is_available(); torch.zeros(1, device="cuda")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pipeinfer_amd import llama as LL, lib as L, pipeline as P
+from tests import oracle_lib as O
+import bench as B
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "7b"
+latency = float(sys.argv[2]) if len(sys.argv) > 2 else 0.008
+n_predict = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+lib = L.load(); L.check(lib.pi_device_init(0))
+tspec, tft, dspec, dft = B.WORKLOADS[wl]
+tgt_path = B.ensure_model("/tmp/pipeinfer_models", tspec, tft, 0x5EED, 1.0, 1.0)
+dft_path = B.ensure_model("/tmp/pipeinfer_models", dspec, dft, 0xD4AF, 1.0, 1.0)
+N_CTX = 1024
+o = O.oracle()
+o.o_set_threads(int(os.environ.get("ORACLE_THREADS", "64")))
+oh = o.o_model_load(tgt_path.encode(), N_CTX, 8)
+assert oh
+
+
+class Both:
+    def __init__(self, stage, n_vocab, check):
+        self.stage, self.n_vocab, self.check = stage, n_vocab, check
+        self.done = collections.OrderedDict(); self.n = 0; self.bad = []
+        self.ops = P.RemoteOps(None, P.START_FN(self._start), P.POLL_FN(self._poll), P.WAIT_FN(self._wait), P.CANCEL_FN(lambda u, b: None))
+
+    def attach(self, ctx):
+        ctx.lib.pipeinfer_context_set_remote.argtypes = [C.c_void_p, C.c_void_p]; ctx.lib.pipeinfer_context_set_remote.restype = None
+        ctx.lib.pipeinfer_context_set_remote(ctx.h, C.byref(self.ops))
+
+    def _start(self, user, run_seq, batch_id, n, meta, nbytes):
+        block = np.frombuffer(C.string_at(meta, (nbytes + 3) // 4 * 4), dtype=np.int32).copy()
+        ids, vals, sums, logits = [np.array(a) for a in self.stage.run(n, block, None, None)]
+        if self.check:
+            words = (N_CTX + 31) // 32
+            tok, pos, dyn = block[:n], block[n:2 * n], block[2 * n:2 * n + 4]
+            kv_head, n_kv = int(dyn[0]), int(dyn[1])
+            bits = block[2 * n + 4:2 * n + 4 + n * words].view(np.uint32).reshape(n, words)
+            vis = np.unpackbits(bits.view(np.uint8).reshape(n, -1), axis=1, bitorder="little")[:, :n_kv]
+            mask = np.where(vis == 1, 0.0, -np.inf).astype(np.float32)
+            want = np.zeros((n, self.n_vocab), np.float32)
+            assert o.o_model_forward(oh, np.ascontiguousarray(tok).ctypes.data, np.ascontiguousarray(pos).ctypes.data, n, kv_head, n_kv, np.ascontiguousarray(mask).ctypes.data, want.ctypes.data) == 0
+            if not np.array_equal(want.view(np.uint32), logits.view(np.uint32)):
+                self.bad.append((self.n, batch_id, n, float(np.abs(want - logits).max())))
+        self.n += 1
+        self.done[run_seq] = (time.time(), n, (ids, vals, sums, logits))
+        return 0
+
+    def _poll(self, user):
+        if not self.done:
+            return 0
+        t0 = next(iter(self.done.values()))[0]
+        return int(time.time() - t0 >= latency)
+
+    def _wait(self, user, run_seq, logits, ids, vals, sums):
+        t0, n, (i8, v8, s, lg) = self.done.pop(run_seq)
+        while time.time() - t0 < latency:
+            pass
+        for dst, a in ((ids, i8), (vals, v8), (sums, s), (logits, lg)):
+            a = np.ascontiguousarray(a); C.memmove(dst, a.ctypes.data, a.nbytes)
+        return 1
+
+
+mt, md = LL.Model(tgt_path), LL.Model(dft_path)
+n_layer = {"7b": 32, "tiny": 3, "70b": 80}[wl]
+stage = P.HipStage(tgt_path, 0, n_layer, True, True, N_CTX, 512)
+rng = np.random.default_rng(0xBEEF)
+prompt = [int(x) for x in rng.integers(3, mt.n_vocab, 32)]
+outs = {}
+for mode, check in ((2, False), (0, True)):
+    ct, cd = LL.Context(mt, n_ctx=N_CTX, n_batch=512), LL.Context(md, n_ctx=N_CTX, n_batch=512)
+    both = Both(stage, mt.n_vocab, check)
+    both.attach(ct)
+    if mode == 0:                                    # the oracle's KV cache has to see the same history: replay the prompt through it
+        pass
+    out, res = LL.speculative(ct, cd, prompt, n_predict=n_predict, n_draft=3, n_parallel=3, p_accept=0.1, p_split=0.9, ignore_eos=1, mode=mode)
+    outs[mode] = [int(x) for x in out[:n_predict]]
+    print("mode", mode, "runs", both.n, "oracle mismatches", len(both.bad), both.bad[:5], {k: res[k] for k in ("n_runs_spec", "n_runs_canceled", "n_accept_clean")})
+    ct.free(); cd.free()
+same = outs[0] == outs[2]
+print("speculative == target-only:", same)
+if not same:
+    bad = next(i for i in range(n_predict) if outs[0][i] != outs[2][i])
+    print("first difference at", bad, outs[2][bad - 2:bad + 2], outs[0][bad - 2:bad + 2])
