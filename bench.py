@@ -90,7 +90,7 @@ def cpu_baseline(tgt_path, n_tokens, n_prompt):
 
 def lossless_diagnostic(ct, prompt, ref_tokens, spec_tokens, n_predict):
     """Speculative and target-only output differ: report where, and how close the call was.  Every run of the engine equals the
-    reference arithmetic bit for bit (tests/debug_trace_compare.py), but that arithmetic depends on the KV-cell layout (attention
+    reference arithmetic bit for bit (tests/trace_compare_worker.py), but that arithmetic depends on the KV-cell layout (attention
     sums run in cell order), and f16 / Q8 re-quantisation amplifies the last-bit differences; on random-weight models a different
     layout can flip a close argmax.  The logits below are those of the common prefix evaluated as one batch."""
     bad = next(i for i in range(n_predict) if ref_tokens[i] != spec_tokens[i])

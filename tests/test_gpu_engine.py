@@ -164,3 +164,18 @@ def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "PIPELINE-OK" in r.stdout
+
+
+@pytest.mark.parametrize("tgt,dft,n_layer", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 3), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 2), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0", 2)])
+def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_layer):
+    """the PipeInfer driver runs with the target behind a proxy context; each run's metadata block (tokens, positions, cells,
+    visibility mask) is executed by the HIP stage AND by the oracle's forward pass on the same cells: logits must agree bit for
+    bit for every run of the generation — accepted, rejected or cancelled (tests/trace_compare_worker.py).  Runs with an
+    artificial run latency so that several speculative runs are in flight and get adopted."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = ":".join([os.path.join(GOLD, tgt + ".gguf"), os.path.join(GOLD, dft + ".gguf"), str(n_layer)])
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "trace_compare_worker.py"), spec, "0.003", "40"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=root, ORACLE_THREADS="4"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]

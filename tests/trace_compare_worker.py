@@ -10,14 +10,19 @@ from pipeinfer_amd import llama as LL, lib as L, pipeline as P
 from tests import oracle_lib as O
 import bench as B
 
+# usage: trace_compare_worker.py <workload | target.gguf:draft.gguf:n_layer> [latency_s] [n_predict]
 wl = sys.argv[1] if len(sys.argv) > 1 else "7b"
 latency = float(sys.argv[2]) if len(sys.argv) > 2 else 0.008
 n_predict = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 lib = L.load(); L.check(lib.pi_device_init(0))
-tspec, tft, dspec, dft = B.WORKLOADS[wl]
-tgt_path = B.ensure_model("/tmp/pipeinfer_models", tspec, tft, 0x5EED, 1.0, 1.0)
-dft_path = B.ensure_model("/tmp/pipeinfer_models", dspec, dft, 0xD4AF, 1.0, 1.0)
-N_CTX = 1024
+if ":" in wl:
+    tgt_path, dft_path, nl = wl.split(":")
+    N_LAYER, N_CTX, N_PROMPT = int(nl), 256, 8
+else:
+    tspec, tft, dspec, dft = B.WORKLOADS[wl]
+    tgt_path = B.ensure_model("/tmp/pipeinfer_models", tspec, tft, 0x5EED, 1.0, 0.85)
+    dft_path = B.ensure_model("/tmp/pipeinfer_models", dspec, dft, 0xD4AF, 1.0, 0.85)
+    N_LAYER, N_CTX, N_PROMPT = {"7b": 32, "tiny": 3, "70b": 80}[wl], 1024, 32
 o = O.oracle()
 o.o_set_threads(int(os.environ.get("ORACLE_THREADS", "64")))
 oh = o.o_model_load(tgt_path.encode(), N_CTX, 8)
@@ -68,18 +73,19 @@ class Both:
 
 
 mt, md = LL.Model(tgt_path), LL.Model(dft_path)
-n_layer = {"7b": 32, "tiny": 3, "70b": 80}[wl]
-stage = P.HipStage(tgt_path, 0, n_layer, True, True, N_CTX, 512)
+n_layer = N_LAYER
+stage = P.HipStage(tgt_path, 0, n_layer, True, True, N_CTX, 64 if N_CTX == 256 else 512)
 rng = np.random.default_rng(0xBEEF)
-prompt = [int(x) for x in rng.integers(3, mt.n_vocab, 32)]
+prompt = [int(x) for x in rng.integers(3, mt.n_vocab, N_PROMPT)]
 outs = {}
 for mode, check in ((2, False), (0, True)):
-    ct, cd = LL.Context(mt, n_ctx=N_CTX, n_batch=512), LL.Context(md, n_ctx=N_CTX, n_batch=512)
+    nb_ = 64 if N_CTX == 256 else 512
+    ct, cd = LL.Context(mt, n_ctx=N_CTX, n_batch=nb_), LL.Context(md, n_ctx=N_CTX, n_batch=nb_)
     both = Both(stage, mt.n_vocab, check)
     both.attach(ct)
     if mode == 0:                                    # the oracle's KV cache has to see the same history: replay the prompt through it
         pass
-    out, res = LL.speculative(ct, cd, prompt, n_predict=n_predict, n_draft=3, n_parallel=3, p_accept=0.1, p_split=0.9, ignore_eos=1, mode=mode)
+    out, res = LL.speculative(ct, cd, prompt, n_predict=n_predict, n_draft=3, n_parallel=3, p_accept=0.05 if N_CTX == 256 else 0.1, p_split=0.9, ignore_eos=1, mode=mode)
     outs[mode] = [int(x) for x in out[:n_predict]]
     print("mode", mode, "runs", both.n, "oracle mismatches", len(both.bad), both.bad[:5], {k: res[k] for k in ("n_runs_spec", "n_runs_canceled", "n_accept_clean")})
     ct.free(); cd.free()
@@ -88,3 +94,5 @@ print("speculative == target-only:", same)
 if not same:
     bad = next(i for i in range(n_predict) if outs[0][i] != outs[2][i])
     print("first difference at", bad, outs[2][bad - 2:bad + 2], outs[0][bad - 2:bad + 2])
+total_bad = len(both.bad)
+print("TRACE-PARITY", "OK" if total_bad == 0 else "FAIL", "spec_runs", res["n_runs_spec"], "accepted", res["n_accept_clean"])
