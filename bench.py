@@ -193,8 +193,17 @@ def main():
     avg_us, avg_bytes, n_s, n_l = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
     lib.pi_kernel_timing_report(12, 1, C.byref(avg_us), C.byref(avg_bytes), C.byref(n_s), C.byref(n_l))
     achieved = (avg_bytes.value / (avg_us.value * 1e-6) / 1e9) if avg_us.value > 0 else 0.0
+    # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): bench.py cannot
+    # run the profiler on itself, so the number comes from profiles/ (same workload, same launches) and says so
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
+        if args.workload == "7b":
+            traffic, traffic_src = pmc["dominant_kernel"]["avg_fetch_bytes_per_launch"], "profiles/r01_pmc_fetch_size.json"
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "k_mmvq_kq<Q4_K,NT=1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_us.value, 3), "alg_bytes_per_launch": round(avg_bytes.value), "launches": int(n_l.value), "sampled": int(n_s.value),
                 "target_decode_call": {"calls": st_t["n_calls"], "gpu_ms_per_call": round(st_t["gpu_ms"] / max(1, st_t["n_calls"]), 4),
                                        "alg_GB_per_call": round(st_t["alg_bytes"] / max(1, st_t["n_calls"]) / 1e9, 4),
