@@ -33,7 +33,6 @@ struct att_args {
     const uint16_t * exp_tab;
     float scale;
     const int32_t * dyn;                                    // optional {kv_head, n_kv} in device memory: lets one captured graph serve every call
-    float * dbg;                                            // test probe: scores (phase 1) and probabilities (phase 2), [2][n_head][n_tok][n_kv]
 };
 
 // x[i] + x[i + n] inside a row of 16 lanes (lanes whose partner is outside read 0 and are not used)
@@ -63,6 +62,18 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     const int n_gqa = g.n_head_kv * HD, n_embd = g.n_head * HD;
     float * S = smem;                                       // [RW][n_kv]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // phase-3 lane mapping, and its first V rows requested now: they depend on nothing, so their HBM latency hides behind
+    // phases 1 and 2 instead of starting a third dependent round trip
+    constexpr int TPC = HD / 8;                              // lanes along the head dimension
+    constexpr int NRG = 256 / (8 * TPC);                     // row groups in the workgroup: 4 (HD 64) or 2 (HD 128)
+    constexpr int RPT = (RW + NRG - 1) / NRG;                // rows per thread
+    const int l = tid & 7, ev = (tid >> 3) % TPC, rg = tid / (8 * TPC);
+    const int np = g.n_kv & ~31;
+    const uint16_t * vbase = g.vc + hk * HD + 8 * ev;
+    uint4 vcur[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int c = 8 * j + l; vcur[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
 
     // ---- phase 1: scores, ggml_vec_dot_f16 order ----
     {
@@ -114,9 +125,6 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         }
     }
     __syncthreads();
-    if (g.dbg) for (int rr = 0; rr < n_rows; rr++) { const int row = row0 + rr, t = row / r, gq = row % r;
-        for (int c = tid; c < g.n_kv; c += 256) g.dbg[((int64_t) (hk * r + gq) * g.n_tok + t) * g.n_kv + c] = S[(size_t) rr * s_stride + c]; }
-
     // ---- phase 2: soft max ----
     for (int rr = 0; rr < n_rows; rr++) {
         float mx = -INFINITY;
@@ -145,20 +153,11 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         const unsigned long long isum = (redu[rr][0] + redu[rr][1]) + (redu[rr][2] + redu[rr][3]);
         const double sum = (double) isum * (1.0 / 16777216.0);
         const float inv = (float) (1.0 / sum);
-        if (g.dbg && tid == 0) { const int row = row0 + rr, t = row / r, gq = row % r; float * d = g.dbg + (int64_t) 2 * g.n_head * g.n_tok * g.n_kv + ((int64_t) (hk * r + gq) * g.n_tok + t) * 4;
-            d[0] = inv; d[1] = (float) (isum >> 24); d[2] = (float) (isum & 0xffffff); d[3] = fmaxf(fmaxf(redf[rr][0], redf[rr][1]), fmaxf(redf[rr][2], redf[rr][3])); }
         for (int c = tid; c < g.n_kv; c += 256) s[c] = pi_h2f(pi_f2h(s[c] * inv));          // P rounded to f16 as the V.P mul_mat does
     }
     __syncthreads();
 
-    if (g.dbg) for (int rr = 0; rr < n_rows; rr++) { const int row = row0 + rr, t = row / r, gq = row % r;
-        for (int c = tid; c < g.n_kv; c += 256) g.dbg[(((int64_t) g.n_head + hk * r + gq) * g.n_tok + t) * g.n_kv + c] = S[(size_t) rr * s_stride + c]; }
     // ---- phase 3: out[row][e] = ggml_vec_dot_f16(n_kv, V[:, e], P[row, :]) ----
-    constexpr int TPC = HD / 8;                              // lanes along the head dimension
-    constexpr int NRG = 256 / (8 * TPC);                     // row groups in the workgroup: 4 (HD 64) or 2 (HD 128)
-    constexpr int RPT = (RW + NRG - 1) / NRG;                // rows per thread
-    const int l = tid & 7, ev = (tid >> 3) % TPC, rg = tid / (8 * TPC);
-    const int np = g.n_kv & ~31;
     float acc[RPT][4][8];
 #pragma unroll
     for (int i = 0; i < RPT; i++)
@@ -166,10 +165,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[i][j][e] = 0.0f;
-    const uint16_t * vbase = g.vc + hk * HD + 8 * ev;
-    uint4 vcur[4], vnxt[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const int c = 8 * j + l; vcur[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
+    uint4 vnxt[4];
     for (int c0 = 0; c0 < np; c0 += 32) {
 #pragma unroll
         for (int j = 0; j < 4; j++) { const int c = c0 + 32 + 8 * j + l; vnxt[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
@@ -247,9 +243,6 @@ extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
     return rc;
 }
 
-static float * g_att_probe = nullptr;
-extern "C" __attribute__((visibility("default"))) void pi_debug_attention_probe(float * dev) { g_att_probe = dev; }
-
 template <int HD>
 static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream) {
     const dim3 grid(g.n_head_kv, (rows + rw - 1) / rw);
@@ -270,7 +263,7 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     g.n_head = n_head; g.n_head_kv = n_head_kv; g.n_tok = n_tok; g.n_kv = n_kv; g.mask_words = (n_kv + 31) / 32;
     g.exp_tab = pi_get_tables().exp_f16;
     g.scale = 1.0f / sqrtf((float) hd);                      // KQ_scale, llama.cpp:5189-5193
-    g.dyn = dyn_dev; g.dbg = g_att_probe;
+    g.dyn = dyn_dev;
     const int rows = n_tok * (n_head / n_head_kv);
     // rows per workgroup: K/V are re-read (from L2) by every chunk of a kv head, so chunks stay as large as the launch can
     // afford while still putting >= ~128 workgroups on the 256 CUs

@@ -1,7 +1,7 @@
 """GPU debug: logits of a k-token batch must equal the logits of the same tokens decoded one by one (same cells)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 from pipeinfer_amd import llama as LL, lib as L
 import bench as B
 lib = L.load(); L.check(lib.pi_device_init(0))

@@ -1,7 +1,7 @@
 """micro-benchmark of the mat-vec kernel per shape (not a test): python tests/perf_mmvq.py"""
 import os, sys, time, ctypes as C
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 from tests import gpu_util as U, oracle_lib as O
 from pipeinfer_amd.tools import synth
 from pipeinfer_amd import lib as L
