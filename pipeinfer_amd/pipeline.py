@@ -352,6 +352,7 @@ def bench_main(args, rank, world):
 
     def stage_file(tag, only):
         path = os.path.join(cache, f"{tspec}-{tft}-bigram-g{args.signal}-n{args.noise}-{tag}of{n_stage}.gguf")
+        made.append(path)
         if not os.path.exists(path):
             t0 = time.time()
             synth.write_model(path + f".tmp{rank}", tspec, tft, seed=0x5EED, structure="bigram", noise=args.noise, signal=args.signal, only=only)
@@ -359,6 +360,7 @@ def bench_main(args, rank, world):
             print(f"[bench rank {rank}] generated {path} in {time.time() - t0:.1f}s", file=sys.stderr)
         return path
 
+    made = []                                       # stage files of THIS split: removed at the end (a 70B target is 41 GB per split)
     n_embd, n_vocab = synth.SPECS[tspec][2], synth.SPECS[tspec][6]
     if rank == 0:
         tgt_path = stage_file("head", lambda name: False)              # header + vocabulary only: the head never reads weights
@@ -387,6 +389,13 @@ def bench_main(args, rank, world):
         t = torch.tensor([stats["gpu_ms"], float(stats["n_calls"]), float(stats["alg_bytes"]), 0.0], dtype=torch.float64)
         dist.gather(t, None, dst=0, group=links.ctrl)
         dist.barrier(group=links.ctrl)
+        backend.close()
+        if not os.environ.get("PIPEINFER_KEEP_STAGE_FILES"):
+            for f in made:
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
         return
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
@@ -414,6 +423,12 @@ def bench_main(args, rank, world):
     gathered = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
     dist.gather(torch.zeros(4, dtype=torch.float64), gathered, dst=0, group=links.ctrl)
     dist.barrier(group=links.ctrl)
+    if not os.environ.get("PIPEINFER_KEEP_STAGE_FILES"):
+        for f in made:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
     n_tok = sum(r["n_predict"] for r in results)
     t_dec = sum(r["t_dec_s"] for r in results)
