@@ -134,6 +134,7 @@ class RemoteTarget:
         self.waiter = threading.Thread(target=self._waiter, daemon=True)
         self.waiter.start()
         self.keep = []                                  # in-flight cancel sends
+        self.sends = collections.deque()                # in-flight run messages (tensors must outlive the sends)
         self.n_started = self.n_results = self.n_skipped = self.n_cancel_msgs = 0
         self.gen = 0                                    # batch ids restart with every generation: cancel notes carry (generation, batch id)
         self.ops = RemoteOps(None, START_FN(self._start), POLL_FN(self._poll), WAIT_FN(self._wait), CANCEL_FN(self._cancel))
@@ -164,8 +165,11 @@ class RemoteTarget:
             arrived = threading.Event()
             self.waitq.put((self.links.irecv_ctrl(buf, self.last, TAG_RESULT), arrived))
             self.pending.append((run_seq, n_tokens, buf, arrived))
-            self.links.send_ctrl(hdr, self.first, TAG_RUN)
-            self.links.send_ctrl(payload, self.first, TAG_RUN)
+            # non-blocking: a gloo send only completes once the first stage has posted the matching receive, i.e. after it has
+            # finished the previous run — the driver must keep drafting meanwhile (messages to one peer keep their order)
+            self.sends.append((dist.isend(hdr, self.first, group=self.links.ctrl, tag=TAG_RUN), dist.isend(payload, self.first, group=self.links.ctrl, tag=TAG_RUN), hdr, payload))
+            while self.sends and self.sends[0][0].is_completed() and self.sends[0][1].is_completed():
+                self.sends.popleft()
             self.n_started += 1
             return 0
         except Exception as e:                          # never let an exception cross the C boundary
@@ -210,6 +214,9 @@ class RemoteTarget:
     def shutdown(self):
         """stops the stage loops (after every started run has been waited for)"""
         assert not self.pending, "runs still in flight"
+        for w1, w2, _, _ in self.sends:
+            w1.wait(); w2.wait()
+        self.sends.clear()
         self.links.send_ctrl(torch.tensor([KIND_SHUTDOWN, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32), self.first, TAG_RUN)
         for r in self.stages:                           # completes the cancel receive every stage keeps posted
             dist.send(torch.tensor([-1, -1], dtype=torch.int32), r, group=self.links.ctrl, tag=TAG_CANCEL)
