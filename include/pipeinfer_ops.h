@@ -72,6 +72,12 @@ PI_API int pi_op_act_quantize(const float * gate_dev, const float * up_dev, int 
 /* out[t][row] = (residual ? residual[t][row] : 0) + W[row] . act[t]      out/residual: f32 [n_tok][ne1] */
 PI_API int pi_op_mul_mat(const pi_weight * w, const void * q8_dev, int n_tok, float * out_dev, const float * residual_dev, void * stream);
 /* up to 3 weights of one type and width applied to the same activations in ONE launch (wq/wk/wv, ffn_up/ffn_gate); same results as separate calls */
+/* attention projections with RoPE and the KV-cache writes as the mat-vec's epilogue (Llama-style RoPE, K-quant weights):
+ *   q16[t][n_head*hd] = f16(rope(Wq.act)),  kc[(kv_head+t)][n_head_kv*hd] = f16(rope(Wk.act)),  vc[(kv_head+t)][..] = f16(Wv.act)
+ * == pi_op_mul_mat x3 + pi_op_rope_kv_store, same bytes.  dyn_dev (optional): {kv_head, n_kv} in device memory, as for pi_op_rope_kv_store. */
+PI_API int pi_op_mul_mat_qkv_rope_ok(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, int neox, int head_dim);
+PI_API int pi_op_mul_mat_qkv_rope(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, const void * q8_dev, int n_tok, const int32_t * pos_dev, const void * rope_table,
+                                  int head_dim, int n_head, int n_head_kv, int kv_head, const int32_t * dyn_dev, uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, void * stream);
 PI_API int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void * q8_dev, int n_tok, float * const * outs_dev, const float * const * residuals_dev, void * stream);
 
 /* RoPE tables as the reference iterates them: cos/sin [n_pos][head_dim/2] f32, built on the host (theta *= theta_scale) */

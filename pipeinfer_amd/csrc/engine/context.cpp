@@ -180,16 +180,21 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             float * q = ctx->qkv, * k = q + (size_t) n_tok * n_embd, * v = k + (size_t) n_tok * n_gqa;
             const int vq = vdt_of(L.wq);
             if (!norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vq, ctx->q8a)) return false;
-            if (vdt_of(L.wk) != vq && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wk), ctx->q8c)) return false;
-            if (vdt_of(L.wv) != vq && vdt_of(L.wv) != vdt_of(L.wk) && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wv), ctx->q8c)) return false;
-            {   // projections of the same type share one launch
-                const pi_weight * ws[3] = { L.wq, L.wk, L.wv };
-                const void * ins[3] = { ctx->q8a, vdt_of(L.wk) == vq ? ctx->q8a : ctx->q8c, vdt_of(L.wv) == vq ? ctx->q8a : ctx->q8c };
-                float * outs[3] = { q, k, v };
-                if (!mul_mat_grouped(3, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
+            if (!getenv("PI_TRACE") && pi_op_mul_mat_qkv_rope_ok(L.wq, L.wk, L.wv, 0, hd)) {
+                // projections, RoPE, f16 rounding and the K/V cache writes in the mat-vec launch(es) themselves
+                OP_OK(pi_op_mul_mat_qkv_rope(L.wq, L.wk, L.wv, ctx->q8a, n_tok, ctx->pos_dev, ctx->rope, hd, hp.n_head, hp.n_head_kv, kv_head, ctx->dyn_dev, ctx->q16, kc, vc, s));
+            } else {
+                if (vdt_of(L.wk) != vq && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wk), ctx->q8c)) return false;
+                if (vdt_of(L.wv) != vq && vdt_of(L.wv) != vdt_of(L.wk) && !norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.wv), ctx->q8c)) return false;
+                {   // projections of the same type share one launch
+                    const pi_weight * ws[3] = { L.wq, L.wk, L.wv };
+                    const void * ins[3] = { ctx->q8a, vdt_of(L.wk) == vq ? ctx->q8a : ctx->q8c, vdt_of(L.wv) == vq ? ctx->q8a : ctx->q8c };
+                    float * outs[3] = { q, k, v };
+                    if (!mul_mat_grouped(3, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
+                }
+                trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
+                OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             }
-            trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
-            OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, s));
             trace(ctx, "att", il, ctx->att, n_embd, n_tok);
             OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));

@@ -32,6 +32,13 @@ struct mmvq_seg {
     const float *   res;        // nullable
     int             M;
     int             wave0;      // first wave (K-quant kernel) of this segment
+    // K-quant kernel, attention projections: where the rows go instead of `out` (pi_op_mul_mat_qkv_rope)
+    //   1  RoPE (pairs 2i, 2i+1), f16, query buffer  dst16[(tok0 + t) * stride16 + row]
+    //   2  RoPE, f16, K cache cell                   dst16[(kv_head + tok0 + t) * stride16 + row]
+    //   3  f16, V cache cell                         dst16[(kv_head + tok0 + t) * stride16 + row]
+    int             store;
+    uint16_t *      dst16;
+    int             stride16;
 };
 struct mmvq_args {
     mmvq_seg seg[MMVQ_MAX_SEG];
@@ -39,6 +46,9 @@ struct mmvq_args {
     const uint8_t * ad;
     const uint8_t * abs_;
     int K, nb;                  // nb: super-blocks (K-quants) or groups of 4 blocks (Q4_0/Q8_0) per row
+    // RoPE + KV-store epilogue (seg.store != 0): positions of the launch's tokens, (cos, sin) table [pos][hd/2][2], {kv_head, n_kv} in device memory
+    const int32_t * pos; const float * rope_cs; const int32_t * dyn;
+    int kv_head, hd, tok0;
 };
 
 static __device__ __forceinline__ int bytes_sub(int v, int c) {            // per-byte v - c for bytes whose result fits int8 (no borrow across bytes)
@@ -302,8 +312,34 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
         }
         const int r = p / NT, t = p % NT;
         if (p < NP && k == 0 && r < rows) {
-            const int64_t o = (int64_t) t * sg.M + row0 + r;
-            sg.out[o] = sg.res ? sg.res[o] + v : v;
+            if (sg.store) xs[p] = v;                                           // RoPE needs the row pair: collect the wave's results first
+            else {
+                const int64_t o = (int64_t) t * sg.M + row0 + r;
+                sg.out[o] = sg.res ? sg.res[o] + v : v;
+            }
+        }
+    }
+    if (sg.store) {
+        // llm_build_kv_store / ggml_rope mode 0 (llama.cpp:3546-3577, ggml.c:11062-11163) as the epilogue of the projection: rows 2i, 2i+1
+        // of a head are neighbours in this wave (R even, row0 multiple of R); the rounding points are those of k_rope_kv
+        wave_lds_sync();
+        const int kvh = g.dyn ? g.dyn[0] : g.kv_head;
+        if (sg.store == 3) {
+            for (int j = lane; j < rows * NT; j += 64) {
+                const int r = j / NT, t = j % NT;
+                sg.dst16[(int64_t) (kvh + g.tok0 + t) * sg.stride16 + row0 + r] = pi_f2h(xs[j]);
+            }
+        } else {
+            for (int j = lane; j < (rows / 2) * NT; j += 64) {
+                const int pr = j / NT, t = j % NT;
+                const float x0 = xs[(2 * pr) * NT + t], x1 = xs[(2 * pr + 1) * NT + t];
+                const int64_t row = row0 + 2 * pr;
+                const int i = (int) (row % g.hd) >> 1;                       // pair index inside the head
+                const float2 cs = *(const float2 *) (g.rope_cs + ((int64_t) g.pos[g.tok0 + t] * (g.hd / 2) + i) * 2);
+                uint16_t * d = sg.dst16 + (int64_t) ((sg.store == 2 ? kvh : 0) + g.tok0 + t) * sg.stride16 + row;
+                d[0] = pi_f2h(x0 * cs.x - x1 * cs.y);
+                d[1] = pi_f2h(x0 * cs.y + x1 * cs.x);
+            }
         }
     }
 }
@@ -441,7 +477,7 @@ extern "C" int pi_kernel_timing_report(int type, int nt, double * avg_us, double
 }
 
 // host-side description of one launch: segments + bytes for the roofline report
-struct mmvq_launch { mmvq_args g; int nseg; int64_t m_total, m_min; double wbytes; bool any_res; };
+struct mmvq_launch { mmvq_args g; int nseg; int64_t m_total, m_min; double wbytes; bool any_res; bool rope = false; };
 
 template <int TYPE, int NT>
 static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
@@ -475,6 +511,7 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         int R = RMAX;
         while (R > 1 && L.m_total / R < 2048) R >>= 1;
         if (r_env) R = r_env < RMAX ? r_env : RMAX;
+        if (L.rope && R < 2) R = 2;                               // the RoPE epilogue needs both rows of a pair in one wave
         int waves = 0;
         for (int i = 0; i < MMVQ_MAX_SEG; i++) {
             if (i < L.nseg) { g.seg[i].wave0 = waves; waves += (g.seg[i].M + R - 1) / R; }
@@ -520,7 +557,10 @@ static int dispatch_nt(mmvq_launch & L, int nt, hipStream_t stream) {
 
 // out[i][t][row] = residual[i][t][row] + vec_dot(W_i[row], act[t]) for n_w (<= 3) weight matrices of the same type and width
 // sharing one quantised activation.  Q4_0/Q8_0 weights are launched one by one.
-extern "C" int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void * q8, int n_tok, float * const * outs, const float * const * ress, void * stream_) {
+// RoPE / KV-store epilogue of a grouped launch: per weight where its rows go (mmvq_seg::store), plus what the epilogue reads
+struct mmvq_rope { int store[MMVQ_MAX_SEG]; uint16_t * dst16[MMVQ_MAX_SEG]; int stride16[MMVQ_MAX_SEG]; const int32_t * pos; const float * cs; const int32_t * dyn; int kv_head, hd; };
+
+static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void * q8, int n_tok, float * const * outs, const float * const * ress, const mmvq_rope * rope, void * stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     if (n_tok <= 0 || n_w <= 0) return 0;
     if (n_w > MMVQ_MAX_SEG) { pi_set_error("pi_op_mul_mat_multi: n_w=%d > %d", n_w, MMVQ_MAX_SEG); return -1; }
@@ -530,7 +570,7 @@ extern "C" int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const 
     for (int i = 1; i < n_w; i++)
         if (ws[i]->type != w0->type || ws[i]->ne0 != w0->ne0) { pi_set_error("pi_op_mul_mat_multi: weights differ in type or width"); return -1; }
     if (vdt == PI_Q8_0 && n_w > 1) {
-        for (int i = 0; i < n_w; i++) { const int rc = pi_op_mul_mat_multi(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, stream_); if (rc) return rc; }
+        for (int i = 0; i < n_w; i++) { const int rc = mul_mat_multi_impl(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, nullptr, stream_); if (rc) return rc; }
         return 0;
     }
     size_t oq, od, ob;
@@ -543,11 +583,15 @@ extern "C" int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const 
         mmvq_launch L;
         L.nseg = n_w; L.m_total = 0; L.m_min = 1 << 30; L.wbytes = 0.0; L.any_res = false;
         L.g.K = (int) K; L.g.nb = (int) nbq;
+        L.g.pos = rope ? rope->pos : nullptr; L.g.rope_cs = rope ? rope->cs : nullptr; L.g.dyn = rope ? rope->dyn : nullptr;
+        L.g.kv_head = rope ? rope->kv_head : 0; L.g.hd = rope ? rope->hd : 2; L.g.tok0 = t0;
+        L.rope = rope != nullptr;
         for (int i = 0; i < n_w; i++) {
             const pi_weight * w = ws[i];
             mmvq_seg & sg = L.g.seg[i];
             sg.p0 = w->p0; sg.p1 = w->p1; sg.p2 = w->p2; sg.M = (int) w->ne1; sg.wave0 = 0;
-            sg.out = outs[i] + (int64_t) t0 * w->ne1;
+            sg.store = rope ? rope->store[i] : 0; sg.dst16 = rope ? rope->dst16[i] : nullptr; sg.stride16 = rope ? rope->stride16[i] : 0;
+            sg.out = outs && outs[i] ? outs[i] + (int64_t) t0 * w->ne1 : nullptr;
             sg.res = ress && ress[i] ? ress[i] + (int64_t) t0 * w->ne1 : nullptr;
             L.m_total += w->ne1; L.wbytes += (double) w->nbytes; L.any_res |= sg.res != nullptr;
         }
@@ -570,6 +614,47 @@ extern "C" int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const 
     return 0;
 }
 
+extern "C" int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void * q8, int n_tok, float * const * outs, const float * const * ress, void * stream) {
+    return mul_mat_multi_impl(n_w, ws, q8, n_tok, outs, ress, nullptr, stream);
+}
+
 extern "C" int pi_op_mul_mat(const pi_weight * w, const void * q8, int n_tok, float * out, const float * res, void * stream) {
-    return pi_op_mul_mat_multi(1, &w, q8, n_tok, &out, &res, stream);
+    return mul_mat_multi_impl(1, &w, q8, n_tok, &out, &res, nullptr, stream);
+}
+
+// 1 when pi_op_mul_mat_qkv_rope applies: Llama-style RoPE (pairs 2i, 2i+1), K-quant projections, even row counts
+extern "C" int pi_op_mul_mat_qkv_rope_ok(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, int neox, int hd) {
+    if (neox || hd % 2 || getenv("PI_NO_ROPE_EPILOGUE")) return 0;
+    const pi_weight * w[3] = { wq, wk, wv };
+    for (int i = 0; i < 3; i++) if (pi_vec_dot_type(w[i]->type) != PI_Q8_K || w[i]->ne1 % 2 || w[i]->ne0 != wq->ne0) return 0;
+    return 1;
+}
+
+struct pi_rope_table_view { float * cs; int n_pos; int head_dim; };          // == pi_rope_table (elementwise.hip)
+
+// q16 = f16(rope(Wq . act)), K cache cells <- f16(rope(Wk . act)), V cache cells <- f16(Wv . act): the attention projections,
+// ggml_rope and llm_build_kv_store (llama.cpp:3546-3577, 4064-4100) with the rotation and the cache writes done by the mat-vec
+// waves themselves (no fp32 q/k/v round trip, no separate launch).  Weights of the same type share a launch.
+extern "C" int pi_op_mul_mat_qkv_rope(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, const void * q8, int n_tok, const int32_t * pos, const void * table_,
+                                      int hd, int n_head, int n_head_kv, int kv_head, const int32_t * dyn_dev, uint16_t * q16, uint16_t * kc, uint16_t * vc, void * stream) {
+    if (!pi_op_mul_mat_qkv_rope_ok(wq, wk, wv, 0, hd)) { pi_set_error("pi_op_mul_mat_qkv_rope: not applicable to these weights"); return -1; }
+    const pi_rope_table_view * tb = (const pi_rope_table_view *) table_;
+    if (tb->head_dim != hd) { pi_set_error("pi_op_mul_mat_qkv_rope: table head_dim %d != %d", tb->head_dim, hd); return -1; }
+    if (wq->ne1 != (int64_t) n_head * hd || wk->ne1 != (int64_t) n_head_kv * hd || wv->ne1 != wk->ne1) { pi_set_error("pi_op_mul_mat_qkv_rope: projection shapes"); return -1; }
+    const pi_weight * ws[3] = { wq, wk, wv };
+    const int store[3] = { 1, 2, 3 };
+    uint16_t * dst[3] = { q16, kc, vc };
+    const int stride[3] = { n_head * hd, n_head_kv * hd, n_head_kv * hd };
+    bool done[3] = { false, false, false };
+    for (int i = 0; i < 3; i++) {
+        if (done[i]) continue;
+        const pi_weight * gw[3]; mmvq_rope r; int ng = 0;
+        r.pos = pos; r.cs = tb->cs; r.dyn = dyn_dev; r.kv_head = kv_head; r.hd = hd;
+        for (int j = i; j < 3; j++)
+            if (!done[j] && ws[j]->type == ws[i]->type) { gw[ng] = ws[j]; r.store[ng] = store[j]; r.dst16[ng] = dst[j]; r.stride16[ng] = stride[j]; ng++; done[j] = true; }
+        for (int j = ng; j < MMVQ_MAX_SEG; j++) { r.store[j] = 0; r.dst16[j] = nullptr; r.stride16[j] = 0; }
+        const int rc = mul_mat_multi_impl(ng, gw, q8, n_tok, nullptr, nullptr, &r, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }

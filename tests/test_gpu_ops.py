@@ -370,3 +370,44 @@ def test_mul_mat_multi_equals_single_launches(gpu, wtype, n_tok):
         assert np.array_equal(a.get(np.float32, (n_tok, m)).view(np.uint32), b.get(np.float32, (n_tok, m)).view(np.uint32))
     for w in ws:
         lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("types", [(O.Q4_K, O.Q4_K, O.Q4_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q5_K, O.Q6_K, O.Q4_K)])
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,kv_head", [(128, 8, 8, 1, 5), (64, 8, 2, 3, 0), (128, 4, 1, 8, 17), (64, 4, 4, 11, 2)])
+def test_qkv_rope_epilogue_equals_separate_launches(gpu, types, hd, n_head, n_head_kv, n_tok, kv_head):
+    """RoPE + f16 rounding + KV-cache writes done by the projection's own waves == mat-vecs into fp32 + pi_op_rope_kv_store"""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    rng = np.random.default_rng(hd + n_tok)
+    k, n_ctx = 512, 40
+    n_embd, n_gqa = n_head * hd, n_head_kv * hd
+    ws = []
+    for t, m in zip(types, (n_embd, n_gqa, n_gqa)):
+        blocks = synth.random_blocks(t, m * k, rng, 0.05)
+        ws.append(lib.pi_weight_upload(t, k, m, blocks.ctypes.data_as(C.c_void_p), None))
+    assert lib.pi_op_mul_mat_qkv_rope_ok(ws[0], ws[1], ws[2], 0, hd) == 1
+    act = rng.standard_normal((n_tok, k)).astype(np.float32)
+    pos = rng.integers(0, 200, n_tok).astype(np.int32)
+    table = lib.pi_rope_table_create(256, hd, 10000.0, 1.0, 0)
+    xd, pd = U.Dev(act), U.Dev(pos)
+    q8 = U.Dev(nbytes=lib.pi_q8_nbytes(O.Q8_K, k, n_tok))
+    L.check(lib.pi_op_quantize(O.Q8_K, xd.ptr, k, n_tok, q8.ptr, None))
+    qf, kf, vf = U.Dev(nbytes=4 * n_tok * n_embd), U.Dev(nbytes=4 * n_tok * n_gqa), U.Dev(nbytes=4 * n_tok * n_gqa)
+    for w, o in zip(ws, (qf, kf, vf)):
+        L.check(lib.pi_op_mul_mat(w, q8.ptr, n_tok, o.ptr, None, None))
+    dyn = U.Dev(np.array([kv_head, 32, n_tok, 0], np.int32))
+    res = []
+    for fused in (False, True):
+        q16 = U.Dev(np.zeros(n_tok * n_embd, np.uint16)); kc = U.Dev(np.zeros(n_ctx * n_gqa, np.uint16)); vc = U.Dev(np.zeros(n_ctx * n_gqa, np.uint16))
+        if fused:
+            L.check(lib.pi_op_mul_mat_qkv_rope(ws[0], ws[1], ws[2], q8.ptr, n_tok, pd.ptr, table, hd, n_head, n_head_kv, -1, dyn.ptr, q16.ptr, kc.ptr, vc.ptr, None))
+        else:
+            L.check(lib.pi_op_rope_kv_store(qf.ptr, kf.ptr, vf.ptr, n_embd, n_gqa, n_gqa, pd.ptr, table, 0, hd, n_head, n_head_kv, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
+        lib.pi_device_sync()
+        res.append((q16.get(np.uint16), kc.get(np.uint16), vc.get(np.uint16)))
+    for a, b, name in zip(res[0], res[1], "qkv"):
+        assert np.array_equal(a, b), name
+    assert res[0][1].any() and res[0][2].any()
+    lib.pi_rope_table_free(table)
+    for w in ws:
+        lib.pi_weight_free(w)
