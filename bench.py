@@ -139,7 +139,8 @@ def main():
     t0 = time.time()
     mt, md = LL.Model(tgt_path), LL.Model(dft_path)
     ct, cd = LL.Context(mt, n_ctx=args.n_ctx, n_batch=512), LL.Context(md, n_ctx=args.n_ctx, n_batch=512)
-    cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "1")))
+    cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "0")))
+    ct.set_priority(int(os.environ.get("PIPEINFER_TARGET_PRIORITY", "0")))
     n_draft_cus = int(os.environ.get("PIPEINFER_DRAFT_CUS", "0"))
     if n_draft_cus > 0 and args.mode == 0:
         cd.set_cu_range(0, n_draft_cus); ct.set_cu_range(n_draft_cus, 256)

@@ -507,7 +507,7 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         // rows per wave: pairs (row, token) share the chain phase (8 per pass) and the activation registers, so more rows
         // amortise them; fewer rows give more waves.  Keep >= ~2048 waves when the matrices allow.  PI_MMVQ_R overrides.
         static const int r_env = getenv("PI_MMVQ_R") ? atoi(getenv("PI_MMVQ_R")) : 0;
-        constexpr int RMAX = NT <= 2 ? 4 : 2;
+        constexpr int RMAX = 2;                                    // measured on the whole decode: 2 rows per wave beats 4 (3.57 vs 3.75 ms per 7B token) although 4 wins on isolated launches
         int R = RMAX;
         while (R > 1 && L.m_total / R < 2048) R >>= 1;
         if (r_env) R = r_env < RMAX ? r_env : RMAX;
