@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--p-split", type=float, default=0.9)
     ap.add_argument("--n-ctx", type=int, default=1024)
     ap.add_argument("--signal", type=float, default=float(os.environ.get("PIPEINFER_SIGNAL", "1.0")))
-    ap.add_argument("--noise", type=float, default=float(os.environ.get("PIPEINFER_NOISE", "0.85")))
+    ap.add_argument("--noise", type=float, default=float(os.environ.get("PIPEINFER_NOISE", "0.8")))
     ap.add_argument("--cache", default=os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)

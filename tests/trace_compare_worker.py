@@ -20,8 +20,8 @@ if ":" in wl:
     N_LAYER, N_CTX, N_PROMPT = int(nl), 256, 8
 else:
     tspec, tft, dspec, dft = B.WORKLOADS[wl]
-    tgt_path = B.ensure_model("/tmp/pipeinfer_models", tspec, tft, 0x5EED, 1.0, 0.85)
-    dft_path = B.ensure_model("/tmp/pipeinfer_models", dspec, dft, 0xD4AF, 1.0, 0.85)
+    tgt_path = B.ensure_model("/tmp/pipeinfer_models", tspec, tft, 0x5EED, 1.0, 0.8)
+    dft_path = B.ensure_model("/tmp/pipeinfer_models", dspec, dft, 0xD4AF, 1.0, 0.8)
     N_LAYER, N_CTX, N_PROMPT = {"7b": 32, "tiny": 3, "70b": 80}[wl], 1024, 32
 o = O.oracle()
 o.o_set_threads(int(os.environ.get("ORACLE_THREADS", "64")))
