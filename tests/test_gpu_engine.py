@@ -179,3 +179,36 @@ def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_lay
                        env=dict(os.environ, PYTHONPATH=root, ORACLE_THREADS="4"))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_full_size_properties_llama_7b(LL, tmp_path_factory):
+    """BASELINE's single-GPU target at full size (Llama-2-7B shapes, Q4_K_M mixture, 4.1 GB of synthetic weights): properties that
+    need no oracle run — a k-token batch gives the same bits as the same tokens decoded one by one (cells contiguous in both), a
+    repeated call gives the same bits (HIP-graph replay included), and removing a speculative branch (seq_rm) restores the logits of
+    the surviving sequence."""
+    import bench as B
+    cache = os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models")
+    path = B.ensure_model(cache, "llama-2-7b", "q4_k_m", 0x5EED, 1.0, 0.8)
+    m = LL.Model(path)
+    rng = np.random.default_rng(5)
+    prompt = [int(x) for x in rng.integers(3, m.n_vocab, 48)]
+    extra = [int(x) for x in rng.integers(3, m.n_vocab, 8)]
+    a, b = LL.Context(m, n_ctx=1024, n_batch=512), LL.Context(m, n_ctx=1024, n_batch=512)
+    la, lb = a.decode(prompt, list(range(48)), [[0]] * 48), b.decode(prompt, list(range(48)), [[0]] * 48)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))                      # determinism, two contexts
+    for k in (1, 3, 8):
+        singles = [a.decode([extra[i]], [48 + i], [[0]])[0] for i in range(k)]
+        batch = b.decode(extra[:k], [48 + i for i in range(k)], [[0]] * k)
+        for i in range(k):
+            assert np.array_equal(singles[i].view(np.uint32), batch[i].view(np.uint32)), (k, i)
+        a.seq_rm(0, 48, -1); b.seq_rm(0, 48, -1)                                        # roll both back to the prompt
+    base = a.decode([extra[0]], [48], [[0]])[0]                                         # cell 48, sequence 0
+    a.seq_rm(0, 48, -1)
+    a.seq_cp(0, 1, 0, 48)                                                               # fork: sequence 1 shares the prompt
+    a.decode([extra[1], extra[2]], [48, 49], [[1], [1]])                               # a speculative branch on sequence 1
+    a.seq_rm(1, 48, -1)                                                                 # rejected: prune it
+    again = a.decode([extra[0]], [48], [[0]])[0]
+    assert np.array_equal(base.view(np.uint32), again.view(np.uint32))
+    for c in (a, b):
+        c.free()
+    m.free()
