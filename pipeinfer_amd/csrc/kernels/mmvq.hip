@@ -428,6 +428,7 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
 //      launch of each kernel instantiation.  Eager launches: samples resolved by pi_kernel_timing_report after a sync.
 //      Captured launches (HIP graphs): the event pair becomes part of the graph and is re-recorded by every replay; the
 //      engine owns the samples of a graph (pi_kt_sink) and folds their elapsed times in after each replay has finished. ----
+#include <hip/hip_ext.h>
 #include <mutex>
 #include <vector>
 #include "kernel_timing.h"
@@ -494,7 +495,9 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         sample = (g_kt_launches[TYPE & 15][NT]++ % g_kt_every) == 0;
         if (sample) { ea = kt_event(); eb = kt_event(); }
     }
-    if (sample) (void) hipEventRecord(ea, stream);
+    // sampled launches go through hipExtLaunchKernelGGL: its start/stop events carry the kernel's own begin/end timestamps (what
+    // rocprofv3 reports as the duration); events recorded around a launch would add the dispatch gap (~3 us) to every sample
+    if (sink) sample = false;                                  // being captured into a graph: no sampling (events of a graph cannot be read back)
     if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
         // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
         const int64_t M = g.seg[0].M;
@@ -502,7 +505,8 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         while (wpb < 4 && M / (8 * wpb * 2) >= 512) wpb *= 2;
         const unsigned grid = (unsigned) ((M + 8 * wpb - 1) / (8 * wpb));
         const size_t lds = (size_t) NT * MMVQ_TILE * (128 + 8);
-        hipLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+        if (sample) hipExtLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
+        else        hipLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
     } else {
         // rows per wave: pairs (row, token) share the chain phase (8 per pass) and the activation registers, so more rows
         // amortise them; fewer rows give more waves.  Keep >= ~2048 waves when the matrices allow.  PI_MMVQ_R overrides.
@@ -523,13 +527,13 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                 constexpr int wpb = RR * NT > 8 ? 2 : 4;
                 const unsigned grid = (unsigned) ((waves + wpb - 1) / wpb);
                 const size_t lds = (size_t) wpb * kq_lds<TYPE, RR * NT>::FLOATS * 4;
-                hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+                if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
+                else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR>), dim3(grid), dim3(64 * wpb), lds, stream, g);
             }
         };
         if (R == 1) go(std::integral_constant<int, 1>{}); else if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
     }
     if (sample) {
-        (void) hipEventRecord(eb, stream);
         // algorithmic bytes of this launch: the weight matrices once + quantised activations + fp32 output (+ residual)
         const double abytes = (double) NT * ((TYPE == PI_Q4_0 || TYPE == PI_Q8_0) ? (double) g.K / 32 * 34 : (double) g.K / 256 * 292);
         const double obytes = (double) NT * L.m_total * 4 * (L.any_res ? 2 : 1);
