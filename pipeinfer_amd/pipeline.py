@@ -32,9 +32,10 @@ import torch
 import torch.distributed as dist
 
 HDR_WORDS = 8
+INLINE_WORDS = 2048                 # run messages are one fixed-size block: header + metadata when it fits (verify batches always do)
 KIND_RUN, KIND_SHUTDOWN = 1, 2
 TAG_RUN, TAG_RESULT, TAG_CANCEL, TAG_ACT = 11, 12, 13, 14
-F_SKIPPED = 1
+F_SKIPPED, F_LONG = 1, 2           # F_LONG: the metadata follows as a second message (prompt-sized batches)
 
 # struct pipeinfer_remote_ops (include/pipeinfer.h)
 START_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t)
@@ -57,6 +58,16 @@ def split_layers(n_layer, n_stage, weights=None):
     lib.pipeinfer_split_layers.restype = None
     lib.pipeinfer_split_layers(n_layer, w, n_stage, out)
     return [(out[2 * i], out[2 * i + 1]) for i in range(n_stage)]
+
+
+def run_message(run_seq, batch_id, n_tokens, words, flags, gen, meta):
+    """header + (when it fits) the metadata block of a run, as one fixed-size int32 message"""
+    msg = torch.zeros(HDR_WORDS + INLINE_WORDS, dtype=torch.int32)
+    long_ = words > INLINE_WORDS
+    msg[:HDR_WORDS] = torch.tensor([KIND_RUN, run_seq, batch_id, n_tokens, words, flags | (F_LONG if long_ else 0), gen, 0], dtype=torch.int32)
+    if not long_:
+        msg[HDR_WORDS:HDR_WORDS + words] = meta[:words]
+    return msg
 
 
 def result_words(n_tokens, n_vocab):
@@ -158,7 +169,7 @@ class RemoteTarget:
         try:
             words = (meta_bytes + 3) // 4
             payload = torch.from_numpy(np.frombuffer(C.string_at(meta, words * 4), dtype=np.int32).copy())
-            hdr = torch.tensor([KIND_RUN, run_seq, batch_id, n_tokens, words, 0, self.gen, 0], dtype=torch.int32)
+            hdr = run_message(run_seq, batch_id, n_tokens, words, 0, self.gen, payload)
             # the receive for this run's result is posted BEFORE the run leaves: the last stage can then always deliver, so a
             # full pipeline drains instead of dead-locking against the head's next (blocking) send
             buf = torch.empty(result_words(n_tokens, self.n_vocab), dtype=torch.float32)
@@ -167,8 +178,10 @@ class RemoteTarget:
             self.pending.append((run_seq, n_tokens, buf, arrived))
             # non-blocking: a gloo send only completes once the first stage has posted the matching receive, i.e. after it has
             # finished the previous run — the driver must keep drafting meanwhile (messages to one peer keep their order)
-            self.sends.append((dist.isend(hdr, self.first, group=self.links.ctrl, tag=TAG_RUN), dist.isend(payload, self.first, group=self.links.ctrl, tag=TAG_RUN), hdr, payload))
-            while self.sends and self.sends[0][0].is_completed() and self.sends[0][1].is_completed():
+            w1 = dist.isend(hdr, self.first, group=self.links.ctrl, tag=TAG_RUN)
+            w2 = dist.isend(payload, self.first, group=self.links.ctrl, tag=TAG_RUN) if words > INLINE_WORDS else None
+            self.sends.append((w1, w2, hdr, payload))
+            while self.sends and self.sends[0][0].is_completed() and (self.sends[0][1] is None or self.sends[0][1].is_completed()):
                 self.sends.popleft()
             self.n_started += 1
             return 0
@@ -215,9 +228,13 @@ class RemoteTarget:
         """stops the stage loops (after every started run has been waited for)"""
         assert not self.pending, "runs still in flight"
         for w1, w2, _, _ in self.sends:
-            w1.wait(); w2.wait()
+            w1.wait()
+            if w2 is not None:
+                w2.wait()
         self.sends.clear()
-        self.links.send_ctrl(torch.tensor([KIND_SHUTDOWN, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32), self.first, TAG_RUN)
+        bye = torch.zeros(HDR_WORDS + INLINE_WORDS, dtype=torch.int32)
+        bye[0] = KIND_SHUTDOWN
+        self.links.send_ctrl(bye, self.first, TAG_RUN)
         for r in self.stages:                           # completes the cancel receive every stage keeps posted
             dist.send(torch.tensor([-1, -1], dtype=torch.int32), r, group=self.links.ctrl, tag=TAG_CANCEL)
         for w, _ in self.keep:
@@ -289,18 +306,21 @@ def stage_loop(links, backend, head, prev, nxt, n_embd, n_vocab, n_batch):
                 cancelled.add((int(cbuf[0]), int(cbuf[1])))
     listener = threading.Thread(target=cancel_listener, daemon=True)
     listener.start()
-    hdr = torch.zeros(HDR_WORDS, dtype=torch.int32)
+    hdr = torch.zeros(HDR_WORDS + INLINE_WORDS, dtype=torch.int32)
     n_runs = n_skipped = 0
     while True:
         links.recv_ctrl(hdr, prev, TAG_RUN)
-        h = hdr.tolist()
+        h = hdr[:HDR_WORDS].tolist()
         if h[0] == KIND_SHUTDOWN:
             if not is_last:
                 links.send_ctrl(hdr, nxt, TAG_RUN)
             break
         _, run_seq, batch_id, n, words, flags, gen = h[:7]
-        meta = torch.empty(words, dtype=torch.int32)
-        links.recv_ctrl(meta, prev, TAG_RUN)
+        if flags & F_LONG:
+            meta = torch.empty(words, dtype=torch.int32)
+            links.recv_ctrl(meta, prev, TAG_RUN)
+        else:
+            meta = hdr[HDR_WORDS:HDR_WORDS + words].clone()
         skipped = bool(flags & F_SKIPPED)
         if not is_first and not skipped:
             links.recv_data(x_in[:n], prev)
@@ -313,15 +333,17 @@ def stage_loop(links, backend, head, prev, nxt, n_embd, n_vocab, n_batch):
             n_runs += 1
         else:
             n_skipped += 1
-        out_hdr = torch.tensor([KIND_RUN, run_seq, batch_id, n, words, F_SKIPPED if skipped else 0, gen, 0], dtype=torch.int32)
         if not is_last:
-            links.send_ctrl(out_hdr, nxt, TAG_RUN)
-            links.send_ctrl(meta, nxt, TAG_RUN)
+            out_msg = run_message(run_seq, batch_id, n, words, F_SKIPPED if skipped else 0, gen, meta)
+            links.send_ctrl(out_msg, nxt, TAG_RUN)
+            if words > INLINE_WORDS:
+                links.send_ctrl(meta, nxt, TAG_RUN)
             if not skipped:
                 links.send_data(x_out[:n], nxt)
         else:
+            out_hdr = np.array([KIND_RUN, run_seq, batch_id, n, words, F_SKIPPED if skipped else 0, gen, 0], np.int32)
             msg = np.zeros(result_words(n, n_vocab), np.float32)            # fixed size per n: the head posted the receive already
-            msg[:HDR_WORDS] = out_hdr.numpy().view(np.float32)
+            msg[:HDR_WORDS] = out_hdr.view(np.float32)
             if not skipped:
                 ids, vals, sums, logits = res
                 o = HDR_WORDS
