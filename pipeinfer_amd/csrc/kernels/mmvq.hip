@@ -208,94 +208,99 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
         int nbt, rpi, r_off, b;
         tile_map(b0, nbt, rpi, r_off, b);
         const bool quad_on = r_off < rpi;
-        if (nb > KQ_TB) tile_load(b0 + KQ_TB, nxt);
-#pragma unroll
-        for (int t0 = 0; t0 < NT; t0 += TG) {                                // token groups: activations stay in registers across rows
-            constexpr int NG_MAX = NT < TG ? NT : TG;
-            kq_act<TYPE> act[NG_MAX];
-#pragma unroll
-            for (int tt = 0; tt < NG_MAX; tt++) if (t0 + tt < NT) kq_load_act<TYPE>(g, (size_t) (t0 + tt) * nb + b0 + b, c, act[tt]);
-#pragma unroll
-            for (int i = 0; i < R; i++) {
-                const int r = r_off + i * rpi;
-                if (i * rpi < rows) {                                        // uniform: some quad still has a row in this step
-                    const bool valid = quad_on && r < rows;
-                    // ---- block-level unpack, shared by this lane's two accumulator lanes ----
-                    int wq[2][8], sc[8], m0 = 0, m1 = 0;
-                    float dx, dminx = 0.0f;
-                    if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
-                        const uint4 hdr = raw[i].hdr;
-                        dx = pi_h2f((uint16_t) (hdr.x & 0xffff)); dminx = pi_h2f((uint16_t) (hdr.x >> 16));
-                        // 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:1446-1453) unpacked four at a time like the reference's utmp[]
-                        const uint32_t scA = hdr.y & 0x3f3f3f3fu, mA = hdr.z & 0x3f3f3f3fu;
-                        const uint32_t scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
-                        const uint32_t mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
-#pragma unroll
-                        for (int j = 0; j < 4; j++) { sc[j] = ub(scA, j); sc[4 + j] = ub(scB, j); }
-                        const uint32_t mw = (c & 2) ? mB : mA;               // this lane is mins lane c: m[2c], m[2c+1]
-                        const int sh = (c & 1) * 16;
-                        m0 = (int) ((mw >> sh) & 0xff); m1 = (int) ((mw >> (sh + 8)) & 0xff);
-                    } else {
-                        dx = pi_h2f((uint16_t) raw[i].d);
-                        const uint32_t s4[4] = { raw[i].hdr.x, raw[i].hdr.y, raw[i].hdr.z, raw[i].hdr.w };
-                        const int hi = c >> 1;                               // k = 2c, 2c+1 share k >> 2
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {                        // j = 4n + g: scale index 8n + 2g + hi
-                            const int idx = 8 * (j >> 2) + 2 * (j & 3);
-                            sc[j] = (int) (int8_t) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xff);
-                        }
-                    }
-                    kq_unpack_w<TYPE>(raw[i].qa, raw[i].h.x, TYPE == PI_Q6_K ? raw[i].h.y : 0u, wq[0]);
-                    kq_unpack_w<TYPE>(raw[i].qb, TYPE == PI_Q6_K ? raw[i].h.z : raw[i].h.y, TYPE == PI_Q6_K ? raw[i].h.w : 0u, wq[1]);
-#pragma unroll
-                    for (int tt = 0; tt < NG_MAX; tt++) {
-                        if (t0 + tt < NT) {
-                            const kq_act<TYPE> & a = act[tt];
-                            int sumi0 = 0, sumi1 = 0;
-#pragma unroll
-                            for (int j = 0; j < 8; j++) { sumi0 += __mul24(sc[j], pi_dot4(wq[0][j], a.y[0][j], 0)); sumi1 += __mul24(sc[j], pi_dot4(wq[1][j], a.y[1][j], 0)); }
-                            const int p = r * NT + t0 + tt;
-                            if (valid) {
-                                *(float2 *) (xs + L::S + p * L::SSTR + b * 8 + 2 * c) = make_float2((float) sumi0, (float) sumi1);
-                                if (c == 0) xs[L::P + p * L::PSTR + b] = a.dy * dx;
+        // the common case — a full tile of 16 blocks, all R rows present — runs without the per-item and per-block guards
+        auto tile_body = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            if (nb > KQ_TB) tile_load(b0 + KQ_TB, nxt);
+    #pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += TG) {                                // token groups: activations stay in registers across rows
+                constexpr int NG_MAX = NT < TG ? NT : TG;
+                kq_act<TYPE> act[NG_MAX];
+    #pragma unroll
+                for (int tt = 0; tt < NG_MAX; tt++) if (t0 + tt < NT) kq_load_act<TYPE>(g, (size_t) (t0 + tt) * nb + b0 + b, c, act[tt]);
+    #pragma unroll
+                for (int i = 0; i < R; i++) {
+                    const int r = r_off + i * rpi;
+                    if (FULL || i * rpi < rows) {                                // uniform: some quad still has a row in this step
+                        const bool valid = FULL || (quad_on && r < rows);
+                        // ---- block-level unpack, shared by this lane's two accumulator lanes ----
+                        int wq[2][8], sc[8], m0 = 0, m1 = 0;
+                        float dx, dminx = 0.0f;
+                        if constexpr (TYPE == PI_Q4_K || TYPE == PI_Q5_K) {
+                            const uint4 hdr = raw[i].hdr;
+                            dx = pi_h2f((uint16_t) (hdr.x & 0xffff)); dminx = pi_h2f((uint16_t) (hdr.x >> 16));
+                            // 6-bit scales/mins (get_scale_min_k4, ggml-quants.c:1446-1453) unpacked four at a time like the reference's utmp[]
+                            const uint32_t scA = hdr.y & 0x3f3f3f3fu, mA = hdr.z & 0x3f3f3f3fu;
+                            const uint32_t scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
+                            const uint32_t mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
+    #pragma unroll
+                            for (int j = 0; j < 4; j++) { sc[j] = ub(scA, j); sc[4 + j] = ub(scB, j); }
+                            const uint32_t mw = (c & 2) ? mB : mA;               // this lane is mins lane c: m[2c], m[2c+1]
+                            const int sh = (c & 1) * 16;
+                            m0 = (int) ((mw >> sh) & 0xff); m1 = (int) ((mw >> (sh + 8)) & 0xff);
+                        } else {
+                            dx = pi_h2f((uint16_t) raw[i].d);
+                            const uint32_t s4[4] = { raw[i].hdr.x, raw[i].hdr.y, raw[i].hdr.z, raw[i].hdr.w };
+                            const int hi = c >> 1;                               // k = 2c, 2c+1 share k >> 2
+    #pragma unroll
+                            for (int j = 0; j < 8; j++) {                        // j = 4n + g: scale index 8n + 2g + hi
+                                const int idx = 8 * (j >> 2) + 2 * (j & 3);
+                                sc[j] = (int) (int8_t) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xff);
                             }
-                            if constexpr (TYPE != PI_Q6_K) {
-                                // mins: prod[c] = m[2c]*(bsums[4c]+bsums[4c+1]) + m[2c+1]*(bsums[4c+2]+bsums[4c+3])
-                                int prod = __mul24(m0, a.bsA) + __mul24(m1, a.bsB);
-                                if constexpr (TYPE == PI_Q4_K) {
-                                    if (valid) xs[L::SM + p * L::MSTR + b * 4 + c] = (float) prod;
-                                } else {
-                                    prod += __shfl_xor(prod, 1, 64); prod += __shfl_xor(prod, 2, 64);
-                                    if (valid && c == 0) xs[L::SM + p * L::PSTR + b] = (float) prod;
+                        }
+                        kq_unpack_w<TYPE>(raw[i].qa, raw[i].h.x, TYPE == PI_Q6_K ? raw[i].h.y : 0u, wq[0]);
+                        kq_unpack_w<TYPE>(raw[i].qb, TYPE == PI_Q6_K ? raw[i].h.z : raw[i].h.y, TYPE == PI_Q6_K ? raw[i].h.w : 0u, wq[1]);
+    #pragma unroll
+                        for (int tt = 0; tt < NG_MAX; tt++) {
+                            if (t0 + tt < NT) {
+                                const kq_act<TYPE> & a = act[tt];
+                                int sumi0 = 0, sumi1 = 0;
+    #pragma unroll
+                                for (int j = 0; j < 8; j++) { sumi0 += __mul24(sc[j], pi_dot4(wq[0][j], a.y[0][j], 0)); sumi1 += __mul24(sc[j], pi_dot4(wq[1][j], a.y[1][j], 0)); }
+                                const int p = r * NT + t0 + tt;
+                                if (valid) {
+                                    *(float2 *) (xs + L::S + p * L::SSTR + b * 8 + 2 * c) = make_float2((float) sumi0, (float) sumi1);
+                                    if (c == 0) xs[L::P + p * L::PSTR + b] = a.dy * dx;
                                 }
-                                if (valid && c == 0) xs[L::PM + p * L::PSTR + b] = -a.dy * dminx;
+                                if constexpr (TYPE != PI_Q6_K) {
+                                    // mins: prod[c] = m[2c]*(bsums[4c]+bsums[4c+1]) + m[2c+1]*(bsums[4c+2]+bsums[4c+3])
+                                    int prod = __mul24(m0, a.bsA) + __mul24(m1, a.bsB);
+                                    if constexpr (TYPE == PI_Q4_K) {
+                                        if (valid) xs[L::SM + p * L::MSTR + b * 4 + c] = (float) prod;
+                                    } else {
+                                        prod += __shfl_xor(prod, 1, 64); prod += __shfl_xor(prod, 2, 64);
+                                        if (valid && c == 0) xs[L::SM + p * L::PSTR + b] = (float) prod;
+                                    }
+                                    if (valid && c == 0) xs[L::PM + p * L::PSTR + b] = -a.dy * dminx;
+                                }
                             }
                         }
                     }
                 }
             }
-        }
-        wave_lds_sync();
-        // ---- ordered part: lane (p, k) extends chain k of pair p by this tile's blocks, in block order ----
-#pragma unroll
-        for (int bb = 0; bb < KQ_TB; bb++) {
-            if (bb < nbt) {
-#pragma unroll
-                for (int ci = 0; ci < NIT; ci++) {
-                    const int p = ci * 8 + s;
-                    if (NP % 8 == 0 || p < NP) {
-                        acc[ci] = fmaf(xs[L::P + p * L::PSTR + bb], xs[L::S + p * L::SSTR + bb * 8 + k], acc[ci]);
-                        if constexpr (TYPE == PI_Q4_K)      accm[ci] = fmaf(xs[L::PM + p * L::PSTR + bb], xs[L::SM + p * L::MSTR + bb * 4 + (k & 3)], accm[ci]);
-                        else if constexpr (TYPE == PI_Q5_K) accm[ci] = accm[ci] + xs[L::PM + p * L::PSTR + bb] * xs[L::SM + p * L::PSTR + bb];   // summs += dmin * hsum (mul, then add)
+            wave_lds_sync();
+            // ---- ordered part: lane (p, k) extends chain k of pair p by this tile's blocks, in block order ----
+    #pragma unroll
+            for (int bb = 0; bb < KQ_TB; bb++) {
+                if (FULL || bb < nbt) {
+    #pragma unroll
+                    for (int ci = 0; ci < NIT; ci++) {
+                        const int p = ci * 8 + s;
+                        if (NP % 8 == 0 || p < NP) {
+                            acc[ci] = fmaf(xs[L::P + p * L::PSTR + bb], xs[L::S + p * L::SSTR + bb * 8 + k], acc[ci]);
+                            if constexpr (TYPE == PI_Q4_K)      accm[ci] = fmaf(xs[L::PM + p * L::PSTR + bb], xs[L::SM + p * L::MSTR + bb * 4 + (k & 3)], accm[ci]);
+                            else if constexpr (TYPE == PI_Q5_K) accm[ci] = accm[ci] + xs[L::PM + p * L::PSTR + bb] * xs[L::SM + p * L::PSTR + bb];   // summs += dmin * hsum (mul, then add)
+                        }
                     }
                 }
             }
-        }
-        wave_lds_sync();
-        if (nb > KQ_TB) {
-#pragma unroll
-            for (int i = 0; i < R; i++) raw[i] = nxt[i];
-        }
+            wave_lds_sync();
+            if (nb > KQ_TB) {
+    #pragma unroll
+                for (int i = 0; i < R; i++) raw[i] = nxt[i];
+            }
+        };
+        if (nbt == KQ_TB && rows == R) tile_body(std::true_type{}); else tile_body(std::false_type{});
     }
     // ---- fold the eight chains of each pair ----
 #pragma unroll
