@@ -206,11 +206,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_mmvq_kq<Q4_K,NT=1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_us.value, 3), "alg_bytes_per_launch": round(avg_bytes.value), "launches": int(n_l.value), "sampled": int(n_s.value),
-                "target_decode_call": {"calls": st_t["n_calls"], "gpu_ms_per_call": round(st_t["gpu_ms"] / max(1, st_t["n_calls"]), 4),
-                                       "alg_GB_per_call": round(st_t["alg_bytes"] / max(1, st_t["n_calls"]) / 1e9, 4),
-                                       "GBps": round(st_t["alg_bytes"] / max(1e-9, st_t["gpu_ms"] * 1e-3) / 1e9, 1)},
-                "draft_decode_call": {"calls": st_d["n_calls"], "gpu_ms_per_call": round(st_d["gpu_ms"] / max(1, st_d["n_calls"]), 4),
-                                      "GBps": round(st_d["alg_bytes"] / max(1e-9, st_d["gpu_ms"] * 1e-3) / 1e9, 1)}}
+                # single-token decode calls only (prompt batches excluded): GPU time between the call's first and last event
+                "target_decode_call": {"calls": st_t["n_calls_1"], "gpu_ms_per_call": round(st_t["gpu_ms_1"] / max(1, st_t["n_calls_1"]), 4),
+                                       "alg_GB_per_call": round(st_t["alg_bytes_1"] / max(1, st_t["n_calls_1"]) / 1e9, 4),
+                                       "GBps": round(st_t["alg_bytes_1"] / max(1e-9, st_t["gpu_ms_1"] * 1e-3) / 1e9, 1)},
+                "draft_decode_call": {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
+                                      "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}}
     lib.pi_kernel_timing(0, 8)
 
     out = {"metric": "accepted tokens/sec + acceptance rate, 70B Q4_K target / 1.1B draft", "value": round(value, 2), "unit": "tokens/s",

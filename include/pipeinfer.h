@@ -64,6 +64,9 @@ struct pipeinfer_stats {
     uint64_t alg_bytes;          /* algorithmic HBM bytes of those calls (SURVEY 8d formula) */
     uint64_t weight_bytes;       /* bytes of this stage's weights resident in HBM */
     uint64_t kv_bytes_per_cell;  /* K+V bytes per cached token for this stage's layers */
+    uint64_t n_calls_1;          /* the same three counters restricted to single-token calls (prompt batches excluded) */
+    double   gpu_ms_1;
+    uint64_t alg_bytes_1;
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
 LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);

@@ -353,6 +353,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         run->launched = ok;
         ctx->stat_calls++;
         ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, n_kv);
+        if (n_tokens == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
     }
     if (ok) ok = hipEventRecord(run->done, ctx->stream) == hipSuccess;
     if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); ctx->pool.push_back(run); return nullptr; }
@@ -398,12 +399,13 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     (void) hipEventRecord(e1, s);
     if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
     float ms = 0.0f;
-    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->stat_gpu_ms += ms;
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n_tokens == 1) ctx->stat_gpu_ms_1 += ms; }
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "stage_run failed"; return -1; }
     const int32_t * h_dyn = (const int32_t *) meta + 2 * n_tokens;
     ctx->stat_calls++;
     ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, h_dyn[1]);
+    if (n_tokens == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, h_dyn[1]); }
     return 0;
 }
 
@@ -431,7 +433,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
             ctx->last_n_tokens = 0;
         }
     }
-    if (run->launched && !ctx->remote) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_gpu_ms += ms; }
+    if (run->launched && !ctx->remote) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n == 1) ctx->stat_gpu_ms_1 += ms; } }
     if (run->launched && run->sink && pi_kt_enabled()) pi_kt_accumulate(run->sink, 1);
     const int64_t dt = time_us() - run->t_start_us;
     if (n == 1) { ctx->t_eval_us += dt; ctx->n_eval++; } else { ctx->t_p_eval_us += dt; ctx->n_p_eval += n; }     // llama.cpp:5807-5815

@@ -114,6 +114,7 @@ struct llama_context {
     int32_t n_eval = 0, n_p_eval = 0, n_sample = 0;
     // roofline accounting
     uint64_t stat_calls = 0; double stat_gpu_ms = 0.0; uint64_t stat_alg_bytes = 0;
+    uint64_t stat_calls_1 = 0; double stat_gpu_ms_1 = 0.0; uint64_t stat_alg_bytes_1 = 0;      // single-token calls only (the decode rate)
 
     std::string last_error;
     ~llama_context();

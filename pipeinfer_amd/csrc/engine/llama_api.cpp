@@ -289,10 +289,11 @@ extern "C" int pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_t
 
 extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out) {
     out->n_calls = ctx->stat_calls; out->gpu_ms = ctx->stat_gpu_ms; out->alg_bytes = ctx->stat_alg_bytes;
+    out->n_calls_1 = ctx->stat_calls_1; out->gpu_ms_1 = ctx->stat_gpu_ms_1; out->alg_bytes_1 = ctx->stat_alg_bytes_1;
     out->weight_bytes = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, 1);
     out->kv_bytes_per_cell = (uint64_t) 4 * ctx->model->hparams.n_embd_gqa() * (uint64_t) (ctx->l1 - ctx->l0);
 }
-extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; }
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; }
 
 // ---- stand-alone KV-cell table (host logic tests) ---------------------------------------------------------------------------------
 struct pi_kvcells { pi::kv_cells cells; explicit pi_kvcells(int n) : cells(n) {} };

@@ -415,7 +415,7 @@ def bench_main(args, rank, world):
     if rank != 0:
         st = stage_loop(links, backend, 0, 0 if rank == 1 else rank - 1, None if rank == world - 1 else rank + 1, n_embd, n_vocab, 512)
         stats = backend.stats()
-        t = torch.tensor([stats["gpu_ms"], float(stats["n_calls"]), float(stats["alg_bytes"]), 0.0], dtype=torch.float64)
+        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), 0.0], dtype=torch.float64)    # single-token calls
         dist.gather(t, None, dst=0, group=links.ctrl)
         dist.barrier(group=links.ctrl)
         backend.close()
