@@ -187,7 +187,7 @@ def main():
     # events on its own stream.  Events recorded inside a captured graph cannot be read back on ROCm 7.2, so the sampling
     # pass replays the same decode step kernel by kernel (graphs off) right after the timed region, on the same context.
     ct.set_graphs(0)
-    lib.pi_kernel_timing(1, 4)
+    lib.pi_kernel_timing(1, 5)          # 5 is coprime to the 3- and 4-launch periods of a layer: every launch shape gets sampled
     generation(1 + args.warmup, mode=2, n_predict=min(32, args.n_predict))
     L.check(lib.pi_device_sync())
     ct.set_graphs(1)
