@@ -225,9 +225,46 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
         for (int i = 0; i < nw; i++) s += sh[i];
         return s;
     };
+    // Every thread's elements (4 consecutive values of chunk wave + c * nw) are the same in the statistics pass and in the
+    // quantisation pass: with <= NQ_REG chunks per wave they are loaded ONCE and stay in registers, and the norm weight / bias are
+    // requested together with x, so the kernel has a single dependent round trip to memory instead of three.
+    constexpr int NQ_REG = 4;
+    const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
+    const int per = (int) ((n_pad / 256 + nw - 1) / nw);
+    const bool in_regs = per <= NQ_REG;
+    float4 xr4[NQ_REG], wr4[NQ_REG], br4[NQ_REG];
+    if (in_regs) {
+#pragma unroll
+        for (int cc = 0; cc < NQ_REG; cc++) {
+            const int64_t e0 = ((int64_t) wave + (int64_t) cc * nw) * 256 + lane * 4;
+            const bool in = cc < per && e0 < n;
+            xr4[cc] = in ? *(const float4 *) (xr + e0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            wr4[cc] = in && w ? *(const float4 *) (w + e0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            br4[cc] = in && b ? *(const float4 *) (b + e0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
     float mean = 0.0f;
     double acc = 0.0;
-    if (rms) {
+    if (in_regs) {
+        // same per-thread order as the loops below: elements tid*4 .. +3, then + blockDim*4, ...
+        if (rms) {
+#pragma unroll
+            for (int cc = 0; cc < NQ_REG; cc++) if (cc < per && ((int64_t) wave + (int64_t) cc * nw) * 256 + lane * 4 < n) {
+                const float4 v = xr4[cc]; acc += (double) (v.x * v.x); acc += (double) (v.y * v.y); acc += (double) (v.z * v.z); acc += (double) (v.w * v.w); }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < NQ_REG; cc++) if (cc < per && ((int64_t) wave + (int64_t) cc * nw) * 256 + lane * 4 < n) {
+                const float4 v = xr4[cc]; acc += (double) v.x; acc += (double) v.y; acc += (double) v.z; acc += (double) v.w; }
+            mean = (float) (block_sum(acc) / n);
+            acc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NQ_REG; cc++) if (cc < per && ((int64_t) wave + (int64_t) cc * nw) * 256 + lane * 4 < n) {
+                const float4 v = xr4[cc];
+                const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+                acc += (double) (a0 * a0); acc += (double) (a1 * a1); acc += (double) (a2 * a2); acc += (double) (a3 * a3);
+            }
+        }
+    } else if (rms) {
         for (int i = tid * 4; i < n; i += blockDim.x * 4) { const float4 v = *(const float4 *) (xr + i); acc += (double) (v.x * v.x); acc += (double) (v.y * v.y); acc += (double) (v.z * v.z); acc += (double) (v.w * v.w); }
     } else {
         for (int i = tid * 4; i < n; i += blockDim.x * 4) { const float4 v = *(const float4 *) (xr + i); acc += (double) v.x; acc += (double) v.y; acc += (double) v.z; acc += (double) v.w; }
@@ -241,18 +278,28 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
     }
     const float var = (float) (block_sum(acc) / n);
     const float scale = 1.0f / sqrtf(var + eps);
-    const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
-    for (int64_t c0 = (int64_t) wave * 256; c0 < n_pad; c0 += (int64_t) nw * 256) {          // whole 256-value chunks per wave
+    int cc = 0;
+    for (int64_t c0 = (int64_t) wave * 256; c0 < n_pad; c0 += (int64_t) nw * 256, cc++) {    // whole 256-value chunks per wave
         const int64_t e0 = c0 + lane * 4;
         float ys[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (e0 < n) {
-            const float4 v = *(const float4 *) (xr + e0);
-            const float xv[4] = { v.x, v.y, v.z, v.w };
+            float4 v, wv, bv;
+            if (in_regs) {
+                // register arrays are indexed by a loop counter: select with a compile-time index (dynamic indexing would spill)
+                v = xr4[0]; wv = wr4[0]; bv = br4[0];
+#pragma unroll
+                for (int q = 1; q < NQ_REG; q++) if (cc == q) { v = xr4[q]; wv = wr4[q]; bv = br4[q]; }
+            } else {
+                v = *(const float4 *) (xr + e0);
+                wv = w ? *(const float4 *) (w + e0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                bv = b ? *(const float4 *) (b + e0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            const float xv[4] = { v.x, v.y, v.z, v.w }, ww[4] = { wv.x, wv.y, wv.z, wv.w }, bb[4] = { bv.x, bv.y, bv.z, bv.w };
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float y = (xv[i] - mean) * scale;
-                if (w) y = y * w[e0 + i];
-                if (b) y = y + b[e0 + i];
+                if (w) y = y * ww[i];
+                if (b) y = y + bb[i];
                 ys[i] = y;
             }
             if (yf) *(float4 *) (yf + (int64_t) t * n + e0) = make_float4(ys[0], ys[1], ys[2], ys[3]);
