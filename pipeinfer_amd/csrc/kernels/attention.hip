@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     const int n_rows = min(RW, n_rows_total - row0);
     const int n_gqa = g.n_head_kv * HD, n_embd = g.n_head * HD;
     float * S = smem;                                       // [RW][n_kv]
+    uint32_t * M = (uint32_t *) (smem + (size_t) RW * s_stride);   // [RW][mask_words]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // phase-3 lane mapping, and its first V rows requested now: they depend on nothing, so their HBM latency hides behind
@@ -71,9 +72,23 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     const int l = tid & 7, ev = (tid >> 3) % TPC, rg = tid / (8 * TPC);
     const int np = g.n_kv & ~31;
     const uint16_t * vbase = g.vc + hk * HD + 8 * ev;
-    uint4 vcur[4];
+    constexpr int PD = RW <= 2 ? 4 : 2;                      // 32-cell steps of V in flight
+    uint4 vb[PD][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const int c = 8 * j + l; vcur[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
+    for (int d = 0; d < PD; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int c = 32 * d + 8 * j + l; vb[d][j] = *(const uint4 *) (vbase + (int64_t) (c < np ? c : 0) * n_gqa); }
+
+    // the n_kv % 32 leftover cells of phase 3 are summed sequentially in double (ggml_vec_dot_f16's tail loop): one dim per lane,
+    // all of them requested now so that the tail costs arithmetic only
+    constexpr int NTAIL = 31;
+    const int n_tail = g.n_kv - np;
+    uint16_t vt[NTAIL];
+    if (n_tail > 0 && rg < n_rows) {
+        const uint16_t * vtb = g.vc + hk * HD + 8 * ev + l;
+#pragma unroll
+        for (int i = 0; i < NTAIL; i++) vt[i] = vtb[(int64_t) min(np + i, g.n_kv - 1) * n_gqa];
+    }
 
     // ---- phase 1: scores, ggml_vec_dot_f16 order ----
     {
@@ -87,44 +102,67 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
 #pragma unroll
             for (int st = 0; st < NS; st++) { q[rr][2 * st] = pi_h2f(qp[32 * st + a]); q[rr][2 * st + 1] = pi_h2f(qp[32 * st + 16 + a]); }
         }
-        constexpr int U = 4;                                // cells in flight per 16-lane group
-        for (int c0 = 0; c0 < g.n_kv; c0 += 16 * U) {
-            uint16_t kr[U][2 * NS];
+        constexpr int U = 4;                                // cells per 16-lane group and step; two steps are in flight
+        uint16_t kr[2][U][2 * NS];
+        auto load_k = [&](int c0, uint16_t (&dst)[U][2 * NS]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int c = c0 + 16 * u + wv * 4 + cg, cc = c < g.n_kv ? c : g.n_kv - 1;
                 const uint16_t * kp = g.kc + (int64_t) cc * n_gqa + hk * HD;
 #pragma unroll
-                for (int st = 0; st < NS; st++) { kr[u][2 * st] = kp[32 * st + a]; kr[u][2 * st + 1] = kp[32 * st + 16 + a]; }
+                for (int st = 0; st < NS; st++) { dst[u][2 * st] = kp[32 * st + a]; dst[u][2 * st + 1] = kp[32 * st + 16 + a]; }
             }
+        };
+        auto score = [&](int c0, const uint16_t (&src)[U][2 * NS]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int c = c0 + 16 * u + wv * 4 + cg;
                 float kf[2 * NS];
 #pragma unroll
-                for (int i = 0; i < 2 * NS; i++) kf[i] = pi_h2f(kr[u][i]);
+                for (int i = 0; i < 2 * NS; i++) kf[i] = pi_h2f(src[u][i]);
 #pragma unroll
-                for (int rr = 0; rr < RW; rr++) {
-                    if (rr < n_rows) {
-                        float x0 = 0.0f, x1 = 0.0f;
+                for (int rr = 0; rr < RW; rr++) {            // rows past n_rows are computed on row 0's q and not stored: no branch in the loop
+                    float x0 = 0.0f, x1 = 0.0f;
 #pragma unroll
-                        for (int st = 0; st < NS; st++) { x0 = fmaf(kf[2 * st], q[rr][2 * st], x0); x1 = fmaf(kf[2 * st + 1], q[rr][2 * st + 1], x1); }
-                        float x = x0 + x1;                  // s[l] += s[16+l], s[8+l] += s[24+l]
-                        x = dpp_add<0x108>(x);              // s[l] += s[8+l]                      row_shl:8
-                        x = dpp_add<0x104>(x);              // t[l] = s[l] + s[l+4]                row_shl:4
-                        x = dpp_add<0xB1>(x);               // t0+t1, t2+t3                        quad_perm [1,0,3,2]
-                        x = dpp_add<0x4E>(x);               // (t0+t1) + (t2+t3)                   quad_perm [2,3,0,1]
-                        if (a == 0 && c < g.n_kv) {
-                            const int t = (row0 + rr) / r;
-                            const bool vis = (g.mask[(int64_t) t * g.mask_words + (c >> 5)] >> (c & 31)) & 1;
-                            S[(size_t) rr * s_stride + c] = vis ? x * g.scale : -INFINITY;
-                        }
+                    for (int st = 0; st < NS; st++) { x0 = fmaf(kf[2 * st], q[rr][2 * st], x0); x1 = fmaf(kf[2 * st + 1], q[rr][2 * st + 1], x1); }
+                    float x = x0 + x1;                      // s[l] += s[16+l], s[8+l] += s[24+l]
+                    x = dpp_add<0x108>(x);                  // s[l] += s[8+l]                      row_shl:8
+                    x = dpp_add<0x104>(x);                  // t[l] = s[l] + s[l+4]                row_shl:4
+                    x = dpp_add<0xB1>(x);                   // t0+t1, t2+t3                        quad_perm [1,0,3,2]
+                    x = dpp_add<0x4E>(x);                   // (t0+t1) + (t2+t3)                   quad_perm [2,3,0,1]
+                    if (a == 0 && c < g.n_kv && rr < n_rows) {
+                        const bool vis = (M[rr * g.mask_words + (c >> 5)] >> (c & 31)) & 1;
+                        S[(size_t) rr * s_stride + c] = vis ? x * g.scale : -INFINITY;
                     }
                 }
             }
+        };
+        load_k(0, kr[0]);
+        // visibility words of this workgroup's rows go to LDS once (a global load inside the scoring loop would put its latency
+        // on every step); the K loads above are already in flight
+        for (int i = tid; i < n_rows * g.mask_words; i += 256) {
+            const int rr = i / g.mask_words, w = i - rr * g.mask_words;
+            M[rr * g.mask_words + w] = g.mask[(int64_t) ((row0 + rr) / r) * g.mask_words + w];
+        }
+        __syncthreads();
+        int c0 = 0;
+        for (; c0 + 32 * U <= g.n_kv; c0 += 32 * U) {        // straight-line body (branches would make the wait counts drain every load);
+            load_k(c0 + 16 * U, kr[1]);                      // a load past the end re-reads the last cell
+            score(c0, kr[0]);
+            load_k(c0 + 32 * U, kr[0]);
+            score(c0 + 16 * U, kr[1]);
+        }
+        if (c0 < g.n_kv) {                                   // at most two more steps
+            const bool two = c0 + 16 * U < g.n_kv;
+            if (two) load_k(c0 + 16 * U, kr[1]);
+            score(c0, kr[0]);
+            if (two) score(c0 + 16 * U, kr[1]);
         }
     }
     __syncthreads();
+#ifdef ATT_STOP_AFTER_P1                                    // tools_dev/README.md: phase timing builds
+    return;
+#endif
     // ---- phase 2: soft max ----
     for (int rr = 0; rr < n_rows; rr++) {
         float mx = -INFINITY;
@@ -157,6 +195,9 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     }
     __syncthreads();
 
+#ifdef ATT_STOP_AFTER_P2
+    return;
+#endif
     // ---- phase 3: out[row][e] = ggml_vec_dot_f16(n_kv, V[:, e], P[row, :]) ----
     float acc[RPT][4][8];
 #pragma unroll
@@ -165,30 +206,39 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[i][j][e] = 0.0f;
-    uint4 vnxt[4];
-    for (int c0 = 0; c0 < np; c0 += 32) {
+    // ring of PD steps with a straight-line loop body: with branches inside, the compiler's wait counts drain every load before
+    // each step; without, PD - 1 steps of loads stay in flight. Loads past np re-read cell 0 and are not used
+    int srow[RPT];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { const int c = c0 + 32 + 8 * j + l; vnxt[j] = *(const uint4 *) (vbase + (int64_t) (c < g.n_kv ? c : 0) * n_gqa); }
+    for (int i = 0; i < RPT; i++) { const int rr = rg + i * NRG; srow[i] = (rr < n_rows ? rr : 0) * s_stride; }
+    auto pv_step = [&](int cb, const uint4 (&vv)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int c = c0 + 8 * j + l;
-            const uint32_t w4[4] = { vcur[j].x, vcur[j].y, vcur[j].z, vcur[j].w };
+            const int c = cb + 8 * j + l;
+            const uint32_t w4[4] = { vv[j].x, vv[j].y, vv[j].z, vv[j].w };
             float vf[8];
 #pragma unroll
             for (int u = 0; u < 4; u++) { vf[2 * u] = pi_h2f((uint16_t) (w4[u] & 0xffff)); vf[2 * u + 1] = pi_h2f((uint16_t) (w4[u] >> 16)); }
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
-                const int rr = rg + i * NRG;
-                if (rr < n_rows) {
-                    const float p = S[(size_t) rr * s_stride + c];
+                const float p = S[srow[i] + c];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) acc[i][j][e] = fmaf(vf[e], p, acc[i][j][e]);
-                }
+                for (int e = 0; e < 8; e++) acc[i][j][e] = fmaf(vf[e], p, acc[i][j][e]);
             }
         }
+    };
+    int c0 = 0;
+    for (; c0 + 32 * PD <= np; c0 += 32 * PD) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) vcur[j] = vnxt[j];
+        for (int d = 0; d < PD; d++) {
+            pv_step(c0 + 32 * d, vb[d]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int cn = c0 + 32 * (d + PD) + 8 * j + l; vb[d][j] = *(const uint4 *) (vbase + (int64_t) (cn < np ? cn : 0) * n_gqa); }
+        }
     }
+#pragma unroll
+    for (int d = 0; d < PD - 1; d++)                          // the last, partial group: its rows are already in the ring
+        if (c0 + 32 * d < np) pv_step(c0 + 32 * d, vb[d]);
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
         const int rr = rg + i * NRG;
@@ -201,29 +251,22 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
             s = s + __shfl_xor(s, 2, 64);                                               // hadd
             res[e] = s;
         }
-        if (rr < n_rows && l == 0) {
+        float mine = res[0];                                                            // every lane of the 8 holds all 8 sums: lane l keeps dim l
+#pragma unroll
+        for (int e = 1; e < 8; e++) mine = l == e ? res[e] : mine;
+        if (rr < n_rows) {
             const int row = row0 + rr, t = row / r, gq = row % r;
-            float * o = g.out + (int64_t) t * n_embd + (hk * r + gq) * HD + 8 * ev;
-            if (np == g.n_kv) {
+            if (n_tail > 0) {
+                double sd = (double) mine;
+                const float * ps = S + (size_t) rr * s_stride + np;
 #pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = res[e];
-            } else {
-                double sd[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) sd[e] = (double) res[e];
-                for (int c = np; c < g.n_kv; c++) {                                     // leftovers, sequential, in double
-                    const float p = S[(size_t) rr * s_stride + c];
-                    const uint4 v = *(const uint4 *) (g.vc + (int64_t) c * n_gqa + hk * HD + 8 * ev);
-                    const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        sd[2 * u]     += (double) (pi_h2f((uint16_t) (w4[u] & 0xffff)) * p);
-                        sd[2 * u + 1] += (double) (pi_h2f((uint16_t) (w4[u] >> 16)) * p);
-                    }
+                for (int i = 0; i < NTAIL; i++) {                                       // straight-line: a select per cell, no register indexing
+                    const double pr = (double) (pi_h2f(vt[i]) * ps[min(i, n_tail - 1)]);
+                    sd = i < n_tail ? sd + pr : sd;
                 }
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = (float) sd[e];
+                mine = (float) sd;
             }
+            g.out[(int64_t) t * n_embd + (hk * r + gq) * HD + 8 * ev + l] = mine;
         }
     }
 }
@@ -234,7 +277,7 @@ template <int HD, int RW> static int att_set_lds(size_t lds) {
     return 0;
 }
 extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
-    const size_t lds = (size_t) ATT_ROWS * n_kv_max * sizeof(float);
+    const size_t lds = (size_t) ATT_ROWS * (n_kv_max + (n_kv_max + 31) / 32) * sizeof(float);
     if (lds > 156 * 1024) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS (> 156 KiB)", n_kv_max, lds); return -1; }
     if (lds <= 60 * 1024) return 0;
     int rc = 0;
@@ -246,7 +289,7 @@ extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
 template <int HD>
 static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream) {
     const dim3 grid(g.n_head_kv, (rows + rw - 1) / rw);
-    const size_t lds = (size_t) rw * g.n_kv * sizeof(float);
+    const size_t lds = (size_t) rw * (g.n_kv + g.mask_words) * sizeof(float);
     switch (rw) {
         case 1: hipLaunchKernelGGL((k_attention<HD, 1>), grid, dim3(256), lds, stream, g); break;
         case 2: hipLaunchKernelGGL((k_attention<HD, 2>), grid, dim3(256), lds, stream, g); break;
@@ -271,7 +314,7 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > 128) rw *= 2;
     static const int rw_env = getenv("PI_ATT_RW") ? atoi(getenv("PI_ATT_RW")) : 0;      // tuning / tests
     if (rw_env == 1 || rw_env == 2 || rw_env == 4 || rw_env == 8) rw = rw_env;
-    if ((size_t) rw * n_kv * sizeof(float) > 156 * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs more than 156 KiB of LDS", n_kv); return -1; }
+    if ((size_t) rw * (n_kv + g.mask_words) * sizeof(float) > 156 * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs more than 156 KiB of LDS", n_kv); return -1; }
     if (hd == 128) att_launch<128>(g, rows, rw, (hipStream_t) stream);
     else if (hd == 64) att_launch<64>(g, rows, rw, (hipStream_t) stream);
     else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }

@@ -126,8 +126,45 @@ def init_links():
         torch.cuda.set_device(local)
         if shared_gpu:
             return Links(ctrl=None, data=None, device=f"cuda:{local}", via_host=True)
-        return Links(ctrl=dist.new_group(backend="gloo"), data=None, device=f"cuda:{local}")
+        links = Links(ctrl=dist.new_group(backend="gloo"), data=None, device=f"cuda:{local}")
+        probe_data_path(links, int(os.environ.get("RANK", "0")), world)
+        return links
     return Links(ctrl=None, data=None, device="cpu")
+
+
+def probe_data_path(links, rank, world, timeout_s=120.0):
+    """one small device tensor down the stage chain 1 -> 2 -> ... -> world-1 before any run: creates the RCCL point-to-point
+    communicators outside the timed region and, if the device path is unusable on this node (exception or no answer), moves
+    every rank to the host-staged path together (the agreement is an all-reduce on the gloo group)"""
+    state = {"ok": True}
+
+    def chain():
+        try:
+            t = torch.full((256,), float(rank), dtype=torch.float32, device=links.device)
+            if rank >= 2:
+                dist.recv(t, rank - 1, group=links.data)
+                if t.is_cuda:
+                    torch.cuda.synchronize()
+                state["ok"] = bool(t[0].item() == float(rank - 1))
+                t.fill_(float(rank))
+            if 1 <= rank < world - 1:
+                dist.send(t, rank + 1, group=links.data)
+                if t.is_cuda:
+                    torch.cuda.synchronize()
+        except Exception as e:                           # noqa: BLE001 - any transport failure means "use the host path"
+            print(f"[pipeline] rank {rank}: device send/recv probe failed ({type(e).__name__}: {e}); staging activations through the host", file=sys.stderr)
+            state["ok"] = False
+
+    th = threading.Thread(target=chain, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        print(f"[pipeline] rank {rank}: device send/recv probe timed out after {timeout_s:.0f} s; staging activations through the host", file=sys.stderr)
+        state["ok"] = False
+    flag = torch.tensor([1 if state["ok"] else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=links.ctrl)
+    if int(flag[0]) == 0:
+        links.via_host = True
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
