@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
     constexpr int NP = R * NT, NIT = (NP + 7) / 8;
     constexpr int TG = 4;                                                    // tokens whose activations are held in registers at once
     using L = kq_lds<TYPE, NP>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index is made a scalar: with it in a VGPR, g.seg[si] turns into per-lane global loads of the kernel arguments — two
+    // dependent memory round trips before the first weight load of every wave
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float * xs = (float *) lds + (size_t) wave * L::FLOATS;
     const int q = lane >> 2, c = lane & 3;                                   // producer role: quad q, accumulator lanes 2c, 2c+1
     const int s = lane >> 3, k = lane & 7;                                   // chain role: pair slot s, accumulator lane k
