@@ -204,22 +204,44 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
             kq_load<TYPE>(sg, (uint32_t) ((row0 + (r < rows ? r : rows - 1)) * nb + (b0 < nb ? b0 : 0) + b), c, raw[i]);
         }
     };
-    kq_raw<TYPE> raw[R], nxt[R];
-    tile_load(0, raw);
-    for (int b0 = 0; b0 < nb; b0 += KQ_TB) {
+    // two tile buffers used alternately (no copy between them: a conditional `raw = nxt` made the compiler move two dwords of the
+    // just-requested tile right behind its loads, i.e. wait for the next tile before touching the current one)
+    // decode widths (NT <= 2) also keep two sets of activations and request a tile's activations BEFORE its weights: vmcnt retires
+    // in order, so the (L2-resident) activations are usable while the weights are still on their way, instead of being requested
+    // only after the weights have arrived — one L2 round trip less on every tile
+    constexpr bool ACT2 = NT <= 2;
+    constexpr int NG_MAX = NT < TG ? NT : TG;
+    auto act_load = [&](int b0, kq_act<TYPE> (&dst)[NG_MAX]) __attribute__((always_inline)) {
+        int nbt, rpi, r_off, b;
+        tile_map(b0, nbt, rpi, r_off, b);
+#pragma unroll
+        for (int tt = 0; tt < NG_MAX; tt++) kq_load_act<TYPE>(g, (size_t) tt * nb + b0 + b, c, dst[tt]);
+    };
+    kq_raw<TYPE> bufA[R], bufB[R];
+    kq_act<TYPE> actA[NG_MAX], actB[NG_MAX];
+    auto tile_step = [&](int b0, kq_raw<TYPE> (&raw)[R], kq_raw<TYPE> (&nxt)[R], kq_act<TYPE> (&actc)[NG_MAX], kq_act<TYPE> (&actn)[NG_MAX], auto pf_tag) __attribute__((always_inline)) {
+        constexpr bool PF = decltype(pf_tag)::value;                          // rows of more than one tile prefetch the next one
         int nbt, rpi, r_off, b;
         tile_map(b0, nbt, rpi, r_off, b);
         const bool quad_on = r_off < rpi;
         // the common case — a full tile of 16 blocks, all R rows present — runs without the per-item and per-block guards
         auto tile_body = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
-            if (nb > KQ_TB) tile_load(b0 + KQ_TB, nxt);
     #pragma unroll
             for (int t0 = 0; t0 < NT; t0 += TG) {                                // token groups: activations stay in registers across rows
-                constexpr int NG_MAX = NT < TG ? NT : TG;
-                kq_act<TYPE> act[NG_MAX];
+                kq_act<TYPE> actl[NG_MAX];                                       // (unused, and removed, when ACT2)
+                if constexpr (!ACT2) {
     #pragma unroll
-                for (int tt = 0; tt < NG_MAX; tt++) if (t0 + tt < NT) kq_load_act<TYPE>(g, (size_t) (t0 + tt) * nb + b0 + b, c, act[tt]);
+                    for (int tt = 0; tt < NG_MAX; tt++) if (t0 + tt < NT) kq_load_act<TYPE>(g, (size_t) (t0 + tt) * nb + b0 + b, c, actl[tt]);
+                } else if constexpr (PF) {
+                    act_load(b0 + KQ_TB < nb ? b0 + KQ_TB : b0, actn);
+                }
+                kq_act<TYPE> (&act)[NG_MAX] = ACT2 ? actc : actl;
+                // the next tile is requested AFTER the (last group's) activations: vmcnt retires in order, so a wait for loads issued
+                // behind the prefetch would also wait for the prefetch
+                // — and unconditionally: a branch here makes the compiler's wait counts assume the worst of both paths (drain all);
+                // the last tile re-requests itself (an L2 hit nobody waits for)
+                if (PF && t0 + TG >= NT) tile_load(b0 + KQ_TB < nb ? b0 + KQ_TB : b0, nxt);
     #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int r = r_off + i * rpi;
@@ -297,12 +319,22 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
                 }
             }
             wave_lds_sync();
-            if (nb > KQ_TB) {
-    #pragma unroll
-                for (int i = 0; i < R; i++) raw[i] = nxt[i];
-            }
         };
         if (nbt == KQ_TB && rows == R) tile_body(std::true_type{}); else tile_body(std::false_type{});
+    };
+    // (the first tile is requested inside each branch: requested before it, the two paths want it in different registers and the
+    // multi-tile path starts by waiting for all of it in order to copy it)
+    if (nb <= KQ_TB) {
+        if constexpr (ACT2) act_load(0, actA);
+        tile_load(0, bufA);
+        tile_step(0, bufA, bufB, actA, actB, std::false_type{});
+    } else {
+        if constexpr (ACT2) act_load(0, actA);
+        tile_load(0, bufA);
+        for (int b0 = 0; b0 < nb; b0 += 2 * KQ_TB) {
+            tile_step(b0, bufA, bufB, actA, actB, std::true_type{});
+            if (b0 + KQ_TB < nb) tile_step(b0 + KQ_TB, bufB, bufA, actB, actA, std::true_type{});
+        }
     }
     // ---- fold the eight chains of each pair ----
 #pragma unroll
