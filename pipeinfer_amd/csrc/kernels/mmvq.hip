@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
     // in order, so the (L2-resident) activations are usable while the weights are still on their way, instead of being requested
     // only after the weights have arrived — one L2 round trip less on every tile
     constexpr bool ACT2 = NT <= 2;
+    constexpr bool WIDE = NT >= 7;
     constexpr int NG_MAX = NT < TG ? NT : TG;
     auto act_load = [&](int b0, kq_act<TYPE> (&dst)[NG_MAX]) __attribute__((always_inline)) {
         int nbt, rpi, r_off, b;
@@ -227,6 +228,7 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
         // the common case — a full tile of 16 blocks, all R rows present — runs without the per-item and per-block guards
         auto tile_body = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            if constexpr (WIDE) { if (nb > KQ_TB) tile_load(b0 + KQ_TB, nxt); }   // wide batches: next tile first, one code instance (below)
     #pragma unroll
             for (int t0 = 0; t0 < NT; t0 += TG) {                                // token groups: activations stay in registers across rows
                 kq_act<TYPE> actl[NG_MAX];                                       // (unused, and removed, when ACT2)
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
                 // behind the prefetch would also wait for the prefetch
                 // — and unconditionally: a branch here makes the compiler's wait counts assume the worst of both paths (drain all);
                 // the last tile re-requests itself (an L2 hit nobody waits for)
-                if (PF && t0 + TG >= NT) tile_load(b0 + KQ_TB < nb ? b0 + KQ_TB : b0, nxt);
+                if (PF && !WIDE && t0 + TG >= NT) tile_load(b0 + KQ_TB < nb ? b0 + KQ_TB : b0, nxt);
     #pragma unroll
                 for (int i = 0; i < R; i++) {
                     const int r = r_off + i * rpi;
@@ -324,7 +326,18 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
     };
     // (the first tile is requested inside each branch: requested before it, the two paths want it in different registers and the
     // multi-tile path starts by waiting for all of it in order to copy it)
-    if (nb <= KQ_TB) {
+    if constexpr (WIDE) {
+        // NT >= 7 is VALU-bound and at the register limit: the three step instances of the scheme below cost it a wave of occupancy
+        // (256 VGPRs), so it keeps one instance with a copy between the two buffers
+        tile_load(0, bufA);
+        for (int b0 = 0; b0 < nb; b0 += KQ_TB) {
+            tile_step(b0, bufA, bufB, actA, actB, std::false_type{});
+            if (nb > KQ_TB) {
+#pragma unroll
+                for (int i = 0; i < R; i++) bufA[i] = bufB[i];
+            }
+        }
+    } else if (nb <= KQ_TB) {
         if constexpr (ACT2) act_load(0, actA);
         tile_load(0, bufA);
         tile_step(0, bufA, bufB, actA, actB, std::false_type{});
