@@ -163,8 +163,11 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
     }
 }
 
-template <int TYPE, int NT, int R>
-__global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
+// ST = 1: instance for rows of a single tile (K <= 4096) at decode width — without the tile loop and its second buffers it fits
+// 128 VGPRs = 4 waves per SIMD, and the bytes in flight per CU are what a single-round launch lives on
+template <int TYPE, int NT, int R, int ST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ST ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
+    static_assert(ST == 0 || NT == 1, "the single-tile instance exists for decode only");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NP = R * NT, NIT = (NP + 7) / 8;
     constexpr int TG = 4;                                                    // tokens whose activations are held in registers at once
@@ -337,11 +340,11 @@ __global__ void __launch_bounds__(256) k_mmvq_kq(const mmvq_args g) {
                 for (int i = 0; i < R; i++) bufA[i] = bufB[i];
             }
         }
-    } else if (nb <= KQ_TB) {
+    } else if (ST || nb <= KQ_TB) {
         if constexpr (ACT2) act_load(0, actA);
         tile_load(0, bufA);
         tile_step(0, bufA, bufB, actA, actB, std::false_type{});
-    } else {
+    } else if constexpr (!ST) {
         if constexpr (ACT2) act_load(0, actA);
         tile_load(0, bufA);
         for (int b0 = 0; b0 < nb; b0 += 2 * KQ_TB) {
@@ -579,8 +582,15 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                 constexpr int wpb = RR * NT > 8 ? 2 : 4;
                 const unsigned grid = (unsigned) ((waves + wpb - 1) / wpb);
                 const size_t lds = (size_t) wpb * kq_lds<TYPE, RR * NT>::FLOATS * 4;
-                if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
-                else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+                if constexpr (NT == 1) {
+                    if (g.nb <= KQ_TB) {
+                        if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 1>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
+                        else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 1>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+                        return;
+                    }
+                }
+                if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 0>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
+                else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 0>), dim3(grid), dim3(64 * wpb), lds, stream, g);
             }
         };
         if (R == 1) go(std::integral_constant<int, 1>{}); else if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
