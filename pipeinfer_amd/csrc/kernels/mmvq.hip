@@ -165,9 +165,13 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
 
 // ST = 1: instance for rows of a single tile (K <= 4096) at decode width — without the tile loop and its second buffers it fits
 // 128 VGPRs = 4 waves per SIMD, and the bytes in flight per CU are what a single-round launch lives on
+// ST = 2: decode instance for longer rows — "tile per wave": the workgroup is one row group, wave t takes tile t exactly like the
+// single-tile instance (so every tile of the row is in flight at once and nothing loops), the products meet in LDS and wave 0 runs
+// the ordered chains through the tiles in block order
 template <int TYPE, int NT, int R, int ST>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ST ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
-    static_assert(ST == 0 || NT == 1, "the single-tile instance exists for decode only");
+__global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(ST ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
+    static_assert(ST == 0 || NT == 1, "the single-tile / tile-per-wave instances exist for decode only");
+    constexpr bool TPW = ST == 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NP = R * NT, NIT = (NP + 7) / 8;
     constexpr int TG = 4;                                                    // tokens whose activations are held in registers at once
@@ -178,11 +182,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ST ? 4
     float * xs = (float *) lds + (size_t) wave * L::FLOATS;
     const int q = lane >> 2, c = lane & 3;                                   // producer role: quad q, accumulator lanes 2c, 2c+1
     const int s = lane >> 3, k = lane & 7;                                   // chain role: pair slot s, accumulator lane k
-    const int wave_id = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int wave_id = TPW ? (int) blockIdx.x : (int) (blockIdx.x * (blockDim.x >> 6) + wave);   // index of the row group
     const int si = (wave_id >= g.seg[1].wave0) + (wave_id >= g.seg[2].wave0);
     const mmvq_seg & sg = g.seg[si];
     const int64_t row0 = (int64_t) (wave_id - sg.wave0) * R;
-    if (row0 >= sg.M) return;                                                // waves never synchronise with each other
+    if (row0 >= sg.M) return;                                                // waves never synchronise with each other (TPW: the whole group leaves)
     const int nb = g.nb;
     const int rows = sg.M - row0 < R ? (int) (sg.M - row0) : R;
 
@@ -196,6 +200,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ST ? 4
         rpi = nbt == KQ_TB ? 1 : KQ_TB / nbt;                                // rows per step
         r_off = nbt == KQ_TB ? 0 : q / nbt;
         b = nbt == KQ_TB ? q : q - r_off * nbt;
+    };
+    // ---- ordered part: lane (p, k) extends chain k of pair p by a tile's blocks, in block order ----
+    auto chain = [&](const float * xt, int nbt, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int bb = 0; bb < KQ_TB; bb++) {
+            if (FULL || bb < nbt) {
+#pragma unroll
+                for (int ci = 0; ci < NIT; ci++) {
+                    const int p = ci * 8 + s;
+                    if (NP % 8 == 0 || p < NP) {
+                        acc[ci] = fmaf(xt[L::P + p * L::PSTR + bb], xt[L::S + p * L::SSTR + bb * 8 + k], acc[ci]);
+                        if constexpr (TYPE == PI_Q4_K)      accm[ci] = fmaf(xt[L::PM + p * L::PSTR + bb], xt[L::SM + p * L::MSTR + bb * 4 + (k & 3)], accm[ci]);
+                        else if constexpr (TYPE == PI_Q5_K) accm[ci] = accm[ci] + xt[L::PM + p * L::PSTR + bb] * xt[L::SM + p * L::PSTR + bb];   // summs += dmin * hsum (mul, then add)
+                    }
+                }
+            }
+        }
     };
     // every weight load of a tile (R items) is issued before the previous tile is consumed: loads are unconditional, indices clamped
     auto tile_load = [&](int b0, kq_raw<TYPE> * raw) {
@@ -307,29 +329,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ST ? 4
                     }
                 }
             }
-            wave_lds_sync();
-            // ---- ordered part: lane (p, k) extends chain k of pair p by this tile's blocks, in block order ----
-    #pragma unroll
-            for (int bb = 0; bb < KQ_TB; bb++) {
-                if (FULL || bb < nbt) {
-    #pragma unroll
-                    for (int ci = 0; ci < NIT; ci++) {
-                        const int p = ci * 8 + s;
-                        if (NP % 8 == 0 || p < NP) {
-                            acc[ci] = fmaf(xs[L::P + p * L::PSTR + bb], xs[L::S + p * L::SSTR + bb * 8 + k], acc[ci]);
-                            if constexpr (TYPE == PI_Q4_K)      accm[ci] = fmaf(xs[L::PM + p * L::PSTR + bb], xs[L::SM + p * L::MSTR + bb * 4 + (k & 3)], accm[ci]);
-                            else if constexpr (TYPE == PI_Q5_K) accm[ci] = accm[ci] + xs[L::PM + p * L::PSTR + bb] * xs[L::SM + p * L::PSTR + bb];   // summs += dmin * hsum (mul, then add)
-                        }
-                    }
-                }
+            if constexpr (!TPW) {
+                wave_lds_sync();
+                chain(xs, nbt, full_tag);
+                wave_lds_sync();
             }
-            wave_lds_sync();
         };
         if (nbt == KQ_TB && rows == R) tile_body(std::true_type{}); else tile_body(std::false_type{});
     };
     // (the first tile is requested inside each branch: requested before it, the two paths want it in different registers and the
     // multi-tile path starts by waiting for all of it in order to copy it)
-    if constexpr (WIDE) {
+    if constexpr (TPW) {
+        const int b0 = wave * KQ_TB;                                           // the launch has one wave per tile
+        if constexpr (ACT2) act_load(b0, actA);
+        tile_load(b0, bufA);
+        tile_step(b0, bufA, bufB, actA, actB, std::false_type{});
+        __syncthreads();
+        if (wave != 0) return;
+        for (int t = 0, b = 0; b < nb; t++, b += KQ_TB) {
+            const float * xt = (const float *) lds + (size_t) t * L::FLOATS;
+            if (nb - b >= KQ_TB) chain(xt, KQ_TB, std::true_type{}); else chain(xt, nb - b, std::false_type{});
+        }
+    } else if constexpr (WIDE) {
         // NT >= 7 is VALU-bound and at the register limit: the three step instances of the scheme below cost it a wave of occupancy
         // (256 VGPRs), so it keeps one instance with a copy between the two buffers
         tile_load(0, bufA);
@@ -583,6 +604,14 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                 const unsigned grid = (unsigned) ((waves + wpb - 1) / wpb);
                 const size_t lds = (size_t) wpb * kq_lds<TYPE, RR * NT>::FLOATS * 4;
                 if constexpr (NT == 1) {
+                    const int ntiles = (g.nb + KQ_TB - 1) / KQ_TB;
+                    static const bool no_tpw = getenv("PI_MMVQ_NO_TPW") != nullptr;    // tuning / tests
+                    if (ntiles > 1 && ntiles <= 16 && !no_tpw) {
+                        const size_t lds_t = (size_t) ntiles * kq_lds<TYPE, RR * NT>::FLOATS * 4;
+                        if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
+                        else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);
+                        return;
+                    }
                     if (g.nb <= KQ_TB) {
                         if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 1>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
                         else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 1>), dim3(grid), dim3(64 * wpb), lds, stream, g);
