@@ -83,6 +83,7 @@ static __device__ __forceinline__ float hsum8_lanes(float a) {
 // unpack ~ 60 instructions); see DESIGN.md for the count against the HBM rate.
 // ================================================================================================================
 #define KQ_TB 16                // blocks per tile
+#define MMVQ_ST_NT 4            // widest batch that gets the loop-free (single-tile / tile-per-wave) instances
 template <int TYPE> struct kq_raw { uint4 hdr, qa, qb, h; uint32_t d; };     // one lane's share of a block (k = 2c, 2c+1)
 
 template <int TYPE>
@@ -169,8 +170,8 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
 // single-tile instance (so every tile of the row is in flight at once and nothing loops), the products meet in LDS and wave 0 runs
 // the ordered chains through the tiles in block order
 template <int TYPE, int NT, int R, int ST>
-__global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(ST ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
-    static_assert(ST == 0 || NT == 1, "the single-tile / tile-per-wave instances exist for decode only");
+__global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
+    static_assert(ST == 0 || (ST == 1 && NT <= MMVQ_ST_NT) || (ST == 2 && NT <= 2), "loop-free instances: single tile up to MMVQ_ST_NT tokens, tile-per-wave up to 2");
     constexpr bool TPW = ST == 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NP = R * NT, NIT = (NP + 7) / 8;
@@ -603,14 +604,16 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                 constexpr int wpb = RR * NT > 8 ? 2 : 4;
                 const unsigned grid = (unsigned) ((waves + wpb - 1) / wpb);
                 const size_t lds = (size_t) wpb * kq_lds<TYPE, RR * NT>::FLOATS * 4;
-                if constexpr (NT == 1) {
+                if constexpr (NT <= MMVQ_ST_NT) {
                     const int ntiles = (g.nb + KQ_TB - 1) / KQ_TB;
                     static const bool no_tpw = getenv("PI_MMVQ_NO_TPW") != nullptr;    // tuning / tests
-                    if (ntiles > 1 && ntiles <= 16 && !no_tpw) {
-                        const size_t lds_t = (size_t) ntiles * kq_lds<TYPE, RR * NT>::FLOATS * 4;
-                        if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
-                        else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);
-                        return;
+                    if constexpr (NT <= 2) {                                           // measured: wider batches are better off in the tile loop
+                        if (ntiles > 1 && ntiles <= 16 && !no_tpw) {
+                            const size_t lds_t = (size_t) ntiles * kq_lds<TYPE, RR * NT>::FLOATS * 4;
+                            if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
+                            else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);
+                            return;
+                        }
                     }
                     if (g.nb <= KQ_TB) {
                         if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 1>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
