@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--cpu-tokens", type=int, default=8)
     ap.add_argument("--mode", type=int, default=0, help="0 PipeInfer, 2 target only")
     ap.add_argument("--min-spec-iters", type=int, default=0)
+    ap.add_argument("--adaptive-window", type=int, default=4, help="accepted tokens without a speculative run before the draft is paused (0: never, the reference behaviour)")
+    ap.add_argument("--adaptive-pause", type=int, default=64, help="tokens the draft sits out once paused (doubles up to 16x while no speculation happens)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,7 +150,7 @@ def main():
     print(f"[bench] models resident in HBM after {time.time() - t0:.1f}s", file=sys.stderr)
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
-                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters)
+                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, adaptive_window=args.adaptive_window, adaptive_pause=args.adaptive_pause)
     rng = np.random.default_rng(0xBEEF)
     prompts = [[int(x) for x in rng.integers(3, mt.n_vocab, args.n_prompt)] for _ in range(args.warmup + args.steps + 1)]
 
@@ -219,10 +221,12 @@ def main():
            "scaling": "strong", "vs_baseline": None, "dtype": "int8 x int4/6 dot, fp32 accumulate (f16 KV)", "data": "synthetic",
            "config": {"workload": f"{tspec} {tft} target + {dspec} {dft} draft on 1xMI355X, two HIP streams (BASELINE configs[1])",
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel,
-                      "p_accept": args.p_accept, "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}"},
+                      "p_accept": args.p_accept, "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}",
+                      "adaptive_draft": {"window": args.adaptive_window, "pause": args.adaptive_pause}},
            "acceptance": {"accepted_draft_tokens": acc_clean, "drafted_tokens": drafted, "rate": round(acc_clean / max(1, drafted), 4),
                           "reference_formula_pct": round(acc_ref, 2), "spec_runs": sum(r["n_runs_spec"] for r in results),
-                          "canceled_runs": sum(r["n_runs_canceled"] for r in results)},
+                          "canceled_runs": sum(r["n_runs_canceled"] for r in results),
+                          "draft_paused_tokens": sum(r["n_draft_paused"] for r in results), "draft_catchups": sum(r["n_draft_catchups"] for r in results)},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff, "ttft_s": round(float(np.mean([r["ttft_s"] for r in results])), 5),
            "itl_s": round(float(np.mean([r["itl_s"] for r in results])), 6), "encode_tps": round(float(np.mean([r["encode_tps"] for r in results])), 1),
            "roofline": roofline}

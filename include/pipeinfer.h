@@ -106,12 +106,19 @@ struct pipeinfer_spec_params {
     int32_t max_inflight;    /* cap on target runs in flight (0 = unlimited, the reference behaviour) */
     int32_t min_spec_iters;  /* speculation iterations to run even when the target is already back (0 = reference behaviour) */
     int32_t verbose;
+    /* our addition (0 = off = the reference's behaviour): when `adaptive_window` accepted tokens in a row passed without a single
+     * speculative run being launched (the draft never got ahead of the target — the normal state when both share one GPU), the
+     * draft model is left alone for `adaptive_pause` tokens (doubling up to 16x while that keeps happening) and then caught up with
+     * one batched decode before speculation is tried again.  Output tokens are unaffected (greedy verification is lossless).
+     * adaptive_window < 0 (tests): pause after every |window| tokens whether or not speculation is happening. */
+    int32_t adaptive_window, adaptive_pause;
 };
 struct pipeinfer_spec_result {
     int32_t n_input, n_predict, n_drafted, n_accept;       /* the reference's counters (speculative.cpp:681-718) */
     int32_t n_accept_clean;                                 /* drafted tokens that ended up in the output */
     int32_t n_drafted_tokens;                               /* drafted tokens sent to the target for verification */
     int32_t n_runs_spec, n_runs_nonspec, n_runs_canceled;
+    int32_t n_draft_paused, n_draft_catchups;              /* adaptive pause: tokens the draft sat out, batched catch-up decodes */
     double  t_enc_s, t_dec_s, ttft_s, itl_s;
     double  decode_tps, encode_tps;
 };

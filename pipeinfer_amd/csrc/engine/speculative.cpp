@@ -261,6 +261,41 @@ struct driver {
         return false;
     }
 
+    // ---- adaptive draft pause (our addition, pipeinfer.h: adaptive_window / adaptive_pause; off by default) ---------------------------
+    // Called once per accepted token.  While the draft is paused its KV cache lags: the accepted tokens are remembered and decoded
+    // in one batch (same cells, same sequence layout as the per-token begin_non_spec_run) right before drafting resumes.
+    int pause_left = 0, pause_len = 0, win_tokens = 0, win_spec0 = 0;
+    std::vector<llama_token> lag_tokens;
+    bool draft_paused() const { return pause_left > 0; }
+    void adaptive_step() {
+        if (P.mode == 2 || P.adaptive_window == 0 || P.adaptive_pause <= 0) return;
+        if (pause_left > 0) { if (--pause_left == 0) { win_tokens = 0; win_spec0 = R.n_runs_spec; } return; }
+        if (P.adaptive_window < 0) {                                       // test hook: pause after every |window| tokens no matter what
+            if (++win_tokens >= -P.adaptive_window) pause_left = P.adaptive_pause;
+            return;
+        }
+        if (R.n_runs_spec != win_spec0) { win_tokens = 0; win_spec0 = R.n_runs_spec; pause_len = 0; return; }     // speculation is happening: keep drafting
+        if (++win_tokens >= P.adaptive_window) {
+            pause_len = pause_len == 0 ? P.adaptive_pause : std::min(pause_len * 2, P.adaptive_pause * 16);
+            pause_left = pause_len;
+        }
+    }
+    bool draft_catch_up() {
+        if (lag_tokens.empty()) return true;
+        const int n = (int) lag_tokens.size(), p0 = n_past_dft - n;
+        pipeinfer_kv_cache_seq_rm_range(dft, 0, max_seq, p0, n_past_dft);
+        const int n_batch = std::max(1, dft->n_batch);
+        for (int i0 = 0; i0 < n; i0 += n_batch) {
+            host_batch b;
+            for (int i = i0; i < std::min(n, i0 + n_batch); i++) b.add(lag_tokens[i], p0 + i, { 0 });
+            if (llama_decode(dft, b.view()) != 0) return false;
+        }
+        pipeinfer_kv_cache_seq_cp_range(dft, 0, 1, max_seq, p0, n_past_dft);
+        lag_tokens.clear();
+        R.n_draft_catchups++;
+        return true;
+    }
+
     // speculative.cpp:765-844.  min_spec_iters > 0 (our addition, default 0 = reference behaviour) runs that many speculation
     // iterations even if the oldest target run has already finished — on one fast GPU the target is often back before the
     // first draft token, and tests need the accept / cancel paths exercised.
@@ -371,7 +406,7 @@ struct driver {
                 spec_past_tgt = n_past_tgt; spec_past_dft = n_past_dft;
                 first_run = true;
             } else if (!tgt_runs.empty()) {
-                if (P.mode == 2) { pi::context_wait(tgt, (pi_run *) tgt_runs.back()->ticket); if (tgt->remote) { while (!llama_mpi_iprobe(tgt)) {} } continue; }      // target only: just wait
+                if (P.mode == 2 || draft_paused()) { pi::context_wait(tgt, (pi_run *) tgt_runs.back()->ticket); if (tgt->remote) { while (!llama_mpi_iprobe(tgt)) {} } continue; }      // target only: just wait
                 run_speculation_loop();
                 continue;
             }
@@ -431,12 +466,17 @@ struct driver {
 
             begin_non_spec_run(tgt, tgt_runs, n_past_tgt);
             if (!has_run_first_token) { has_run_first_token = true; first_token = true; }
-            if (P.mode != 2) {
+            adaptive_step();
+            if (P.mode != 2 && !draft_paused()) {
+                if (!draft_catch_up()) return -2;
                 begin_non_spec_run(dft, dft_runs, n_past_dft);
                 std::shared_ptr<async_run> d = dft_runs.back();
                 dft_runs.pop_back();
                 llama_finish_async_decode(dft, d->batch.view(), d->ticket);
-            } else n_past_dft++;
+            } else {
+                if (P.mode != 2) { lag_tokens.push_back(id); R.n_draft_paused++; }      // the draft sits this token out (caught up later in one batch)
+                n_past_dft++;
+            }
             spec_past_tgt = n_past_tgt; spec_past_dft = n_past_dft;
 
             if (R.n_predict > P.n_predict || has_eos) break;              // (checked here so the last token does not launch more speculation)
@@ -446,7 +486,7 @@ struct driver {
                 current.seq_offset = free_offsets.front();
                 free_offsets.pop_front();
             }
-            if (P.mode != 2) run_speculation_loop();
+            if (P.mode != 2 && !draft_paused()) run_speculation_loop();
         }
         const int64_t t_dec_end = pi::time_us();
 
@@ -469,7 +509,7 @@ extern "C" struct pipeinfer_spec_params pipeinfer_spec_default_params(void) {
     struct pipeinfer_spec_params p;
     memset(&p, 0, sizeof p);
     p.n_predict = 128; p.n_draft = 3; p.n_parallel = 3; p.p_accept = 0.1f; p.p_split = 0.9f; p.p_recovery = 0.0f; p.p_decay = 0.0f;   // dolphin_tinyllama_8_nodes.sh
-    p.temp = -1.0f; p.ignore_eos = 1; p.mode = 0; p.max_inflight = 0; p.verbose = 0;
+    p.temp = -1.0f; p.ignore_eos = 1; p.mode = 0; p.max_inflight = 0; p.verbose = 0; p.adaptive_window = 0; p.adaptive_pause = 0;
     return p;
 }
 

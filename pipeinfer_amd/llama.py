@@ -32,12 +32,14 @@ class llama_context_params(C.Structure):
 class pipeinfer_spec_params(C.Structure):
     _fields_ = [("n_predict", C.c_int32), ("n_draft", C.c_int32), ("n_parallel", C.c_int32), ("p_accept", C.c_float), ("p_split", C.c_float),
                 ("p_recovery", C.c_float), ("p_decay", C.c_float), ("temp", C.c_float), ("ignore_eos", C.c_int32), ("mode", C.c_int32),
-                ("max_inflight", C.c_int32), ("min_spec_iters", C.c_int32), ("verbose", C.c_int32)]
+                ("max_inflight", C.c_int32), ("min_spec_iters", C.c_int32), ("verbose", C.c_int32),
+                ("adaptive_window", C.c_int32), ("adaptive_pause", C.c_int32)]
 
 
 class pipeinfer_spec_result(C.Structure):
     _fields_ = [("n_input", C.c_int32), ("n_predict", C.c_int32), ("n_drafted", C.c_int32), ("n_accept", C.c_int32), ("n_accept_clean", C.c_int32),
                 ("n_drafted_tokens", C.c_int32), ("n_runs_spec", C.c_int32), ("n_runs_nonspec", C.c_int32), ("n_runs_canceled", C.c_int32),
+                ("n_draft_paused", C.c_int32), ("n_draft_catchups", C.c_int32),
                 ("t_enc_s", C.c_double), ("t_dec_s", C.c_double), ("ttft_s", C.c_double), ("itl_s", C.c_double), ("decode_tps", C.c_double), ("encode_tps", C.c_double)]
 
     def as_dict(self):

@@ -465,7 +465,8 @@ def bench_main(args, rank, world):
         return
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
-                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")))
+                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")),
+                adaptive_window=args.adaptive_window, adaptive_pause=args.adaptive_pause)
     rng = np.random.default_rng(0xBEEF)
     prompts = [[int(x) for x in rng.integers(3, mt.n_vocab, args.n_prompt)] for _ in range(args.warmup + args.steps + 1)]
 
@@ -511,6 +512,7 @@ def bench_main(args, rank, world):
                       "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "layer_ranges": [list(r) for r in ranges]},
            "acceptance": {"accepted_draft_tokens": acc_clean, "drafted_tokens": drafted, "rate": round(acc_clean / max(1, drafted), 4),
                           "spec_runs": sum(r["n_runs_spec"] for r in results), "canceled_runs": sum(r["n_runs_canceled"] for r in results),
+                          "draft_paused_tokens": sum(r["n_draft_paused"] for r in results), "draft_catchups": sum(r["n_draft_catchups"] for r in results),
                           "runs_skipped_by_stages": remote.n_skipped},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff,
            "roofline": {"bound": "hbm", "kernel": "stage forward pass (slowest stage)", "achieved": slow["GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s",

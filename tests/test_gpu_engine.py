@@ -130,6 +130,30 @@ def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split
         m.free()
 
 
+@pytest.mark.parametrize("window,pause,min_spec", [(2, 3, 0), (-3, 2, 1), (-2, 5, 2), (1, 1, 0)])
+def test_adaptive_draft_pause_is_lossless_and_the_draft_catches_up(LL, window, pause, min_spec):
+    """pipeinfer.h adaptive_window / adaptive_pause: the draft sits out tokens while speculation is not happening and is caught up with
+    one batched decode.  The output must stay the target's greedy continuation; with an identical draft model and forced pauses
+    (window < 0) in the middle of continuous speculation, drafted tokens must still be accepted after a catch-up — a draft KV cache
+    left out of step would mispredict."""
+    tgt = dft = "tiny_llama_q4_k_m"
+    prompt, want = greedy_reference(tgt, 8, 24)
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    res = {}
+    for name, kw in (("plain", {}), ("paused", dict(adaptive_window=window, adaptive_pause=pause))):
+        ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
+        out, res[name] = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=3, n_parallel=3, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec, **kw)
+        assert out[:24] == want, (name, out, want, res[name])
+        ct.free(); cd.free()
+    assert res["plain"]["n_draft_paused"] == 0 and res["plain"]["n_draft_catchups"] == 0
+    assert res["paused"]["n_draft_paused"] > 0
+    if window < 0:
+        assert res["paused"]["n_draft_catchups"] > 0
+        rate = lambda r: r["n_accept_clean"] / max(1, r["n_drafted_tokens"])
+        assert res["paused"]["n_accept_clean"] > 0 and rate(res["paused"]) >= 0.5 * rate(res["plain"]), res
+    mt.free(); md.free()
+
+
 def test_pipeinfer_driver_lossless_under_timing_jitter(LL):
     """the driver's control flow depends on which run finishes first, so repeat one configuration with fresh contexts
     (this caught target and draft contexts racing on a shared top-k scratch buffer)."""
