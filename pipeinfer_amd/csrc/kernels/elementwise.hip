@@ -480,54 +480,76 @@ extern "C" int pi_op_add(const float * a, const float * b, float * o, int64_t n,
 // stage 1: grid (n_tok, NCH) — each workgroup finds the k best of its slice of the vocabulary and its partial max / sum-exp
 // stage 2: one workgroup per token merges NCH*k candidates (same ordering) and the partial sums.
 #define TOPK_NCH 32
+// (both stages read their values once into registers; the k selection rounds then run on registers and LDS only)
+#define TOPK_VPT 8                                                     // values per thread held in registers by stage 1 (slices up to 2048)
 __global__ void __launch_bounds__(256) k_topk1(const float * __restrict__ logits, int n_vocab, int k, int32_t * __restrict__ cid, float * __restrict__ cval, float * __restrict__ cmax, float * __restrict__ csum) {
-    __shared__ float sv[4]; __shared__ int si[4]; __shared__ float sb; __shared__ int sbi;
+    __shared__ float sv[2][4]; __shared__ int si[2][4];
     const int t = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (n_vocab + TOPK_NCH - 1) / TOPK_NCH, lo = ch * per, hi = min(n_vocab, lo + per);
     const float * l = logits + (int64_t) t * n_vocab;
+    const bool in_regs = per <= 256 * TOPK_VPT;
+    float rv[TOPK_VPT];
+#pragma unroll
+    for (int j = 0; j < TOPK_VPT; j++) { const int i = lo + tid + 256 * j; rv[j] = (in_regs && i < hi) ? l[i] : -INFINITY; }
     float prev_v = INFINITY; int prev_i = -1;
     float first = -INFINITY;
     for (int r = 0; r < k; r++) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = lo + tid; i < hi; i += 256) {
-            const float v = l[i];
-            const bool after = v < prev_v || (v == prev_v && i > prev_i);
-            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < TOPK_VPT; j++) {
+                const int i = lo + tid + 256 * j; const float v = rv[j];
+                const bool after = i < hi && (v < prev_v || (v == prev_v && i > prev_i));
+                if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+            }
+        } else {
+            for (int i = lo + tid; i < hi; i += 256) {
+                const float v = l[i];
+                const bool after = v < prev_v || (v == prev_v && i > prev_i);
+                if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
+        if (lane == 0) { sv[r & 1][wv] = bv; si[r & 1][wv] = bi; }     // double-buffered: one barrier per round
         __syncthreads();
-        if (lane == 0) { sv[wv] = bv; si[wv] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w2 = 1; w2 < 4; w2++) if (sv[w2] > bv || (sv[w2] == bv && si[w2] < bi)) { bv = sv[w2]; bi = si[w2]; }
-            sb = bv; sbi = bi;
-            cid[((int64_t) t * TOPK_NCH + ch) * k + r] = bi; cval[((int64_t) t * TOPK_NCH + ch) * k + r] = bv;
-        }
-        __syncthreads();
-        prev_v = sb; prev_i = sbi;
+        bv = sv[r & 1][0]; bi = si[r & 1][0];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; w2++) { const float ov = sv[r & 1][w2]; const int oi = si[r & 1][w2]; if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
+        if (tid == 0) { cid[((int64_t) t * TOPK_NCH + ch) * k + r] = bi; cval[((int64_t) t * TOPK_NCH + ch) * k + r] = bv; }
+        prev_v = bv; prev_i = bi;
         if (r == 0) first = prev_v;
     }
     float s = 0.0f;
-    for (int i = lo + tid; i < hi; i += 256) s += expf(l[i] - first);
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < TOPK_VPT; j++) { const int i = lo + tid + 256 * j; if (i < hi) s += expf(rv[j] - first); }
+    } else {
+        for (int i = lo + tid; i < hi; i += 256) s += expf(l[i] - first);
+    }
     s = pi_lanes_sum<64>(s);
     __syncthreads();
-    if (lane == 0) sv[wv] = s;
+    if (lane == 0) sv[0][wv] = s;
     __syncthreads();
-    if (tid == 0) { cmax[t * TOPK_NCH + ch] = first; csum[t * TOPK_NCH + ch] = (sv[0] + sv[1]) + (sv[2] + sv[3]); }
+    if (tid == 0) { cmax[t * TOPK_NCH + ch] = first; csum[t * TOPK_NCH + ch] = (sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3]); }
 }
 __global__ void __launch_bounds__(64) k_topk2(int k, const int32_t * __restrict__ cid, const float * __restrict__ cval, const float * __restrict__ cmax, const float * __restrict__ csum,
                                                int32_t * __restrict__ ids, float * __restrict__ vals, float * __restrict__ sumexp) {
     const int t = blockIdx.x, lane = threadIdx.x;
-    const int n = TOPK_NCH * k;
+    const int n = TOPK_NCH * k;                                        // <= 256: four candidates per lane
+    float cv[4]; int ci[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int i = lane + 64 * j; cv[j] = i < n ? cval[(int64_t) t * n + i] : -INFINITY; ci[j] = i < n ? cid[(int64_t) t * n + i] : 0x7fffffff; }
+    const float pm = lane < TOPK_NCH ? cmax[t * TOPK_NCH + lane] : -INFINITY, ps = lane < TOPK_NCH ? csum[t * TOPK_NCH + lane] : 0.0f;
     float prev_v = INFINITY; int prev_i = -1;
     for (int r = 0; r < k; r++) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = lane; i < n; i += 64) {
-            const float v = cval[(int64_t) t * n + i]; const int id = cid[(int64_t) t * n + i];
-            const bool after = v < prev_v || (v == prev_v && id > prev_i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float v = cv[j]; const int id = ci[j];
+            const bool after = lane + 64 * j < n && (v < prev_v || (v == prev_v && id > prev_i));
             if (after && (v > bv || (v == bv && id < bi))) { bv = v; bi = id; }
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -537,11 +559,9 @@ __global__ void __launch_bounds__(64) k_topk2(int k, const int32_t * __restrict_
         if (lane == 0) { ids[t * k + r] = bi; vals[t * k + r] = bv; }
         prev_v = bv; prev_i = bi;
     }
-    float mx = -INFINITY;
-    for (int i = lane; i < TOPK_NCH; i += 64) mx = fmaxf(mx, cmax[t * TOPK_NCH + i]);
-    mx = pi_wave_max(mx);
-    float s = 0.0f;
-    for (int i = lane; i < TOPK_NCH; i += 64) { const float m = cmax[t * TOPK_NCH + i]; if (m != -INFINITY) s += csum[t * TOPK_NCH + i] * expf(m - mx); }
+    static_assert(TOPK_NCH <= 64, "one partial per lane");
+    float mx = pi_wave_max(pm);
+    float s = (lane < TOPK_NCH && pm != -INFINITY) ? ps * expf(pm - mx) : 0.0f;
     s = pi_lanes_sum<64>(s);
     if (lane == 0) sumexp[t] = s;
 }
