@@ -129,11 +129,11 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__
     float amax = 0.0f, mx = 0.0f; int idx = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+    pi_butterfly<32>([&](auto o) {
+        constexpr int O = decltype(o)::value;
+        const float oa = pi_partner<O>(amax), om = pi_partner<O>(mx); const int oi = pi_partner<O>(idx);
         if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-    }
+    });
     int q[4] = { 0, 0, 0, 0 };
     float d = 0.0f;
     if (amax != 0.0f) {
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__
     // k-major: values 4*lane..4*lane+3 are dword (lane & 7) of 32-group (lane >> 3) -> lane k = lane & 7 keeps 8 consecutive dwords
     ((uint32_t *) (qs + ((int64_t) t * nb + blk) * 256))[(lane & 7) * 8 + (lane >> 3)] = packed;
     int s = q[0] + q[1] + q[2] + q[3];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    s += pi_partner<1>(s); s += pi_partner<2>(s);
     if ((lane & 3) == 0) bsums[((int64_t) t * nb + blk) * 16 + (lane >> 2)] = (int16_t) s;
     if (lane == 0) dd[(int64_t) t * nb + blk] = d;
 }
@@ -176,11 +176,11 @@ static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int
     float amax = 0.0f, mx = 0.0f; int idx = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+    pi_butterfly<32>([&](auto o) {
+        constexpr int O = decltype(o)::value;
+        const float oa = pi_partner<O>(amax), om = pi_partner<O>(mx); const int oi = pi_partner<O>(idx);
         if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-    }
+    });
     int q[4] = { 0, 0, 0, 0 };
     float d = 0.0f;
     if (amax != 0.0f) {
@@ -192,7 +192,7 @@ static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int
     ((uint32_t *) (qs + row_blk * 256))[(lane & 7) * 8 + (lane >> 3)] =
         (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
     int s = q[0] + q[1] + q[2] + q[3];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    s += pi_partner<1>(s); s += pi_partner<2>(s);
     if ((lane & 3) == 0) bsums[row_blk * 16 + (lane >> 2)] = (int16_t) s;
     if (lane == 0) dd[row_blk] = d;
 }

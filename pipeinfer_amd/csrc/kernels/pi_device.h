@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define PI_WAVE 64
 
@@ -13,11 +14,39 @@ static __device__ __forceinline__ float pi_h2f(uint16_t h) { return __half2float
 // first — the two differ when the fp32 product lands exactly on an f16 tie.
 static __device__ __forceinline__ uint16_t pi_f2h(float f) { asm volatile("" : "+v"(f)); return __half_as_ushort(__float2half_rn(f)); }
 
+// Partner exchange for butterfly reductions without the LDS crossbar (`__shfl_xor` is a ds_bpermute: ~100 cycles a step, and the
+// small kernels are chains of such steps).  O = 32 / 16: gfx950's v_permlane32_swap / v_permlane16_swap + a select; O = 8 / 4: DPP
+// row rotations — lane i gets lane (i + O) % 16 of its row, which is not i ^ O, but for a reduction that every lane finishes with the
+// same commutative op the operand *sets* and the association are those of the xor butterfly (the partner's partial is symmetric under
+// the steps already taken), so sums are bit-identical and max / arg-max are the same element; O = 2 / 1: DPP quad permutes (= xor).
+// Blocks are one-dimensional, so lane = threadIdx.x % 64.
+template <int O>
+static __device__ __forceinline__ int pi_partner(int v) {
+    static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "power of two below the wave size");
+    if constexpr (O == 32) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (threadIdx.x & 32) ? r[0] : r[1]; }
+    else if constexpr (O == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (threadIdx.x & 16) ? r[0] : r[1]; }
+    else if constexpr (O == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);      // row_ror:8
+    else if constexpr (O == 4) return __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);      // row_ror:4
+    else if constexpr (O == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    else return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);                             // quad_perm [1,0,3,2]
+}
+template <int O> static __device__ __forceinline__ float pi_partner(float v) { return __builtin_bit_cast(float, pi_partner<O>(__builtin_bit_cast(int, v))); }
+template <int O> static __device__ __forceinline__ double pi_partner(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned) pi_partner<O>((int) (unsigned) b), hi = (unsigned) pi_partner<O>((int) (unsigned) ((unsigned long long) b >> 32));
+    return __builtin_bit_cast(double, (long long) (((unsigned long long) hi << 32) | lo));
+}
+// applies f(partner distance as integral_constant) for O, O/2, ..., 1
+template <int O, class F> static __device__ __forceinline__ void pi_butterfly(F && f) {
+    f(std::integral_constant<int, O>{});
+    if constexpr (O > 1) pi_butterfly<O / 2>(f);
+}
+
 // butterfly sum over W consecutive lanes (W power of two <= 64); every lane ends with the total
 template <int W>
 static __device__ __forceinline__ float pi_lanes_sum(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, PI_WAVE);
+    static_assert(W != 8, "the distance-4 step is a row rotation: only valid after the distance-8 step (W >= 16) or absent (W <= 4)");
+    if constexpr (W > 1) pi_butterfly<W / 2>([&](auto o) { v += pi_partner<decltype(o)::value>(v); });
     return v;
 }
 static __device__ __forceinline__ float pi_lanes_sum_rt(float v, int w) {
@@ -25,13 +54,11 @@ static __device__ __forceinline__ float pi_lanes_sum_rt(float v, int w) {
     return v;
 }
 static __device__ __forceinline__ double pi_wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, PI_WAVE);
+    pi_butterfly<32>([&](auto o) { v += pi_partner<decltype(o)::value>(v); });
     return v;
 }
 static __device__ __forceinline__ float pi_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, PI_WAVE));
+    pi_butterfly<32>([&](auto o) { v = fmaxf(v, pi_partner<decltype(o)::value>(v)); });
     return v;
 }
 
