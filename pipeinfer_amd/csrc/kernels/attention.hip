@@ -181,8 +181,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
             if (x != -INFINITY) { v = pi_h2f(g.exp_tab[pi_f2h(x - mx)]); isum += (unsigned long long) (v * 16777216.0f); }
             s[c] = v;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o, 64);
+        pi_butterfly<32>([&](auto o) { isum += pi_partner<decltype(o)::value>(isum); });
         if (lane == 0) redu[rr][wv] = isum;
     }
     __syncthreads();
@@ -246,9 +245,9 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             float s = (acc[i][0][e] + acc[i][2][e]) + (acc[i][1][e] + acc[i][3][e]);     // registers: 0+=2, 1+=3, 0+=1  (per lane l)
-            s = s + __shfl_xor(s, 4, 64);                                               // t[l] = x[l] + x[l+4]
-            s = s + __shfl_xor(s, 1, 64);                                               // hadd
-            s = s + __shfl_xor(s, 2, 64);                                               // hadd
+            s = s + pi_xor4(s);                                                         // t[l] = x[l] + x[l+4]
+            s = s + pi_partner<1>(s);                                                   // hadd
+            s = s + pi_partner<2>(s);                                                   // hadd
             res[e] = s;
         }
         float mine = res[0];                                                            // every lane of the 8 holds all 8 sums: lane l keeps dim l

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__
     float xs[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     if (e0 < k) { const float4 v = *(const float4 *) (x + (int64_t) t * k + e0); xs[0] = v.x; xs[1] = v.y; xs[2] = v.z; xs[3] = v.w; }
     float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = fmaxf(amax, pi_partner<1>(amax)); amax = fmaxf(amax, pi_partner<2>(amax)); amax = fmaxf(amax, pi_xor4(amax));
     const float d = amax / 127.f;
     const float id = amax != 0.0f ? 127.f / amax : 0.0f;
     int q[4];
@@ -198,7 +198,7 @@ static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int
 }
 static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int lane, int64_t tok_ng, int64_t e0, uint32_t * qs, uint16_t * dd) {
     float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = fmaxf(amax, pi_partner<1>(amax)); amax = fmaxf(amax, pi_partner<2>(amax)); amax = fmaxf(amax, pi_xor4(amax));
     const float d = amax / 127.f;
     const float id = amax != 0.0f ? 127.f / amax : 0.0f;
     int q[4];
@@ -509,10 +509,10 @@ __global__ void __launch_bounds__(256) k_topk1(const float * __restrict__ logits
                 if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
             }
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        pi_butterfly<32>([&](auto o) {
+            const float ov = pi_partner<decltype(o)::value>(bv); const int oi = pi_partner<decltype(o)::value>(bi);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        });
         if (lane == 0) { sv[r & 1][wv] = bv; si[r & 1][wv] = bi; }     // double-buffered: one barrier per round
         __syncthreads();
         bv = sv[r & 1][0]; bi = si[r & 1][0];
@@ -552,10 +552,10 @@ __global__ void __launch_bounds__(64) k_topk2(int k, const int32_t * __restrict_
             const bool after = lane + 64 * j < n && (v < prev_v || (v == prev_v && id > prev_i));
             if (after && (v > bv || (v == bv && id < bi))) { bv = v; bi = id; }
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        pi_butterfly<32>([&](auto o) {
+            const float ov = pi_partner<decltype(o)::value>(bv); const int oi = pi_partner<decltype(o)::value>(bi);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        });
         if (lane == 0) { ids[t * k + r] = bi; vals[t * k + r] = bv; }
         prev_v = bv; prev_i = bi;
     }

@@ -58,9 +58,9 @@ static __device__ __forceinline__ int ub(uint32_t w, int i) { return (int) ((w >
 
 // folds the 8 lanes of a row exactly like hsum_float_8: (a4+a0, a5+a1, a6+a2, a7+a3) -> (r0+r2, r1+r3) -> s0+s1
 static __device__ __forceinline__ float hsum8_lanes(float a) {
-    a = a + __shfl_xor(a, 4, 64);
-    a = a + __shfl_xor(a, 2, 64);
-    a = a + __shfl_xor(a, 1, 64);
+    a = a + pi_xor4(a);
+    a = a + pi_partner<2>(a);
+    a = a + pi_partner<1>(a);
     return a;
 }
 
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_wa
                                     if constexpr (TYPE == PI_Q4_K) {
                                         if (valid) xs[L::SM + p * L::MSTR + b * 4 + c] = (float) prod;
                                     } else {
-                                        prod += __shfl_xor(prod, 1, 64); prod += __shfl_xor(prod, 2, 64);
+                                        prod += pi_partner<1>(prod); prod += pi_partner<2>(prod);
                                         if (valid && c == 0) xs[L::SM + p * L::PSTR + b] = (float) prod;
                                     }
                                     if (valid && c == 0) xs[L::PM + p * L::PSTR + b] = -a.dy * dminx;
@@ -381,8 +381,8 @@ __global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_wa
         float v = hsum8_lanes(acc[ci]);
         if constexpr (TYPE == PI_Q4_K) {
             float mv = (k < 4) ? accm[ci] : 0.0f;
-            mv = mv + __shfl_xor(mv, 2, 64);                                    // (m0+m2, m1+m3)
-            mv = mv + __shfl_xor(mv, 1, 64);                                    // (m0+m2) + (m1+m3)
+            mv = mv + pi_partner<2>(mv);                                        // (m0+m2, m1+m3)
+            mv = mv + pi_partner<1>(mv);                                        // (m0+m2) + (m1+m3)
             v = v + mv;
         } else if constexpr (TYPE == PI_Q5_K) {
             v = v + accm[ci];

@@ -36,6 +36,16 @@ template <int O> static __device__ __forceinline__ double pi_partner(double v) {
     const unsigned lo = (unsigned) pi_partner<O>((int) (unsigned) b), hi = (unsigned) pi_partner<O>((int) (unsigned) ((unsigned long long) b >> 32));
     return __builtin_bit_cast(double, (long long) (((unsigned long long) hi << 32) | lo));
 }
+template <int O> static __device__ __forceinline__ unsigned long long pi_partner(unsigned long long v) {
+    const unsigned lo = (unsigned) pi_partner<O>((int) (unsigned) v), hi = (unsigned) pi_partner<O>((int) (unsigned) (v >> 32));
+    return ((unsigned long long) hi << 32) | lo;
+}
+// the value of lane i ^ 4 exactly (groups of 8 lanes: the (l, l+4) fold of an AVX hsum): two row shifts and a select
+static __device__ __forceinline__ int pi_xor4(int v) {
+    const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, true), dn = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shl:4, row_shr:4
+    return (threadIdx.x & 4) ? dn : up;
+}
+static __device__ __forceinline__ float pi_xor4(float v) { return __builtin_bit_cast(float, pi_xor4(__builtin_bit_cast(int, v))); }
 // applies f(partner distance as integral_constant) for O, O/2, ..., 1
 template <int O, class F> static __device__ __forceinline__ void pi_butterfly(F && f) {
     f(std::integral_constant<int, O>{});
