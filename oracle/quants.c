@@ -54,7 +54,7 @@ int o_blck_size(int type) {
     switch (type) {
         case OT_F32: case OT_F16: return 1;
         case OT_Q4_0: case OT_Q8_0: return OQK;
-        case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: case OT_Q8_K: return OQK_K;
+        case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: case OT_Q8_K: return OQK_K;
     }
     return 0;
 }
@@ -64,7 +64,7 @@ int o_type_size(int type) {
         case OT_F32: return 4; case OT_F16: return 2;
         case OT_Q4_0: return sizeof(oblk_q4_0); case OT_Q8_0: return sizeof(oblk_q8_0);
         case OT_Q4_K: return sizeof(oblk_q4_K); case OT_Q5_K: return sizeof(oblk_q5_K);
-        case OT_Q6_K: return sizeof(oblk_q6_K); case OT_Q8_K: return sizeof(oblk_q8_K);
+        case OT_Q6_K: return sizeof(oblk_q6_K); case OT_Q8_K: return sizeof(oblk_q8_K); case OT_Q3_K: return sizeof(oblk_q3_K);
     }
     return 0;
 }
@@ -76,7 +76,7 @@ int o_vec_dot_type(int type) {
     switch (type) {
         case OT_F32: return OT_F32; case OT_F16: return OT_F16;
         case OT_Q4_0: case OT_Q8_0: return OT_Q8_0;
-        case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: return OT_Q8_K;
+        case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: return OT_Q8_K;
     }
     return -1;
 }
@@ -158,7 +158,24 @@ static inline int q6k_at(const oblk_q6_K * b, int e) {                        //
     return ((g & 2) ? lo >> 4 : lo & 0xF) | (((b->qh[32 * n + l] >> (2 * g)) & 3) << 4);
 }
 
-// ggml-quants.c:1074-1092, 1168-1182, 1917-1954, 2117-2160, 2263-2308
+// Q3_K (ggml-quants.c:1711-1759): sixteen 6-bit scales packed in 12 bytes (stored + 32), weight = (2 low bits | high bit << 2) - 4
+static inline void q3k_scales(const oblk_q3_K * b, int8_t * sc) {
+    const uint32_t kmask1 = 0x03030303, kmask2 = 0x0f0f0f0f;
+    uint32_t a[3], aux[4];
+    memcpy(a, b->scales, 12);
+    aux[0] = (a[0] & kmask2) | (((a[2] >> 0) & kmask1) << 4);
+    aux[1] = (a[1] & kmask2) | (((a[2] >> 2) & kmask1) << 4);
+    aux[2] = ((a[0] >> 4) & kmask2) | (((a[2] >> 4) & kmask1) << 4);
+    aux[3] = ((a[1] >> 4) & kmask2) | (((a[2] >> 6) & kmask1) << 4);
+    memcpy(sc, aux, 16);
+    for (int i = 0; i < 16; i++) sc[i] = (int8_t) (sc[i] - 32);
+}
+static inline int q3k_at(const oblk_q3_K * b, int e) {                        // -4..3
+    const int n = e >> 7, j = (e >> 5) & 3, l = e & 31;
+    return ((b->qs[32 * n + l] >> (2 * j)) & 3) - ((b->hmask[l] & (1 << (4 * n + j))) ? 0 : 4);
+}
+
+// ggml-quants.c:1074-1092, 1168-1182, 1711-1759, 1917-1954, 2117-2160, 2263-2308
 void o_dequantize_row(int type, const void * vx, float * y, int k) {
     switch (type) {
         case OT_F32: memcpy(y, vx, (size_t) 4 * k); break;
@@ -202,6 +219,14 @@ void o_dequantize_row(int type, const void * vx, float * y, int k) {
                 }
             }
         } break;
+        case OT_Q3_K: {
+            const oblk_q3_K * x = vx;
+            for (int i = 0; i < k / OQK_K; i++) {
+                const float d_all = o_fp16_to_fp32(x[i].d);
+                int8_t sc[16]; q3k_scales(&x[i], sc);
+                for (int e = 0; e < OQK_K; e++) { const float dl = d_all * sc[e >> 4]; *y++ = dl * q3k_at(&x[i], e); }
+            }
+        } break;
         case OT_Q6_K: {
             const oblk_q6_K * x = vx;
             for (int i = 0; i < k / OQK_K; i++) {
@@ -243,6 +268,12 @@ void o_block_isums(int type, const void * xb, const void * yb, int32_t * isum, i
         for (int e = 0; e < OQK_K; e++) isum[(e & 31) >> 2] += x->scales[e >> 4] * (q6k_at(x, e) - 32) * y->qs[e];
         return;
     }
+    if (type == OT_Q3_K) {                                                       // ggml-quants.c:4443-4533: same lane grouping, scale of element e = sc[e >> 4]
+        const oblk_q3_K * x = xb;
+        int8_t sc[16]; q3k_scales(x, sc);
+        for (int e = 0; e < OQK_K; e++) isum[(e & 31) >> 2] += sc[e >> 4] * q3k_at(x, e) * y->qs[e];
+        return;
+    }
     const uint8_t * scales = type == OT_Q4_K ? ((const oblk_q4_K *) xb)->scales : ((const oblk_q5_K *) xb)->scales;
     for (int s = 0; s < 8; s++) {
         uint8_t sc, m; scale_min_k4(s, scales, &sc, &m);
@@ -255,7 +286,7 @@ void o_block_isums(int type, const void * xb, const void * yb, int32_t * isum, i
     }
 }
 
-// ggml_vec_dot_q4_K_q8_K AVX2 arm (ggml-quants.c:5318-5381), q5_K (:5967-6050), q6_K (:6741-6810),
+// ggml_vec_dot_q4_K_q8_K AVX2 arm (ggml-quants.c:5318-5381), q5_K (:5967-6050), q6_K (:6741-6810), q3_K (:4443-4533),
 // q4_0 (:2500-2523), q8_0 (:3584-3605)
 float o_vec_dot(int type, int n, const void * vx, const void * vy) {
     float acc[8] = { 0 };
@@ -289,6 +320,16 @@ float o_vec_dot(int type, int n, const void * vx, const void * vy) {
     }
     const int nb = n / OQK_K;
     const oblk_q8_K * y = vy;
+    if (type == OT_Q3_K) {                                                       // acc = fmadd(broadcast(d), cvt(sumi), acc) per block, hsum_float_8 (:4450-4533)
+        const oblk_q3_K * x = vx;
+        for (int i = 0; i < nb; i++) {
+            int32_t is[8], ms;
+            o_block_isums(type, &x[i], &y[i], is, &ms);
+            const float d = y[i].d * o_fp16_to_fp32(x[i].d);
+            for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+        }
+        return hsum8(acc);
+    }
     if (type == OT_Q6_K) {
         const oblk_q6_K * x = vx;
         for (int i = 0; i < nb; i++) {

@@ -160,6 +160,16 @@ def random_blocks(ttype, n_elem, rng, std):
         out[:, 0:2] = _f16(d).view(np.uint8).reshape(nb, 2)
         out[:, 2:4] = _f16(d * ratio).view(np.uint8).reshape(nb, 2)
         out[:, 4:16] = _pack_k4_scales(sc, m)
+    elif ttype == G.T_Q3_K:
+        # hmask 32 | qs 64 | scales 12 | d 2: random 3-bit weights (-4..3, std 2.29); the sixteen stored scales become 32 +- (4..19)
+        mag = 4 + out[:, 96:108].astype(np.int32) % 16                                          # reuse the random bytes: 12 per block
+        mag = np.concatenate([mag, 4 + (out[:, 32:36].astype(np.int32) % 16)], axis=1)          # 16 magnitudes
+        sign = np.where(out[:, 40:56] & 1, 1, -1)
+        sc6 = (32 + sign * mag).astype(np.uint8)                                                # 6-bit values 13..51
+        lo, hi = sc6 & 0xF, sc6 >> 4
+        out[:, 96:104] = lo[:, 0:8] | (lo[:, 8:16] << 4)
+        out[:, 104:108] = hi[:, 0:4] | (hi[:, 4:8] << 2) | (hi[:, 8:12] << 4) | (hi[:, 12:16] << 6)
+        out[:, 108:110] = _f16(std / (11.5 * 2.29) * jitter).view(np.uint8).reshape(nb, 2)
     elif ttype == G.T_Q6_K:
         sc = (20 + out[:, 192:208] % 25).astype(np.int8)
         sc[out[:, 192:208] >= 128] *= -1

@@ -100,6 +100,25 @@ def kernel_vectors():
     np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
 
 
+def kernel_vectors_q3k():
+    """same vectors as kernel_vectors() for Q3_K, in a file of their own so that kernels.npz stays byte-identical"""
+    r = O.Impl("ref")
+    q = ref_quantizer()
+    out = {}
+    k, t = 1024, O.Q3_K
+    rng = np.random.default_rng(100 + t)
+    w = (rng.standard_normal((6, k)) * 0.05).astype(np.float32)
+    blocks = q(t, w).reshape(6, -1)
+    act = np.stack([synth_signal(k, s + t) for s in range(3)])
+    qa = np.stack([r.quantize_act(O.VEC_DOT_TYPE[t], a) for a in act])
+    out["q3_K_blocks"] = blocks
+    out["q3_K_act"] = act
+    out["q3_K_qact"] = qa
+    out["q3_K_dots"] = np.array([[r.vec_dot(t, k, blocks[i], qa[j]) for i in range(6)] for j in range(3)], np.float32)
+    out["q3_K_deq"] = np.stack([r.dequantize(t, b, k) for b in blocks])
+    np.savez_compressed(os.path.join(HERE, "kernels_q3k.npz"), **out)
+
+
 def model_vectors():
     q = ref_quantizer()
     for stem, spec, ftype, seed in MODELS:
@@ -132,5 +151,9 @@ def model_vectors():
 
 if __name__ == "__main__":
     assert O.ref() is not None, "needs oracle/_ref (make -C oracle ref)"
-    kernel_vectors()
-    model_vectors()
+    if sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
+        kernel_vectors_q3k()
+    else:
+        kernel_vectors()
+        kernel_vectors_q3k()
+        model_vectors()

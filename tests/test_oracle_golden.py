@@ -17,11 +17,14 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q4_K, O.Q5_K, O.Q6_K])
+K3 = np.load(os.path.join(GOLD, "kernels_q3k.npz"))
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K])
 def test_quant_golden(t):
     o = O.Impl("oracle")
     name = O.TYPE_NAMES[t]
-    blocks, act, qact, dots, deq = (K[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
+    blocks, act, qact, dots, deq = ((K3 if t == O.Q3_K else K)[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
     k = act.shape[1]
     for j in range(act.shape[0]):
         assert np.array_equal(o.quantize_act(O.VEC_DOT_TYPE[t], act[j]), qact[j])          # bytes identical
