@@ -46,6 +46,15 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
             const float d1 = d * sc, m1 = mn * m;
             y = d1 * q - m1;
         } break;
+        case PI_Q3_K: {                                                                          // dequantize_row_q3_K, ggml-quants.c:1711-1759
+            const int64_t b = row * w.nb + (e >> 8);
+            const int ee = (int) (e & 255), n = ee >> 7, j = (ee >> 5) & 3, l = ee & 31, c = l >> 3, h = (l >> 2) & 1;
+            const uint8_t lo = w.p0[b * 96 + 16 * c + 8 * n + 4 * h + (l & 3)];                  // qs[32n + l]
+            const uint8_t hm = w.p0[b * 96 + 64 + 8 * c + 4 * h + (l & 3)];                      // hmask[l]
+            const int q = (int) ((lo >> (2 * j)) & 3) - (((hm >> (4 * n + j)) & 1) ? 0 : 4);
+            const float dl = pi_h2f(((const uint16_t *) w.p2)[b]) * (float) ((const int8_t *) w.p1)[b * 16 + (ee >> 4)];
+            y = dl * (float) q;
+        } break;
         case PI_Q6_K: {
             const int64_t b = row * w.nb + (e >> 8);
             const int ee = (int) (e & 255), n = ee >> 7, g = (ee >> 5) & 3, l = ee & 31;

@@ -85,6 +85,7 @@ static __device__ __forceinline__ float hsum8_lanes(float a) {
 #define KQ_TB 16                // blocks per tile
 #define MMVQ_ST_NT 4            // widest batch that gets the loop-free (single-tile / tile-per-wave) instances
 template <int TYPE> struct kq_raw { uint4 hdr, qa, qb, h; uint32_t d; };     // one lane's share of a block (k = 2c, 2c+1)
+template <int TYPE> constexpr bool kq_has_mins = TYPE == PI_Q4_K || TYPE == PI_Q5_K;       // Q6_K and Q3_K are scale-only (symmetric) formats
 
 template <int TYPE>
 static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk, int c, kq_raw<TYPE> & o) {
@@ -95,6 +96,12 @@ static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk,
         o.qa  = *(const uint4 *) (p + QOFF + 32 * c);
         o.qb  = *(const uint4 *) (p + QOFF + 32 * c + 16);
         if constexpr (TYPE == PI_Q5_K) { const uint2 hh = *(const uint2 *) (p + 16 + 8 * c); o.h.x = hh.x; o.h.y = hh.y; }
+    } else if constexpr (TYPE == PI_Q3_K) {                                  // runtime.hip: k_repack_q3_K
+        const uint8_t * p = w.p0 + (size_t) blk * 96;
+        o.qa  = *(const uint4 *) (p + 16 * c);                               // qs: half 0 (elements 8c.., 8c+4..), half 1 (same)
+        const uint2 hh = *(const uint2 *) (p + 64 + 8 * c); o.h.x = hh.x; o.h.y = hh.y;     // hmask of elements 8c.., 8c+4..
+        o.hdr = *(const uint4 *) (w.p1 + (size_t) blk * 16);                 // sixteen int8 scales, already - 32
+        o.d   = ((const uint16_t *) w.p2)[blk];
     } else {
         const uint8_t * p = w.p0 + (size_t) blk * 192;
         o.qa  = *(const uint4 *) (p + 32 * c);
@@ -102,6 +109,16 @@ static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk,
         o.h   = *(const uint4 *) (p + 128 + 16 * c);
         o.hdr = *(const uint4 *) (w.p1 + (size_t) blk * 16);
         o.d   = ((const uint16_t *) w.p2)[blk];
+    }
+}
+
+// Q3_K: group g = 4j + s of the block is (qs dword of half j >> 2s) & 3 per byte, | high bit g of the hmask dword << 2, minus 4
+// (ggml-quants.c:4486-4520: the AVX2 arm subtracts 4 where the high bit is NOT set — the same thing)
+static __device__ __forceinline__ void kq_unpack_q3(uint32_t q_half0, uint32_t q_half1, uint32_t hm, int * wq) {
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        const uint32_t q = g < 4 ? q_half0 : q_half1;
+        wq[g] = bytes_sub((int) (((q >> (2 * (g & 3))) & 0x03030303u) | (((hm >> g) & 0x01010101u) << 2)), 0x04040404);
     }
 }
 
@@ -137,7 +154,7 @@ template <int TYPE, int NP> struct kq_lds {                                  // 
     static constexpr int SSTR = KQ_TB * 8 + 8, PSTR = KQ_TB + 1, MSTR = KQ_TB * 4 + 4;      // strides padded to spread banks
     static constexpr int S = 0, P = S + NP * SSTR, SM = P + NP * PSTR,
                          PM = SM + (TYPE == PI_Q4_K ? NP * MSTR : TYPE == PI_Q5_K ? NP * PSTR : 0),
-                         FLOATS = (PM + (TYPE == PI_Q6_K ? 0 : NP * PSTR) + 3) & ~3;
+                         FLOATS = (PM + (kq_has_mins<TYPE> ? NP * PSTR : 0) + 3) & ~3;
 };
 
 static __device__ __forceinline__ void wave_lds_sync() {
@@ -158,7 +175,7 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
     a.y[1][4] = (int) y3.x; a.y[1][5] = (int) y3.y; a.y[1][6] = (int) y3.z; a.y[1][7] = (int) y3.w;
     a.dy = ((const float *) g.ad)[ab];
     a.bsA = a.bsB = 0;
-    if constexpr (TYPE != PI_Q6_K) {                                         // int16 pair sums like _mm_hadd_epi16
+    if constexpr (kq_has_mins<TYPE>) {                                       // int16 pair sums like _mm_hadd_epi16
         const short4 bs = *(const short4 *) (g.abs_ + ab * 32 + 8 * c);
         a.bsA = (int) (short) (bs.x + bs.y); a.bsB = (int) (short) (bs.z + bs.w);
     }
@@ -300,8 +317,13 @@ __global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_wa
                                 sc[j] = (int) (int8_t) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xff);
                             }
                         }
-                        kq_unpack_w<TYPE>(raw[i].qa, raw[i].h.x, TYPE == PI_Q6_K ? raw[i].h.y : 0u, wq[0]);
-                        kq_unpack_w<TYPE>(raw[i].qb, TYPE == PI_Q6_K ? raw[i].h.z : raw[i].h.y, TYPE == PI_Q6_K ? raw[i].h.w : 0u, wq[1]);
+                        if constexpr (TYPE == PI_Q3_K) {
+                            kq_unpack_q3(raw[i].qa.x, raw[i].qa.z, raw[i].h.x, wq[0]);
+                            kq_unpack_q3(raw[i].qa.y, raw[i].qa.w, raw[i].h.y, wq[1]);
+                        } else {
+                            kq_unpack_w<TYPE>(raw[i].qa, raw[i].h.x, TYPE == PI_Q6_K ? raw[i].h.y : 0u, wq[0]);
+                            kq_unpack_w<TYPE>(raw[i].qb, TYPE == PI_Q6_K ? raw[i].h.z : raw[i].h.y, TYPE == PI_Q6_K ? raw[i].h.w : 0u, wq[1]);
+                        }
     #pragma unroll
                         for (int tt = 0; tt < NG_MAX; tt++) {
                             if (t0 + tt < NT) {
@@ -314,7 +336,7 @@ __global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_wa
                                     *(float2 *) (xs + L::S + p * L::SSTR + b * 8 + 2 * c) = make_float2((float) sumi0, (float) sumi1);
                                     if (c == 0) xs[L::P + p * L::PSTR + b] = a.dy * dx;
                                 }
-                                if constexpr (TYPE != PI_Q6_K) {
+                                if constexpr (kq_has_mins<TYPE>) {
                                     // mins: prod[c] = m[2c]*(bsums[4c]+bsums[4c+1]) + m[2c+1]*(bsums[4c+2]+bsums[4c+3])
                                     int prod = __mul24(m0, a.bsA) + __mul24(m1, a.bsB);
                                     if constexpr (TYPE == PI_Q4_K) {
@@ -701,6 +723,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         }
         int rc = -1;
         switch (w0->type) {
+            case PI_Q3_K: rc = dispatch_nt<PI_Q3_K>(L, nt, stream); break;
             case PI_Q4_K: rc = dispatch_nt<PI_Q4_K>(L, nt, stream); break;
             case PI_Q5_K: rc = dispatch_nt<PI_Q5_K>(L, nt, stream); break;
             case PI_Q6_K: rc = dispatch_nt<PI_Q6_K>(L, nt, stream); break;

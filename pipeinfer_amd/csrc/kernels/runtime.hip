@@ -126,6 +126,25 @@ __global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uin
     for (int k = 0; k < 16; k++) sc[i * 16 + k] = b[192 + k];
     d[i] = (uint16_t) (b[208] | (b[209] << 8));
 }
+// Q3_K (110 bytes: hmask 32 | qs 64 | scales 12 | d): plane a = 96 bytes per block, k-major for quad lane c (elements 8c..8c+7 of every
+// 32-group): [c][half j][dword h] of qs at 16c + 8j + 4h, then hmask dwords at 64 + 8c + 4h; the sixteen 6-bit scales are decoded
+// once (ggml-quants.c:1731-1736) and stored as int8 (value - 32) in plane sc; d in plane d
+__global__ void k_repack_q3_K(const uint8_t * __restrict__ src, uint8_t * a, int8_t * sc, uint16_t * d, int64_t nblocks) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint8_t * b = src + i * 110;                       // 2-byte aligned only: assemble dwords from bytes
+    auto ld = [&](int off) { return (uint32_t) b[off] | (uint32_t) b[off + 1] << 8 | (uint32_t) b[off + 2] << 16 | (uint32_t) b[off + 3] << 24; };
+    uint32_t * o = (uint32_t *) (a + i * 96);
+    for (int c = 0; c < 4; c++) {
+        for (int j = 0; j < 2; j++) for (int h = 0; h < 2; h++) o[c * 4 + j * 2 + h] = ld(32 + 32 * j + 8 * c + 4 * h);      // qs[32j + 8c + 4h ..]
+        for (int h = 0; h < 2; h++) o[16 + c * 2 + h] = ld(8 * c + 4 * h);                                                    // hmask[8c + 4h ..]
+    }
+    const uint32_t a0 = ld(96), a1 = ld(100), a2 = ld(104), kmask1 = 0x03030303u, kmask2 = 0x0f0f0f0fu;
+    const uint32_t aux[4] = { (a0 & kmask2) | (((a2 >> 0) & kmask1) << 4), (a1 & kmask2) | (((a2 >> 2) & kmask1) << 4),
+                              ((a0 >> 4) & kmask2) | (((a2 >> 4) & kmask1) << 4), ((a1 >> 4) & kmask2) | (((a2 >> 6) & kmask1) << 4) };
+    for (int k = 0; k < 16; k++) sc[i * 16 + k] = (int8_t) ((int) ((aux[k >> 2] >> (8 * (k & 3))) & 0xff) - 32);
+    d[i] = (uint16_t) (b[108] | (b[109] << 8));
+}
 __global__ void k_repack_q4_0(const uint8_t * __restrict__ src, uint32_t * qs, uint16_t * d, int64_t rows, int64_t nb, int64_t ng) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * nb) return;
@@ -155,7 +174,8 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     const int64_t nblocks = w->nb * ne1;
     w->nbytes = (size_t) nblocks * tsz;
     const bool small = type == PI_Q4_0 || type == PI_Q8_0;
-    const size_t alloc = small ? (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32) + (size_t) ne1 * w->ng * 8 + 512 : w->nbytes + 512;
+    const size_t alloc = small ? (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32) + (size_t) ne1 * w->ng * 8 + 512
+                       : type == PI_Q3_K ? (size_t) nblocks * (96 + 16 + 2) + 512 : w->nbytes + 512;
     if (hipMalloc(&w->base, alloc) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", alloc); delete w; return nullptr; }
     uint8_t * base = (uint8_t *) w->base;
     w->p0 = base; w->p1 = w->p2 = w->p3 = nullptr;
@@ -171,7 +191,10 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     const unsigned grid = (unsigned) ((nblocks + threads - 1) / threads);
     if (type == PI_Q4_K) hipLaunchKernelGGL(k_repack_k45, dim3(grid), dim3(threads), 0, stream, staging, base, nblocks, 144, 16);
     else if (type == PI_Q5_K) hipLaunchKernelGGL(k_repack_k45, dim3(grid), dim3(threads), 0, stream, staging, base, nblocks, 176, 48);
-    else if (type == PI_Q6_K) {
+    else if (type == PI_Q3_K) {
+        w->p1 = base + nblocks * 96; w->p2 = w->p1 + nblocks * 16;
+        hipLaunchKernelGGL(k_repack_q3_K, dim3(grid), dim3(threads), 0, stream, staging, base, (int8_t *) w->p1, (uint16_t *) w->p2, nblocks);
+    } else if (type == PI_Q6_K) {
         w->p1 = base + nblocks * 192; w->p2 = w->p1 + nblocks * 16;
         hipLaunchKernelGGL(k_repack_q6_K, dim3(grid), dim3(threads), 0, stream, staging, base, (uint8_t *) w->p1, (uint16_t *) w->p2, nblocks);
     } else {
@@ -194,7 +217,7 @@ extern "C" int pi_weight_type(const pi_weight * w) { return w->type; }
 extern "C" int pi_vec_dot_type(int t) {
     switch (t) {
         case PI_Q4_0: case PI_Q8_0: return PI_Q8_0;
-        case PI_Q4_K: case PI_Q5_K: case PI_Q6_K: return PI_Q8_K;
+        case PI_Q3_K: case PI_Q4_K: case PI_Q5_K: case PI_Q6_K: return PI_Q8_K;
         case PI_F16: return PI_F16; case PI_F32: return PI_F32;
     }
     return -1;
