@@ -42,14 +42,14 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
     hd = n_embd // n_head
     n_gqa = hd * n_head_kv
     ftype = ftype.lower()
-    base = {"q4_0": G.T_Q4_0, "q8_0": G.T_Q8_0, "q4_k_m": G.T_Q4_K, "q4_k_s": G.T_Q4_K, "q5_k_m": G.T_Q5_K, "q5_k_s": G.T_Q5_K,
+    base = {"q4_0": G.T_Q4_0, "q8_0": G.T_Q8_0, "q3_k_m": G.T_Q3_K, "q4_k_m": G.T_Q4_K, "q4_k_s": G.T_Q4_K, "q5_k_m": G.T_Q5_K, "q5_k_s": G.T_Q5_K,
             "q6_k": G.T_Q6_K, "f16": G.T_F16, "f32": G.T_F32}[ftype]
-    kq = ftype.startswith(("q4_k", "q5_k", "q6_k"))
+    kq = ftype.startswith(("q3_k", "q4_k", "q5_k", "q6_k"))
     is_70b = arch == "llama" and n_layer == 80 and n_head != n_head_kv    # llama.cpp MODEL_70B detection (n_layer 80)
 
     def fix(t, nx):
         # K-quants need ne0 % 256 == 0; fallbacks per llama.cpp:7985-8003 that stay inside our kernel set
-        if t in (G.T_Q4_K, G.T_Q5_K, G.T_Q6_K) and nx % 256 != 0:
+        if t in (G.T_Q3_K, G.T_Q4_K, G.T_Q5_K, G.T_Q6_K) and nx % 256 != 0:
             return G.T_Q8_0 if t == G.T_Q6_K else G.T_Q4_0
         return t
 
@@ -62,7 +62,9 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
 
     def v_type(i):
         t = base
-        if ftype in ("q4_k_m", "q5_k_m") and use_more_bits(i, n_layer):
+        if ftype == "q3_k_m":                                           # llama.cpp:7919-7921
+            t = G.T_Q5_K if i < 2 else G.T_Q4_K
+        elif ftype in ("q4_k_m", "q5_k_m") and use_more_bits(i, n_layer):
             t = G.T_Q6_K
         elif ftype == "q4_k_s" and i < 4:
             t = G.T_Q5_K
@@ -72,7 +74,9 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
 
     def down_type(i):
         t = base
-        if ftype == "q4_k_m":
+        if ftype == "q3_k_m":                                           # llama.cpp:7937-7941
+            t = G.T_Q5_K if i < 2 else (G.T_Q4_K if arch != "falcon" or use_more_bits(i, n_layer) else G.T_Q3_K)
+        elif ftype == "q4_k_m":
             if arch == "falcon":
                 t = G.T_Q6_K if i < 2 else (G.T_Q5_K if use_more_bits(i, n_layer) else G.T_Q4_K)
             elif use_more_bits(i, n_layer):
@@ -93,7 +97,7 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
                 (p + "attn_q.weight", (n_embd, n_embd), fix(base, n_embd), "proj"),
                 (p + "attn_k.weight", (n_embd, n_gqa), fix(base, n_embd), "proj"),
                 (p + "attn_v.weight", (n_embd, n_gqa), fix(v_type(i) if kq else base, n_embd), "proj"),
-                (p + "attn_output.weight", (n_embd, n_embd), fix(base, n_embd), "out"),
+                (p + "attn_output.weight", (n_embd, n_embd), fix(G.T_Q4_K if ftype == "q3_k_m" else base, n_embd), "out"),     # llama.cpp:7958-7961
                 (p + "ffn_norm.weight", (n_embd,), G.T_F32, "ones"),
                 (p + "ffn_gate.weight", (n_embd, n_ff), fix(base, n_embd), "proj"),
                 (p + "ffn_down.weight", (n_ff, n_embd), fix(down_type(i) if kq else base, n_ff), "out"),
@@ -103,7 +107,7 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
             plan += [(p + "attn_norm.weight", (n_embd,), G.T_F32, "ones"), (p + "attn_norm.bias", (n_embd,), G.T_F32, "zeros")]
             if two_norms:
                 plan += [(p + "attn_norm_2.weight", (n_embd,), G.T_F32, "ones"), (p + "attn_norm_2.bias", (n_embd,), G.T_F32, "zeros")]
-            qkv_t = G.T_Q5_K if ftype == "q4_k_m" else (G.T_Q6_K if ftype == "q5_k_m" else base)
+            qkv_t = G.T_Q5_K if ftype == "q4_k_m" else (G.T_Q6_K if ftype == "q5_k_m" else (G.T_Q4_K if ftype == "q3_k_m" else base))
             plan += [
                 (p + "attn_qkv.weight", (n_embd, n_embd + 2 * n_gqa), fix(qkv_t, n_embd), "proj"),
                 (p + "attn_output.weight", (n_embd, n_embd), fix(base, n_embd), "out"),
@@ -205,6 +209,28 @@ def quantize_simple(ttype, x):
         out = np.zeros((b.shape[0], 18), np.uint8)
         out[:, 0:2] = _f16(d).view(np.uint8).reshape(-1, 2)
         out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+        return out.reshape(-1)
+    if ttype == G.T_Q3_K:
+        b = x.reshape(-1, 16, 16)                                          # [nb, 16 groups, 16]
+        gs = np.abs(b).max(2) / 4.0
+        d = gs.max(1) / 31.0
+        d = np.where(d == 0, 1e-8, d)
+        sc = np.clip(np.rint(gs / d[:, None]), 1, 31).astype(np.int32)
+        q = (np.clip(np.rint(b / (d[:, None, None] * sc[:, :, None])), -4, 3).astype(np.int32) + 4).reshape(-1, 2, 4, 32)   # [nb, half n, j, l] 0..7
+        nb = q.shape[0]
+        out = np.zeros((nb, 110), np.uint8)
+        lo, hi = (q & 3).astype(np.uint8), (q >> 2).astype(np.uint8)
+        out[:, 32:96] = (lo[:, :, 0] | (lo[:, :, 1] << 2) | (lo[:, :, 2] << 4) | (lo[:, :, 3] << 6)).reshape(nb, 64)      # qs[32n + l]
+        hm = np.zeros((nb, 32), np.uint8)
+        for n in range(2):
+            for j in range(4):
+                hm |= hi[:, n, j] << (4 * n + j)
+        out[:, 0:32] = hm
+        sc6 = (sc + 32).astype(np.uint8)
+        l4, h2 = sc6 & 0xF, sc6 >> 4
+        out[:, 96:104] = l4[:, 0:8] | (l4[:, 8:16] << 4)
+        out[:, 104:108] = h2[:, 0:4] | (h2[:, 4:8] << 2) | (h2[:, 8:12] << 4) | (h2[:, 12:16] << 6)
+        out[:, 108:110] = _f16(d).view(np.uint8).reshape(nb, 2)
         return out.reshape(-1)
     if ttype == G.T_Q6_K:
         b = x.reshape(-1, 16, 16)                                          # [nb, 16 groups, 16]

@@ -23,6 +23,7 @@ MODELS = [  # (file stem, spec, ftype, seed)
     ("tiny_llama_b_q4_k_m", "tiny-llama-b", "q4_k_m", 13),     # "draft"-vs-"target" pair partner, MHA
     ("tiny_falcon_q4_0", "tiny-falcon", "q4_0", 14),           # 7B-style: MQA, single norm, Q8_0 head
     ("tiny_falcon40_q4_k_m", "tiny-falcon40", "q4_k_m", 15),   # 40B-style: GQA, two norms, Q5_K qkv
+    ("tiny_llama_q3_k_m", "tiny-llama", "q3_k_m", 16),         # Q3_K / Q4_K / Q5_K / Q6_K mixture of llama.cpp:7919-7961
 ]
 
 
@@ -119,9 +120,11 @@ def kernel_vectors_q3k():
     np.savez_compressed(os.path.join(HERE, "kernels_q3k.npz"), **out)
 
 
-def model_vectors():
+def model_vectors(only=None):
     q = ref_quantizer()
     for stem, spec, ftype, seed in MODELS:
+        if only and stem not in only:
+            continue
         path = os.path.join(HERE, stem + ".gguf")
         synth.write_model(path, spec, ftype, seed=seed, std=0.08, quantizer=q)
         n_vocab = synth.SPECS[spec][6]
@@ -153,6 +156,7 @@ if __name__ == "__main__":
     assert O.ref() is not None, "needs oracle/_ref (make -C oracle ref)"
     if sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
+        model_vectors(only=["tiny_llama_q3_k_m"])
     else:
         kernel_vectors()
         kernel_vectors_q3k()
