@@ -630,7 +630,7 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                     const int ntiles = (g.nb + KQ_TB - 1) / KQ_TB;
                     static const bool no_tpw = getenv("PI_MMVQ_NO_TPW") != nullptr;    // tuning / tests
                     if constexpr (NT <= 2) {                                           // measured: wider batches are better off in the tile loop
-                        if (ntiles > 1 && ntiles <= 16 && !no_tpw) {
+                        if (ntiles > 1 && ntiles <= 4 && !no_tpw) {                 // measured: 2-3 tiles win (K = 8192: 11.3 vs 14.5 us), 7 tiles lose (K = 28672: 36.9 vs 34.0; NT = 2: 57 vs 43) — wave 0's serial chain grows with the row
                             const size_t lds_t = (size_t) ntiles * kq_lds<TYPE, RR * NT>::FLOATS * 4;
                             if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
                             else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);
