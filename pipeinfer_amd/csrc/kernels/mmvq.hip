@@ -187,8 +187,8 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
 // single-tile instance (so every tile of the row is in flight at once and nothing loops), the products meet in LDS and wave 0 runs
 // the ordered chains through the tiles in block order
 template <int TYPE, int NT, int R, int ST>
-__global__ void __launch_bounds__(ST == 2 ? 1024 : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
-    static_assert(ST == 0 || (ST == 1 && NT <= MMVQ_ST_NT) || (ST == 2 && NT <= 2), "loop-free instances: single tile up to MMVQ_ST_NT tokens, tile-per-wave up to 2");
+__global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
+    static_assert(ST == 0 || (ST != 0 && NT <= MMVQ_ST_NT), "loop-free instances: decode and small verify batches");
     constexpr bool TPW = ST == 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NP = R * NT, NIT = (NP + 7) / 8;
@@ -629,8 +629,8 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                 if constexpr (NT <= MMVQ_ST_NT) {
                     const int ntiles = (g.nb + KQ_TB - 1) / KQ_TB;
                     static const bool no_tpw = getenv("PI_MMVQ_NO_TPW") != nullptr;    // tuning / tests
-                    if constexpr (NT <= 2) {                                           // measured: wider batches are better off in the tile loop
-                        if (ntiles > 1 && ntiles <= 4 && !no_tpw) {                 // measured: 2-3 tiles win (K = 8192: 11.3 vs 14.5 us), 7 tiles lose (K = 28672: 36.9 vs 34.0; NT = 2: 57 vs 43) — wave 0's serial chain grows with the row
+                    if constexpr (NT <= 4) {                                           // measured per width: up to 4 tiles at NT <= 2, two tiles at NT 3-4 (70B K = 8192: -15 %), the loop otherwise
+                        if (ntiles > 1 && ntiles <= (NT <= 2 ? 4 : 2) && !no_tpw) {                 // measured: 2-3 tiles win (K = 8192: 11.3 vs 14.5 us), 7 tiles lose (K = 28672: 36.9 vs 34.0; NT = 2: 57 vs 43) — wave 0's serial chain grows with the row
                             const size_t lds_t = (size_t) ntiles * kq_lds<TYPE, RR * NT>::FLOATS * 4;
                             if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
                             else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);

@@ -106,7 +106,8 @@ def test_mul_mat_golden_blocks(gpu, t):
 @pytest.mark.parametrize("k,rows,n_tok", [(256, 37, 3), (768, 64, 1), (1024, 100, 8), (2048, 256, 2), (4096, 515, 1), (4096, 515, 5), (11008, 96, 11),
                                           (28672, 40, 8), (11008, 96, 1), (4544, 71, 4), (18176, 24, 2), (256, 1024, 7), (512, 8, 6),
                                           # the loop-free decode instances: single tile up to 4 tokens, tile per wave (2..16 tiles) up to 2, longer rows fall back to the loop
-                                          (4096, 33, 3), (4096, 33, 4), (8192, 40, 1), (28672, 17, 1), (28672, 17, 2), (65536, 5, 1), (69632, 6, 1), (69632, 6, 2), (3840, 9, 2)])
+                                          (4096, 33, 3), (4096, 33, 4), (8192, 40, 1), (28672, 17, 1), (28672, 17, 2), (65536, 5, 1), (69632, 6, 1), (69632, 6, 2), (3840, 9, 2),
+                                          (8192, 24, 3), (8192, 24, 4), (5120, 10, 3), (8192, 24, 2), (14336, 12, 2), (14336, 12, 3)])
 def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
     if k % O.BLCK[t]:
         pytest.skip("K-quants need K % 256 == 0")
