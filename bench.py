@@ -34,6 +34,8 @@ WORKLOADS = {
     "7b": ("llama-2-7b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),
     "70b": ("llama-2-70b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),
     "tiny": ("tiny-llama-b", "q4_k_m", "tiny-llama", "q4_k_m"),
+    "1b": ("tinyllama-1.1b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),          # the draft model on its own (use with --mode 2)
+    "70b-q3km": ("llama-2-70b", "q3_k_m", "tinyllama-1.1b", "q4_k_m"),       # the paper's Dolphin-70B Q3_K_M setup (README.md:165)
 }
 
 
