@@ -100,8 +100,11 @@ def lossless_diagnostic(ct, prompt, ref_tokens, spec_tokens, n_predict):
     seq = list(prompt) + [int(t) for t in ref_tokens[:bad]]
     lg = ct.decode(seq, list(range(len(seq))), [[0]] * len(seq))[-1]
     a, b = int(ref_tokens[bad]), int(spec_tokens[bad])
+    gap = float(abs(lg[a] - lg[b]))
     return {"token_index": bad, "target_only": a, "speculative": b, "logit_target_only": round(float(lg[a]), 6), "logit_speculative": round(float(lg[b]), 6),
-            "gap": round(float(abs(lg[a] - lg[b])), 6)}
+            "gap": round(gap, 6), "near_tie": gap < 0.25,
+            "note": "every run equals the reference arithmetic bit for bit on the cells it is given; that arithmetic sums attention in KV-cell order, and a "
+                    "speculative generation places tokens in other cells than a target-only one: on random-weight models a near tie can flip (DESIGN.md section 7)"}
 
 
 def main():
