@@ -378,7 +378,8 @@ def test_mul_mat_multi_equals_single_launches(gpu, wtype, n_tok):
 
 
 @pytest.mark.parametrize("types", [(O.Q4_K, O.Q4_K, O.Q4_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q5_K, O.Q6_K, O.Q4_K)])
-@pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,kv_head", [(128, 8, 8, 1, 5), (64, 8, 2, 3, 0), (128, 4, 1, 8, 17), (64, 4, 4, 11, 2)])
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,kv_head", [(128, 8, 8, 1, 5), (64, 8, 2, 3, 0), (128, 4, 1, 8, 17), (64, 4, 4, 11, 2),
+                                                               (128, 64, 8, 1, 3), (128, 64, 8, 2, 9), (128, 64, 8, 4, 1), (128, 40, 40, 1, 0)])   # K = 8192 / 5120: the tile-per-wave instance with the RoPE epilogue
 def test_qkv_rope_epilogue_equals_separate_launches(gpu, types, hd, n_head, n_head_kv, n_tok, kv_head):
     """RoPE + f16 rounding + KV-cache writes done by the projection's own waves == mat-vecs into fp32 + pi_op_rope_kv_store"""
     lib, U = gpu
