@@ -444,6 +444,92 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
 }
 
 // ================================================================================================================
+// Q4_0 / Q8_0 x Q8_0 at decode widths: the workgroup is 8 rows, wave w takes the groups [w*G, (w+1)*G) of those rows — every
+// group of the rows is in flight at once (8x the waves of k_mmvq_q0 below) — and keeps its (d_x*d_y, integer dot) pairs in
+// registers; the ordered fma chains (ggml-quants.c:2500-2523, 3584-3605: one fma per 32-block, blocks in order) then pass from
+// wave to wave through LDS, 4*G dependent fma per hand-over.
+// ================================================================================================================
+template <int TYPE, int NT, int G>
+__global__ void __launch_bounds__(1024) k_mmvq_q0r(const mmvq_args g) {
+    const mmvq_seg & sg = g.seg[0];
+    __shared__ float hand[NT][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int r = lane >> 3, k = lane & 7;
+    const int64_t row = (int64_t) blockIdx.x * 8 + r;
+    const bool live = row < sg.M;
+    const int64_t rowc = live ? row : sg.M - 1;
+    const int ng = g.nb, g_lo = wave * G;
+    // activations (L2-resident) are requested before the weights: vmcnt retires in order
+    uint4 yv[NT][G]; uint2 ydv[NT][G];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+            const int gg = g_lo + gi < ng ? g_lo + gi : ng - 1;
+            yv[t][gi]  = *(const uint4 *) (g.aq + ((size_t) t * ng + gg) * 128 + 16 * k);
+            ydv[t][gi] = *(const uint2 *) (g.ad + ((size_t) t * ng + gg) * 8);
+        }
+    uint4 wx[G]; uint2 wd[G];
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        const int64_t grp = rowc * ng + (g_lo + gi < ng ? g_lo + gi : ng - 1);
+        if constexpr (TYPE == PI_Q4_0) wx[gi] = *(const uint4 *) (sg.p0 + grp * 64 + 16 * (k & 3));
+        else                           wx[gi] = *(const uint4 *) (sg.p0 + grp * 128 + 16 * k);
+        wd[gi] = *(const uint2 *) (sg.p1 + grp * 8);
+    }
+    float sc[NT][G][4], pr[NT][G][4];
+#pragma unroll
+    for (int gi = 0; gi < G; gi++) {
+        const uint32_t x4[4] = { wx[gi].x, wx[gi].y, wx[gi].z, wx[gi].w };
+        int xs[4]; float dx[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if constexpr (TYPE == PI_Q4_0) xs[b] = bytes_sub((int) (((k & 4) ? (x4[b] >> 4) : x4[b]) & 0x0F0F0F0Fu), 0x08080808);
+            else                           xs[b] = (int) x4[b];
+            dx[b] = pi_h2f((uint16_t) (((b < 2 ? wd[gi].x : wd[gi].y) >> (16 * (b & 1))) & 0xffff));
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int y4[4] = { (int) yv[t][gi].x, (int) yv[t][gi].y, (int) yv[t][gi].z, (int) yv[t][gi].w };
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const float dy = pi_h2f((uint16_t) (((b < 2 ? ydv[t][gi].x : ydv[t][gi].y) >> (16 * (b & 1))) & 0xffff));
+                sc[t][gi][b] = dx[b] * dy;
+                pr[t][gi][b] = (float) pi_dot4(xs[b], y4[b], 0);
+            }
+        }
+    }
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = 0.0f;
+    for (int w = 0; w < nw; w++) {                                           // ordered part: wave w continues where wave w - 1 stopped
+        if (w == wave) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (w > 0) acc[t] = hand[t][lane];
+#pragma unroll
+                for (int gi = 0; gi < G; gi++)
+                    if (g_lo + gi < ng) {
+#pragma unroll
+                        for (int b = 0; b < 4; b++) acc[t] = fmaf(sc[t][gi][b], pr[t][gi][b], acc[t]);
+                    }
+                hand[t][lane] = acc[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave != nw - 1) return;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float v = hsum8_lanes(acc[t]);
+        if (live && k == 0) {
+            const int64_t o = (int64_t) t * sg.M + row;
+            sg.out[o] = sg.res ? sg.res[o] + v : v;
+        }
+    }
+}
+
+// ================================================================================================================
 // Q4_0 / Q8_0 x Q8_0: lane (r, k) walks groups of four 32-blocks
 // ================================================================================================================
 template <int TYPE, int NT>
@@ -598,14 +684,35 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
     // rocprofv3 reports as the duration); events recorded around a launch would add the dispatch gap (~3 us) to every sample
     if (sink) sample = false;                                  // being captured into a graph: no sampling (events of a graph cannot be read back)
     if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
-        // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
         const int64_t M = g.seg[0].M;
-        int wpb = 1;
-        while (wpb < 4 && M / (8 * wpb * 2) >= 512) wpb *= 2;
-        const unsigned grid = (unsigned) ((M + 8 * wpb - 1) / (8 * wpb));
-        const size_t lds = (size_t) NT * MMVQ_TILE * (128 + 8);
-        if (sample) hipExtLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
-        else        hipLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+        bool launched = false;
+        if constexpr (NT <= 2) {                                   // decode widths: one wave per range of groups (k_mmvq_q0r)
+            static const bool no_r = getenv("PI_MMVQ_NO_Q0R") != nullptr;      // tuning / tests
+            const unsigned grid = (unsigned) ((M + 7) / 8);
+            auto go_r = [&](auto gc) {                                 // G groups per wave, at most 16 waves per workgroup
+                constexpr int G = decltype(gc)::value;
+                const int nwv = (g.nb + G - 1) / G;
+                if (sample) hipExtLaunchKernelGGL((k_mmvq_q0r<TYPE, NT, G>), dim3(grid), dim3(64 * nwv), 0, stream, ea, eb, 0, g);
+                else        hipLaunchKernelGGL((k_mmvq_q0r<TYPE, NT, G>), dim3(grid), dim3(64 * nwv), 0, stream, g);
+                launched = true;
+            };
+            if (!no_r && g.nb >= 8) {                                  // (registers: 8 / 12 groups per wave only fit at NT = 1)
+                if (g.nb <= 64) go_r(std::integral_constant<int, 4>{});
+                else if constexpr (NT == 1) {
+                    if (g.nb <= 128) go_r(std::integral_constant<int, 8>{});
+                    else if (g.nb <= 192) go_r(std::integral_constant<int, 12>{});
+                }
+            }
+        }
+        if (!launched) {
+            // waves per workgroup: keep >= ~512 workgroups for the 256 CUs when the matrix is tall enough
+            int wpb = 1;
+            while (wpb < 4 && M / (8 * wpb * 2) >= 512) wpb *= 2;
+            const unsigned grid = (unsigned) ((M + 8 * wpb - 1) / (8 * wpb));
+            const size_t lds = (size_t) NT * MMVQ_TILE * (128 + 8);
+            if (sample) hipExtLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
+            else        hipLaunchKernelGGL((k_mmvq_q0<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+        }
     } else {
         // rows per wave: pairs (row, token) share the chain phase (8 per pass) and the activation registers, so more rows
         // amortise them; fewer rows give more waves.  Keep >= ~2048 waves when the matrices allow.  PI_MMVQ_R overrides.
