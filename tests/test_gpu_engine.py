@@ -155,6 +155,29 @@ def test_adaptive_draft_pause_is_lossless_and_the_draft_catches_up(LL, window, p
     mt.free(); md.free()
 
 
+def test_cpp_llama_h_caller_reproduces_the_reference(tmp_path):
+    """examples/speculative_min.cpp — a C++11 program that sees nothing but include/llama.h (+ pipeinfer.h) and the shared library, in
+    the style of the reference's examples/speculative: llama_batch_init / llama_decode / llama_get_logits_ith / llama_sample_token_greedy,
+    then the asynchronous speculative driver.  Both token lines must be the reference's greedy continuation of the fixture."""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "speculative_min")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "speculative_min.cpp"),
+                    "-L" + os.path.join(root, "pipeinfer_amd"), "-lpipeinfer_amd", "-Wl,-rpath," + os.path.join(root, "pipeinfer_amd"), "-o", exe], check=True)
+    tgt, dft = "tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"
+    prompt, want = greedy_reference(tgt, 8, 24)
+    r = subprocess.run([exe, os.path.join(GOLD, tgt + ".gguf"), os.path.join(GOLD, dft + ".gguf"), "24"] + [str(t) for t in prompt],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = {l.split(":")[0]: l.split(":")[1].split() for l in r.stdout.splitlines() if ":" in l}
+    assert [int(t) for t in lines["plain"]] == want, (lines, want)
+    assert [int(t) for t in lines["spec"]] == want, (lines, want)
+    stats = [l for l in r.stdout.splitlines() if l.startswith("spec_runs")][0].split()
+    assert int(stats[1]) > 0                                      # speculation really ran
+
+
 def test_pipeinfer_driver_lossless_under_timing_jitter(LL):
     """the driver's control flow depends on which run finishes first, so repeat one configuration with fresh contexts
     (this caught target and draft contexts racing on a shared top-k scratch buffer)."""
