@@ -24,7 +24,7 @@ extern "C" {
 #define ORACLE_API __attribute__((visibility("default")))
 
 // ggml type ids (ggml.h enum ggml_type)
-enum { OT_F32 = 0, OT_F16 = 1, OT_Q4_0 = 2, OT_Q8_0 = 8, OT_Q3_K = 11, OT_Q4_K = 12, OT_Q5_K = 13, OT_Q6_K = 14, OT_Q8_K = 15 };
+enum { OT_F32 = 0, OT_F16 = 1, OT_Q4_0 = 2, OT_Q8_0 = 8, OT_Q2_K = 10, OT_Q3_K = 11, OT_Q4_K = 12, OT_Q5_K = 13, OT_Q6_K = 14, OT_Q8_K = 15 };
 
 #define OQK   32
 #define OQK_K 256
@@ -35,6 +35,7 @@ typedef struct { uint16_t d; int8_t qs[32]; }                                   
 typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; }          oblk_q4_K;  // :116-122
 typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } oblk_q5_K; // :138-145
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } oblk_q6_K;  // :152-158
+typedef struct { uint8_t scales[16]; uint8_t qs[64]; uint16_t d; uint16_t dmin; } oblk_q2_K;                // ggml-quants.h:74-79 (84 bytes)
 typedef struct { uint8_t hmask[32]; uint8_t qs[64]; uint8_t scales[12]; uint16_t d; } oblk_q3_K;   // ggml-quants.h:95-100 (110 bytes)
 typedef struct { float d; int8_t qs[256]; int16_t bsums[16]; }                     oblk_q8_K;  // :161-166
 #pragma pack(pop)

@@ -54,7 +54,7 @@ int o_blck_size(int type) {
     switch (type) {
         case OT_F32: case OT_F16: return 1;
         case OT_Q4_0: case OT_Q8_0: return OQK;
-        case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: case OT_Q8_K: return OQK_K;
+        case OT_Q2_K: case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: case OT_Q8_K: return OQK_K;
     }
     return 0;
 }
@@ -64,7 +64,7 @@ int o_type_size(int type) {
         case OT_F32: return 4; case OT_F16: return 2;
         case OT_Q4_0: return sizeof(oblk_q4_0); case OT_Q8_0: return sizeof(oblk_q8_0);
         case OT_Q4_K: return sizeof(oblk_q4_K); case OT_Q5_K: return sizeof(oblk_q5_K);
-        case OT_Q6_K: return sizeof(oblk_q6_K); case OT_Q8_K: return sizeof(oblk_q8_K); case OT_Q3_K: return sizeof(oblk_q3_K);
+        case OT_Q6_K: return sizeof(oblk_q6_K); case OT_Q8_K: return sizeof(oblk_q8_K); case OT_Q3_K: return sizeof(oblk_q3_K); case OT_Q2_K: return sizeof(oblk_q2_K);
     }
     return 0;
 }
@@ -76,7 +76,7 @@ int o_vec_dot_type(int type) {
     switch (type) {
         case OT_F32: return OT_F32; case OT_F16: return OT_F16;
         case OT_Q4_0: case OT_Q8_0: return OT_Q8_0;
-        case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: return OT_Q8_K;
+        case OT_Q2_K: case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: return OT_Q8_K;
     }
     return -1;
 }
@@ -158,6 +158,9 @@ static inline int q6k_at(const oblk_q6_K * b, int e) {                        //
     return ((g & 2) ? lo >> 4 : lo & 0xF) | (((b->qh[32 * n + l] >> (2 * g)) & 3) << 4);
 }
 
+// Q2_K (ggml-quants.c:1495-1540): sixteen bytes of (4-bit scale | 4-bit min << 4), 2-bit weights 0..3: x = d*sc*q - dmin*m
+static inline int q2k_at(const oblk_q2_K * b, int e) { const int n = e >> 7, j = (e >> 5) & 3, l = e & 31; return (b->qs[32 * n + l] >> (2 * j)) & 3; }
+
 // Q3_K (ggml-quants.c:1711-1759): sixteen 6-bit scales packed in 12 bytes (stored + 32), weight = (2 low bits | high bit << 2) - 4
 static inline void q3k_scales(const oblk_q3_K * b, int8_t * sc) {
     const uint32_t kmask1 = 0x03030303, kmask2 = 0x0f0f0f0f;
@@ -219,6 +222,17 @@ void o_dequantize_row(int type, const void * vx, float * y, int k) {
                 }
             }
         } break;
+        case OT_Q2_K: {
+            const oblk_q2_K * x = vx;
+            for (int i = 0; i < k / OQK_K; i++) {
+                const float d = o_fp16_to_fp32(x[i].d), min = o_fp16_to_fp32(x[i].dmin);
+                for (int e = 0; e < OQK_K; e++) {
+                    const uint8_t sc = x[i].scales[e >> 4];
+                    const float dl = d * (sc & 0xF), ml = min * (sc >> 4);
+                    *y++ = dl * q2k_at(&x[i], e) - ml;
+                }
+            }
+        } break;
         case OT_Q3_K: {
             const oblk_q3_K * x = vx;
             for (int i = 0; i < k / OQK_K; i++) {
@@ -266,6 +280,11 @@ void o_block_isums(int type, const void * xb, const void * yb, int32_t * isum, i
     if (type == OT_Q6_K) {
         const oblk_q6_K * x = xb;
         for (int e = 0; e < OQK_K; e++) isum[(e & 31) >> 2] += x->scales[e >> 4] * (q6k_at(x, e) - 32) * y->qs[e];
+        return;
+    }
+    if (type == OT_Q2_K) {                                                       // ggml-quants.c:3708-3771; *msum is unused: the mins go lane by lane (o_vec_dot)
+        const oblk_q2_K * x = xb;
+        for (int e = 0; e < OQK_K; e++) isum[(e & 31) >> 2] += (x->scales[e >> 4] & 0xF) * q2k_at(x, e) * y->qs[e];
         return;
     }
     if (type == OT_Q3_K) {                                                       // ggml-quants.c:4443-4533: same lane grouping, scale of element e = sc[e >> 4]
@@ -320,6 +339,20 @@ float o_vec_dot(int type, int n, const void * vx, const void * vy) {
     }
     const int nb = n / OQK_K;
     const oblk_q8_K * y = vy;
+    if (type == OT_Q2_K) {   // per block: acc = fmadd(dmin, cvt(madd_epi16(mins, bsums)), acc) — lane k = m[2k]*bs[2k] + m[2k+1]*bs[2k+1] — THEN acc = fmadd(d, cvt(sumi), acc)
+        const oblk_q2_K * x = vx;
+        for (int i = 0; i < nb; i++) {
+            int32_t is[8], ms;
+            const float d = y[i].d * o_fp16_to_fp32(x[i].d), dmin = -y[i].d * o_fp16_to_fp32(x[i].dmin);
+            for (int k = 0; k < 8; k++) {
+                const int32_t prod = (x[i].scales[2 * k] >> 4) * y[i].bsums[2 * k] + (x[i].scales[2 * k + 1] >> 4) * y[i].bsums[2 * k + 1];
+                acc[k] = fmaf(dmin, (float) prod, acc[k]);
+            }
+            o_block_isums(type, &x[i], &y[i], is, &ms);
+            for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+        }
+        return hsum8(acc);
+    }
     if (type == OT_Q3_K) {                                                       // acc = fmadd(broadcast(d), cvt(sumi), acc) per block, hsum_float_8 (:4450-4533)
         const oblk_q3_K * x = vx;
         for (int i = 0; i < nb; i++) {

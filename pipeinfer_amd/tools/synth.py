@@ -42,14 +42,14 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
     hd = n_embd // n_head
     n_gqa = hd * n_head_kv
     ftype = ftype.lower()
-    base = {"q4_0": G.T_Q4_0, "q8_0": G.T_Q8_0, "q3_k_m": G.T_Q3_K, "q4_k_m": G.T_Q4_K, "q4_k_s": G.T_Q4_K, "q5_k_m": G.T_Q5_K, "q5_k_s": G.T_Q5_K,
+    base = {"q4_0": G.T_Q4_0, "q8_0": G.T_Q8_0, "q2_k": G.T_Q2_K, "q3_k_m": G.T_Q3_K, "q4_k_m": G.T_Q4_K, "q4_k_s": G.T_Q4_K, "q5_k_m": G.T_Q5_K, "q5_k_s": G.T_Q5_K,
             "q6_k": G.T_Q6_K, "f16": G.T_F16, "f32": G.T_F32}[ftype]
-    kq = ftype.startswith(("q3_k", "q4_k", "q5_k", "q6_k"))
+    kq = ftype.startswith(("q2_k", "q3_k", "q4_k", "q5_k", "q6_k"))
     is_70b = arch == "llama" and n_layer == 80 and n_head != n_head_kv    # llama.cpp MODEL_70B detection (n_layer 80)
 
     def fix(t, nx):
         # K-quants need ne0 % 256 == 0; fallbacks per llama.cpp:7985-8003 that stay inside our kernel set
-        if t in (G.T_Q3_K, G.T_Q4_K, G.T_Q5_K, G.T_Q6_K) and nx % 256 != 0:
+        if t in (G.T_Q2_K, G.T_Q3_K, G.T_Q4_K, G.T_Q5_K, G.T_Q6_K) and nx % 256 != 0:
             return G.T_Q8_0 if t == G.T_Q6_K else G.T_Q4_0
         return t
 
@@ -62,7 +62,9 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
 
     def v_type(i):
         t = base
-        if ftype == "q3_k_m":                                           # llama.cpp:7919-7921
+        if ftype == "q2_k":                                             # llama.cpp:7918
+            t = G.T_Q3_K
+        elif ftype == "q3_k_m":                                         # llama.cpp:7919-7921
             t = G.T_Q5_K if i < 2 else G.T_Q4_K
         elif ftype in ("q4_k_m", "q5_k_m") and use_more_bits(i, n_layer):
             t = G.T_Q6_K
@@ -74,7 +76,9 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
 
     def down_type(i):
         t = base
-        if ftype == "q3_k_m":                                           # llama.cpp:7937-7941
+        if ftype == "q2_k":                                             # llama.cpp:7936
+            t = G.T_Q3_K
+        elif ftype == "q3_k_m":                                         # llama.cpp:7937-7941
             t = G.T_Q5_K if i < 2 else (G.T_Q4_K if arch != "falcon" or use_more_bits(i, n_layer) else G.T_Q3_K)
         elif ftype == "q4_k_m":
             if arch == "falcon":
@@ -97,11 +101,11 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
                 (p + "attn_q.weight", (n_embd, n_embd), fix(base, n_embd), "proj"),
                 (p + "attn_k.weight", (n_embd, n_gqa), fix(base, n_embd), "proj"),
                 (p + "attn_v.weight", (n_embd, n_gqa), fix(v_type(i) if kq else base, n_embd), "proj"),
-                (p + "attn_output.weight", (n_embd, n_embd), fix(G.T_Q4_K if ftype == "q3_k_m" else base, n_embd), "out"),     # llama.cpp:7958-7961
+                (p + "attn_output.weight", (n_embd, n_embd), fix(G.T_Q4_K if ftype == "q3_k_m" else (G.T_Q3_K if ftype == "q2_k" else base), n_embd), "out"),     # llama.cpp:7958-7961
                 (p + "ffn_norm.weight", (n_embd,), G.T_F32, "ones"),
-                (p + "ffn_gate.weight", (n_embd, n_ff), fix(base, n_embd), "proj"),
+                (p + "ffn_gate.weight", (n_embd, n_ff), fix(G.T_Q3_K if ftype == "q2_k" else base, n_embd), "proj"),       # llama.cpp:7976-7978
                 (p + "ffn_down.weight", (n_ff, n_embd), fix(down_type(i) if kq else base, n_ff), "out"),
-                (p + "ffn_up.weight", (n_embd, n_ff), fix(base, n_embd), "proj"),
+                (p + "ffn_up.weight", (n_embd, n_ff), fix(G.T_Q3_K if ftype == "q2_k" else base, n_embd), "proj"),
             ]
         else:
             plan += [(p + "attn_norm.weight", (n_embd,), G.T_F32, "ones"), (p + "attn_norm.bias", (n_embd,), G.T_F32, "zeros")]
@@ -164,6 +168,14 @@ def random_blocks(ttype, n_elem, rng, std):
         out[:, 0:2] = _f16(d).view(np.uint8).reshape(nb, 2)
         out[:, 2:4] = _f16(d * ratio).view(np.uint8).reshape(nb, 2)
         out[:, 4:16] = _pack_k4_scales(sc, m)
+    elif ttype == G.T_Q2_K:
+        # scales 16 (4-bit scale | 4-bit min << 4) | qs 64 | d | dmin: x = d*sc*q - dmin*m with q in 0..3; mins centred on 1.5 scales
+        sc = 4 + out[:, 0:16] % 12                                                              # 4..15
+        m = np.clip(np.rint(1.5 * sc), 0, 15).astype(np.uint8)
+        out[:, 0:16] = sc | (m << 4)
+        d = std / (9.5 * 1.118) * jitter                                                         # q - 1.5 has std 1.118
+        out[:, 80:82] = _f16(d).view(np.uint8).reshape(nb, 2)
+        out[:, 82:84] = _f16(d).view(np.uint8).reshape(nb, 2)
     elif ttype == G.T_Q3_K:
         # hmask 32 | qs 64 | scales 12 | d 2: random 3-bit weights (-4..3, std 2.29); the sixteen stored scales become 32 +- (4..19)
         mag = 4 + out[:, 96:108].astype(np.int32) % 16                                          # reuse the random bytes: 12 per block
@@ -209,6 +221,23 @@ def quantize_simple(ttype, x):
         out = np.zeros((b.shape[0], 18), np.uint8)
         out[:, 0:2] = _f16(d).view(np.uint8).reshape(-1, 2)
         out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+        return out.reshape(-1)
+    if ttype == G.T_Q2_K:
+        b = x.reshape(-1, 16, 16)                                          # [nb, 16 groups, 16]
+        lo, hi = b.min(2), b.max(2)
+        lo = np.minimum(lo, 0.0)                                           # x = scale*q - min with min >= 0
+        gs = (hi - lo) / 3.0
+        d = np.where(gs.max(1) == 0, 1e-8, gs.max(1) / 15.0)
+        dm = np.where((-lo).max(1) == 0, 1e-8, (-lo).max(1) / 15.0)
+        sc = np.clip(np.rint(gs / d[:, None]), 1, 15).astype(np.int32)
+        m = np.clip(np.rint(-lo / dm[:, None]), 0, 15).astype(np.int32)
+        q = np.clip(np.rint((b + (dm[:, None] * m)[:, :, None]) / (d[:, None] * sc)[:, :, None]), 0, 3).astype(np.uint8).reshape(-1, 2, 4, 32)
+        nb = q.shape[0]
+        out = np.zeros((nb, 84), np.uint8)
+        out[:, 0:16] = (sc | (m << 4)).astype(np.uint8)
+        out[:, 16:80] = (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).reshape(nb, 64)
+        out[:, 80:82] = _f16(d).view(np.uint8).reshape(nb, 2)
+        out[:, 82:84] = _f16(dm).view(np.uint8).reshape(nb, 2)
         return out.reshape(-1)
     if ttype == G.T_Q3_K:
         b = x.reshape(-1, 16, 16)                                          # [nb, 16 groups, 16]

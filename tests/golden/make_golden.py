@@ -24,6 +24,7 @@ MODELS = [  # (file stem, spec, ftype, seed)
     ("tiny_falcon_q4_0", "tiny-falcon", "q4_0", 14),           # 7B-style: MQA, single norm, Q8_0 head
     ("tiny_falcon40_q4_k_m", "tiny-falcon40", "q4_k_m", 15),   # 40B-style: GQA, two norms, Q5_K qkv
     ("tiny_llama_q3_k_m", "tiny-llama", "q3_k_m", 16),         # Q3_K / Q4_K / Q5_K / Q6_K mixture of llama.cpp:7919-7961
+    ("tiny_llama_q2_k", "tiny-llama", "q2_k", 17),             # Q2_K / Q3_K / Q6_K mixture (llama.cpp:7918, 7936, 7958, 7976)
 ]
 
 
@@ -101,23 +102,24 @@ def kernel_vectors():
     np.savez_compressed(os.path.join(HERE, "kernels.npz"), **out)
 
 
-def kernel_vectors_q3k():
-    """same vectors as kernel_vectors() for Q3_K, in a file of their own so that kernels.npz stays byte-identical"""
+def kernel_vectors_q3k(t=None, fname="kernels_q3k.npz"):
+    """same vectors as kernel_vectors() for Q3_K (and Q2_K), in files of their own so that kernels.npz stays byte-identical"""
     r = O.Impl("ref")
     q = ref_quantizer()
     out = {}
-    k, t = 1024, O.Q3_K
+    k, t = 1024, (O.Q3_K if t is None else t)
     rng = np.random.default_rng(100 + t)
     w = (rng.standard_normal((6, k)) * 0.05).astype(np.float32)
     blocks = q(t, w).reshape(6, -1)
     act = np.stack([synth_signal(k, s + t) for s in range(3)])
     qa = np.stack([r.quantize_act(O.VEC_DOT_TYPE[t], a) for a in act])
-    out["q3_K_blocks"] = blocks
-    out["q3_K_act"] = act
-    out["q3_K_qact"] = qa
-    out["q3_K_dots"] = np.array([[r.vec_dot(t, k, blocks[i], qa[j]) for i in range(6)] for j in range(3)], np.float32)
-    out["q3_K_deq"] = np.stack([r.dequantize(t, b, k) for b in blocks])
-    np.savez_compressed(os.path.join(HERE, "kernels_q3k.npz"), **out)
+    name = O.TYPE_NAMES[t]
+    out[f"{name}_blocks"] = blocks
+    out[f"{name}_act"] = act
+    out[f"{name}_qact"] = qa
+    out[f"{name}_dots"] = np.array([[r.vec_dot(t, k, blocks[i], qa[j]) for i in range(6)] for j in range(3)], np.float32)
+    out[f"{name}_deq"] = np.stack([r.dequantize(t, b, k) for b in blocks])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
 def model_vectors(only=None):
@@ -157,7 +159,11 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
         model_vectors(only=["tiny_llama_q3_k_m"])
+    elif sys.argv[1:] == ["q2k"]:
+        kernel_vectors_q3k(O.Q2_K, "kernels_q2k.npz")
+        model_vectors(only=["tiny_llama_q2_k"])
     else:
         kernel_vectors()
         kernel_vectors_q3k()
+        kernel_vectors_q3k(O.Q2_K, "kernels_q2k.npz")
         model_vectors()

@@ -10,7 +10,7 @@ from tests import scenarios as S
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 K = np.load(os.path.join(GOLD, "kernels.npz"))
-MODELS = ["tiny_llama_q4_k_m", "tiny_llama_q4_0", "tiny_llama_b_q4_k_m", "tiny_falcon_q4_0", "tiny_falcon40_q4_k_m", "tiny_llama_q3_k_m"]
+MODELS = ["tiny_llama_q4_k_m", "tiny_llama_q4_0", "tiny_llama_b_q4_k_m", "tiny_falcon_q4_0", "tiny_falcon40_q4_k_m", "tiny_llama_q3_k_m", "tiny_llama_q2_k"]
 
 
 def bits(a):
@@ -18,13 +18,14 @@ def bits(a):
 
 
 K3 = np.load(os.path.join(GOLD, "kernels_q3k.npz"))
+K2 = np.load(os.path.join(GOLD, "kernels_q2k.npz"))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K])
 def test_quant_golden(t):
     o = O.Impl("oracle")
     name = O.TYPE_NAMES[t]
-    blocks, act, qact, dots, deq = ((K3 if t == O.Q3_K else K)[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
+    blocks, act, qact, dots, deq = ({O.Q3_K: K3, O.Q2_K: K2}.get(t, K)[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
     k = act.shape[1]
     for j in range(act.shape[0]):
         assert np.array_equal(o.quantize_act(O.VEC_DOT_TYPE[t], act[j]), qact[j])          # bytes identical
@@ -67,7 +68,7 @@ def test_model_scenarios_golden(stem):
     g = np.load(os.path.join(GOLD, stem + ".npz"))
     path = os.path.join(GOLD, stem + ".gguf")
     m = O.OracleModel(path, n_ctx=128, max_seq=8)
-    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16}[stem]
+    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17}[stem]
     outs = S.run_scenario(S.scenario_spec_like(m.n_vocab, seed=seed), m)
     for i, lg in enumerate(outs):
         assert np.allclose(lg, g[f"spec_like_{i}"], rtol=0, atol=1e-5), (stem, i, np.abs(lg - g[f"spec_like_{i}"]).max())

@@ -9,7 +9,7 @@ from tests import oracle_lib as O
 
 pytestmark = pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
 
-QTYPES = [O.Q4_0, O.Q8_0, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
+QTYPES = [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
 
 
 def synth(n, seed):
