@@ -29,7 +29,7 @@ extern "C" {
 #define PI_API __attribute__((visibility("default")))
 
 /* ggml tensor type ids (ggml.h enum ggml_type) */
-enum pi_type { PI_F32 = 0, PI_F16 = 1, PI_Q4_0 = 2, PI_Q8_0 = 8, PI_Q3_K = 11, PI_Q4_K = 12, PI_Q5_K = 13, PI_Q6_K = 14, PI_Q8_K = 15 };
+enum pi_type { PI_F32 = 0, PI_F16 = 1, PI_Q4_0 = 2, PI_Q8_0 = 8, PI_Q2_K = 10, PI_Q3_K = 11, PI_Q4_K = 12, PI_Q5_K = 13, PI_Q6_K = 14, PI_Q8_K = 15 };
 
 typedef struct pi_weight pi_weight;    /* a weight matrix resident in HBM in the kernel-friendly layout */
 

@@ -16,6 +16,7 @@ size_t type_row_size(int type, int64_t ne0) {
         case 1:  return (size_t) ne0 * 2;
         case 2:  return (size_t) ne0 / 32 * 18;
         case 8:  return (size_t) ne0 / 32 * 34;
+        case 10: return (size_t) ne0 / 256 * 84;
         case 11: return (size_t) ne0 / 256 * 110;
         case 12: return (size_t) ne0 / 256 * 144;
         case 13: return (size_t) ne0 / 256 * 176;

@@ -46,6 +46,15 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
             const float d1 = d * sc, m1 = mn * m;
             y = d1 * q - m1;
         } break;
+        case PI_Q2_K: {                                                                          // dequantize_row_q2_K, ggml-quants.c:1495-1540
+            const int64_t b = row * w.nb + (e >> 8);
+            const int ee = (int) (e & 255), n = ee >> 7, j = (ee >> 5) & 3, l = ee & 31, c = l >> 3, h = (l >> 2) & 1;
+            const int q = (w.p0[b * 64 + 16 * c + 8 * n + 4 * h + (l & 3)] >> (2 * j)) & 3;        // qs[32n + l]
+            const uint8_t scb = w.p1[b * 16 + (ee >> 4)];
+            const uint32_t dd = ((const uint32_t *) w.p2)[b];
+            const float dl = pi_h2f((uint16_t) (dd & 0xffff)) * (float) (scb & 0xF), ml = pi_h2f((uint16_t) (dd >> 16)) * (float) (scb >> 4);
+            y = dl * (float) q - ml;
+        } break;
         case PI_Q3_K: {                                                                          // dequantize_row_q3_K, ggml-quants.c:1711-1759
             const int64_t b = row * w.nb + (e >> 8);
             const int ee = (int) (e & 255), n = ee >> 7, j = (ee >> 5) & 3, l = ee & 31, c = l >> 3, h = (l >> 2) & 1;

@@ -85,7 +85,7 @@ static __device__ __forceinline__ float hsum8_lanes(float a) {
 #define KQ_TB 16                // blocks per tile
 #define MMVQ_ST_NT 4            // widest batch that gets the loop-free (single-tile / tile-per-wave) instances
 template <int TYPE> struct kq_raw { uint4 hdr, qa, qb, h; uint32_t d; };     // one lane's share of a block (k = 2c, 2c+1)
-template <int TYPE> constexpr bool kq_has_mins = TYPE == PI_Q4_K || TYPE == PI_Q5_K;       // Q6_K and Q3_K are scale-only (symmetric) formats
+template <int TYPE> constexpr bool kq_has_mins = TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q2_K;   // Q6_K and Q3_K are scale-only (symmetric) formats
 
 template <int TYPE>
 static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk, int c, kq_raw<TYPE> & o) {
@@ -96,6 +96,10 @@ static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk,
         o.qa  = *(const uint4 *) (p + QOFF + 32 * c);
         o.qb  = *(const uint4 *) (p + QOFF + 32 * c + 16);
         if constexpr (TYPE == PI_Q5_K) { const uint2 hh = *(const uint2 *) (p + 16 + 8 * c); o.h.x = hh.x; o.h.y = hh.y; }
+    } else if constexpr (TYPE == PI_Q2_K) {                                  // runtime.hip: k_repack_q2_K
+        o.qa  = *(const uint4 *) (w.p0 + (size_t) blk * 64 + 16 * c);        // qs: half 0 (elements 8c.., 8c+4..), half 1 (same)
+        o.hdr = *(const uint4 *) (w.p1 + (size_t) blk * 16);                 // sixteen (scale | min << 4)
+        o.d   = ((const uint32_t *) w.p2)[blk];                              // d | dmin << 16
     } else if constexpr (TYPE == PI_Q3_K) {                                  // runtime.hip: k_repack_q3_K
         const uint8_t * p = w.p0 + (size_t) blk * 96;
         o.qa  = *(const uint4 *) (p + 16 * c);                               // qs: half 0 (elements 8c.., 8c+4..), half 1 (same)
@@ -110,6 +114,12 @@ static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk,
         o.hdr = *(const uint4 *) (w.p1 + (size_t) blk * 16);
         o.d   = ((const uint16_t *) w.p2)[blk];
     }
+}
+
+// Q2_K: group g = 4j + s is (qs dword of half j >> 2s) & 3 per byte, unsigned 0..3 (ggml-quants.c:3745-3748)
+static __device__ __forceinline__ void kq_unpack_q2(uint32_t q_half0, uint32_t q_half1, int * wq) {
+#pragma unroll
+    for (int g = 0; g < 8; g++) wq[g] = (int) (((g < 4 ? q_half0 : q_half1) >> (2 * (g & 3))) & 0x03030303u);
 }
 
 // Q3_K: group g = 4j + s of the block is (qs dword of half j >> 2s) & 3 per byte, | high bit g of the hmask dword << 2, minus 4
@@ -153,7 +163,7 @@ static __device__ __forceinline__ void kq_unpack_w(const uint4 qv, uint32_t h0, 
 template <int TYPE, int NP> struct kq_lds {                                  // floats per wave
     static constexpr int SSTR = KQ_TB * 8 + 8, PSTR = KQ_TB + 1, MSTR = KQ_TB * 4 + 4;      // strides padded to spread banks
     static constexpr int S = 0, P = S + NP * SSTR, SM = P + NP * PSTR,
-                         PM = SM + (TYPE == PI_Q4_K ? NP * MSTR : TYPE == PI_Q5_K ? NP * PSTR : 0),
+                         PM = SM + (TYPE == PI_Q4_K ? NP * MSTR : TYPE == PI_Q5_K ? NP * PSTR : TYPE == PI_Q2_K ? NP * SSTR : 0),
                          FLOATS = (PM + (kq_has_mins<TYPE> ? NP * PSTR : 0) + 3) & ~3;
 };
 
@@ -177,7 +187,8 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
     a.bsA = a.bsB = 0;
     if constexpr (kq_has_mins<TYPE>) {                                       // int16 pair sums like _mm_hadd_epi16
         const short4 bs = *(const short4 *) (g.abs_ + ab * 32 + 8 * c);
-        a.bsA = (int) (short) (bs.x + bs.y); a.bsB = (int) (short) (bs.z + bs.w);
+        if constexpr (TYPE == PI_Q2_K) { a.bsA = (int) (((uint32_t) (uint16_t) bs.x) | ((uint32_t) (uint16_t) bs.y << 16)); a.bsB = (int) (((uint32_t) (uint16_t) bs.z) | ((uint32_t) (uint16_t) bs.w << 16)); }   // the four raw sums
+        else { a.bsA = (int) (short) (bs.x + bs.y); a.bsB = (int) (short) (bs.z + bs.w); }
     }
 }
 
@@ -229,6 +240,7 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
                 for (int ci = 0; ci < NIT; ci++) {
                     const int p = ci * 8 + s;
                     if (NP % 8 == 0 || p < NP) {
+                        if constexpr (TYPE == PI_Q2_K) acc[ci] = fmaf(xt[L::PM + p * L::PSTR + bb], xt[L::SM + p * L::SSTR + bb * 8 + k], acc[ci]);   // the mins go into the same chain, first
                         acc[ci] = fmaf(xt[L::P + p * L::PSTR + bb], xt[L::S + p * L::SSTR + bb * 8 + k], acc[ci]);
                         if constexpr (TYPE == PI_Q4_K)      accm[ci] = fmaf(xt[L::PM + p * L::PSTR + bb], xt[L::SM + p * L::MSTR + bb * 4 + (k & 3)], accm[ci]);
                         else if constexpr (TYPE == PI_Q5_K) accm[ci] = accm[ci] + xt[L::PM + p * L::PSTR + bb] * xt[L::SM + p * L::PSTR + bb];   // summs += dmin * hsum (mul, then add)
@@ -307,6 +319,17 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
                             const uint32_t mw = (c & 2) ? mB : mA;               // this lane is mins lane c: m[2c], m[2c+1]
                             const int sh = (c & 1) * 16;
                             m0 = (int) ((mw >> sh) & 0xff); m1 = (int) ((mw >> (sh + 8)) & 0xff);
+                        } else if constexpr (TYPE == PI_Q2_K) {
+                            dx = pi_h2f((uint16_t) (raw[i].d & 0xffff)); dminx = pi_h2f((uint16_t) (raw[i].d >> 16));
+                            const uint32_t s4[4] = { raw[i].hdr.x, raw[i].hdr.y, raw[i].hdr.z, raw[i].hdr.w };
+                            const int hi = c >> 1;
+    #pragma unroll
+                            for (int j = 0; j < 8; j++) {                        // scale of group j for these lanes: low nibble of byte 2j + hi
+                                const int idx = 8 * (j >> 2) + 2 * (j & 3);
+                                sc[j] = (int) ((s4[idx >> 2] >> (8 * ((idx & 3) + hi))) & 0xf);
+                            }
+                            const uint32_t mw = ((c == 0 ? s4[0] : c == 1 ? s4[1] : c == 2 ? s4[2] : s4[3]) >> 4) & 0x0f0f0f0fu;      // mins 4c..4c+3
+                            m0 = (int) mw;                                       // (used byte-wise below)
                         } else {
                             dx = pi_h2f((uint16_t) raw[i].d);
                             const uint32_t s4[4] = { raw[i].hdr.x, raw[i].hdr.y, raw[i].hdr.z, raw[i].hdr.w };
@@ -320,6 +343,9 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
                         if constexpr (TYPE == PI_Q3_K) {
                             kq_unpack_q3(raw[i].qa.x, raw[i].qa.z, raw[i].h.x, wq[0]);
                             kq_unpack_q3(raw[i].qa.y, raw[i].qa.w, raw[i].h.y, wq[1]);
+                        } else if constexpr (TYPE == PI_Q2_K) {
+                            kq_unpack_q2(raw[i].qa.x, raw[i].qa.z, wq[0]);
+                            kq_unpack_q2(raw[i].qa.y, raw[i].qa.w, wq[1]);
                         } else {
                             kq_unpack_w<TYPE>(raw[i].qa, raw[i].h.x, TYPE == PI_Q6_K ? raw[i].h.y : 0u, wq[0]);
                             kq_unpack_w<TYPE>(raw[i].qb, TYPE == PI_Q6_K ? raw[i].h.z : raw[i].h.y, TYPE == PI_Q6_K ? raw[i].h.w : 0u, wq[1]);
@@ -336,7 +362,15 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
                                     *(float2 *) (xs + L::S + p * L::SSTR + b * 8 + 2 * c) = make_float2((float) sumi0, (float) sumi1);
                                     if (c == 0) xs[L::P + p * L::PSTR + b] = a.dy * dx;
                                 }
-                                if constexpr (kq_has_mins<TYPE>) {
+                                if constexpr (TYPE == PI_Q2_K) {
+                                    // madd_epi16(mins, bsums): lane k = m[2k]*bs[2k] + m[2k+1]*bs[2k+1]; this quad lane holds k = 2c, 2c+1
+                                    const int p0 = __mul24(ub((uint32_t) m0, 0), (int) (short) (a.bsA & 0xffff)) + __mul24(ub((uint32_t) m0, 1), (int) (short) ((uint32_t) a.bsA >> 16));
+                                    const int p1 = __mul24(ub((uint32_t) m0, 2), (int) (short) (a.bsB & 0xffff)) + __mul24(ub((uint32_t) m0, 3), (int) (short) ((uint32_t) a.bsB >> 16));
+                                    if (valid) {
+                                        *(float2 *) (xs + L::SM + p * L::SSTR + b * 8 + 2 * c) = make_float2((float) p0, (float) p1);
+                                        if (c == 0) xs[L::PM + p * L::PSTR + b] = -a.dy * dminx;
+                                    }
+                                } else if constexpr (kq_has_mins<TYPE>) {
                                     // mins: prod[c] = m[2c]*(bsums[4c]+bsums[4c+1]) + m[2c+1]*(bsums[4c+2]+bsums[4c+3])
                                     int prod = __mul24(m0, a.bsA) + __mul24(m1, a.bsB);
                                     if constexpr (TYPE == PI_Q4_K) {
@@ -830,6 +864,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         }
         int rc = -1;
         switch (w0->type) {
+            case PI_Q2_K: rc = dispatch_nt<PI_Q2_K>(L, nt, stream); break;
             case PI_Q3_K: rc = dispatch_nt<PI_Q3_K>(L, nt, stream); break;
             case PI_Q4_K: rc = dispatch_nt<PI_Q4_K>(L, nt, stream); break;
             case PI_Q5_K: rc = dispatch_nt<PI_Q5_K>(L, nt, stream); break;

@@ -54,7 +54,7 @@ static inline int pi_type_blck(int t) {
 static inline int pi_type_size(int t) {
     switch (t) {
         case PI_F32: return 4; case PI_F16: return 2; case PI_Q4_0: return 18; case PI_Q8_0: return 34;
-        case PI_Q3_K: return 110; case PI_Q4_K: return 144; case PI_Q5_K: return 176; case PI_Q6_K: return 210; case PI_Q8_K: return 292;
+        case PI_Q2_K: return 84; case PI_Q3_K: return 110; case PI_Q4_K: return 144; case PI_Q5_K: return 176; case PI_Q6_K: return 210; case PI_Q8_K: return 292;
     }
     return 0;
 }

@@ -145,6 +145,19 @@ __global__ void k_repack_q3_K(const uint8_t * __restrict__ src, uint8_t * a, int
     for (int k = 0; k < 16; k++) sc[i * 16 + k] = (int8_t) ((int) ((aux[k >> 2] >> (8 * (k & 3))) & 0xff) - 32);
     d[i] = (uint16_t) (b[108] | (b[109] << 8));
 }
+// Q2_K (84 bytes: scales 16 | qs 64 | d | dmin): plane a = 64 bytes per block, qs k-major like Q3_K ([c][half j][dword h] at 16c + 8j + 4h);
+// plane sc = the sixteen (scale | min << 4) bytes; plane d = d | dmin << 16
+__global__ void k_repack_q2_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint32_t * d, int64_t nblocks) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const uint8_t * b = src + i * 84;                        // 4-byte aligned (84 = 21 dwords)
+    const uint32_t * bw = (const uint32_t *) b;
+    uint32_t * o = (uint32_t *) (a + i * 64);
+    for (int c = 0; c < 4; c++)
+        for (int j = 0; j < 2; j++) for (int h = 0; h < 2; h++) o[c * 4 + j * 2 + h] = bw[4 + 8 * j + 2 * c + h];             // qs[32j + 8c + 4h ..]
+    for (int k = 0; k < 4; k++) ((uint32_t *) (sc + i * 16))[k] = bw[k];
+    d[i] = bw[20];
+}
 __global__ void k_repack_q4_0(const uint8_t * __restrict__ src, uint32_t * qs, uint16_t * d, int64_t rows, int64_t nb, int64_t ng) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * nb) return;
@@ -175,7 +188,7 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     w->nbytes = (size_t) nblocks * tsz;
     const bool small = type == PI_Q4_0 || type == PI_Q8_0;
     const size_t alloc = small ? (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32) + (size_t) ne1 * w->ng * 8 + 512
-                       : type == PI_Q3_K ? (size_t) nblocks * (96 + 16 + 2) + 512 : w->nbytes + 512;
+                       : type == PI_Q3_K ? (size_t) nblocks * (96 + 16 + 2) + 512 : w->nbytes + 512;        // (Q2_K: 64 + 16 + 4 = its 84 bytes)
     if (hipMalloc(&w->base, alloc) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", alloc); delete w; return nullptr; }
     uint8_t * base = (uint8_t *) w->base;
     w->p0 = base; w->p1 = w->p2 = w->p3 = nullptr;
@@ -191,7 +204,10 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     const unsigned grid = (unsigned) ((nblocks + threads - 1) / threads);
     if (type == PI_Q4_K) hipLaunchKernelGGL(k_repack_k45, dim3(grid), dim3(threads), 0, stream, staging, base, nblocks, 144, 16);
     else if (type == PI_Q5_K) hipLaunchKernelGGL(k_repack_k45, dim3(grid), dim3(threads), 0, stream, staging, base, nblocks, 176, 48);
-    else if (type == PI_Q3_K) {
+    else if (type == PI_Q2_K) {
+        w->p1 = base + nblocks * 64; w->p2 = w->p1 + nblocks * 16;
+        hipLaunchKernelGGL(k_repack_q2_K, dim3(grid), dim3(threads), 0, stream, staging, base, (uint8_t *) w->p1, (uint32_t *) w->p2, nblocks);
+    } else if (type == PI_Q3_K) {
         w->p1 = base + nblocks * 96; w->p2 = w->p1 + nblocks * 16;
         hipLaunchKernelGGL(k_repack_q3_K, dim3(grid), dim3(threads), 0, stream, staging, base, (int8_t *) w->p1, (uint16_t *) w->p2, nblocks);
     } else if (type == PI_Q6_K) {
@@ -217,7 +233,7 @@ extern "C" int pi_weight_type(const pi_weight * w) { return w->type; }
 extern "C" int pi_vec_dot_type(int t) {
     switch (t) {
         case PI_Q4_0: case PI_Q8_0: return PI_Q8_0;
-        case PI_Q3_K: case PI_Q4_K: case PI_Q5_K: case PI_Q6_K: return PI_Q8_K;
+        case PI_Q2_K: case PI_Q3_K: case PI_Q4_K: case PI_Q5_K: case PI_Q6_K: return PI_Q8_K;
         case PI_F16: return PI_F16; case PI_F32: return PI_F32;
     }
     return -1;

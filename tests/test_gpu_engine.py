@@ -14,7 +14,7 @@ from tests import scenarios as S
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16}
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17}
 LOGIT_TOL = 1e-3
 
 
@@ -109,7 +109,7 @@ def greedy_reference(stem, n_prompt, n_gen):
 
 @pytest.mark.parametrize("tgt,dft", [("tiny_llama_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_llama_q4_k_m", "tiny_llama_q4_0"),
                                       ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0"),
-                                      ("tiny_llama_q3_k_m", "tiny_llama_q4_0")])
+                                      ("tiny_llama_q3_k_m", "tiny_llama_q4_0"), ("tiny_llama_q2_k", "tiny_llama_q3_k_m")])
 @pytest.mark.parametrize("n_draft,n_parallel,p_split,min_spec", [(3, 3, 0.9, 0), (3, 3, 0.9, 1), (8, 1, 0.9, 2), (4, 3, 0.05, 3)])
 def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split, min_spec):
     """accepted-token sequence of the asynchronous speculative driver == the reference target's greedy continuation.

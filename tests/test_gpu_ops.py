@@ -18,7 +18,7 @@ from tests import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-QTYPES = [O.Q4_0, O.Q8_0, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
+QTYPES = [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
 
 
 @pytest.fixture(scope="module")
@@ -92,7 +92,7 @@ def test_activation_quantiser_golden(gpu, vdt):
 def test_mul_mat_golden_blocks(gpu, t):
     """weights quantised by the reference's own quantiser + reference vec_dot results (tests/golden/kernels.npz)"""
     lib, U = gpu
-    K = np.load(os.path.join(GOLD, "kernels_q3k.npz" if t == O.Q3_K else "kernels.npz"))
+    K = np.load(os.path.join(GOLD, {O.Q3_K: "kernels_q3k.npz", O.Q2_K: "kernels_q2k.npz"}.get(t, "kernels.npz")))
     name = O.TYPE_NAMES[t]
     blocks, act, dots = K[f"{name}_blocks"], K[f"{name}_act"], K[f"{name}_dots"]
     rows, k = blocks.shape[0], act.shape[1]
@@ -142,6 +142,8 @@ def test_mul_mat_integer_sums_exact(gpu, t):
         blocks[:, 0:2] = one
     elif t in (O.Q4_K, O.Q5_K):
         blocks[:, 0:2] = one; blocks[:, 2:4] = one
+    elif t == O.Q2_K:
+        blocks[:, 80:82] = one; blocks[:, 82:84] = one                                   # scales and mins are 4-bit already
     elif t == O.Q3_K:
         blocks[:, 108:110] = one                                                         # |scale - 32| <= 19 as generated
     else:
