@@ -107,7 +107,8 @@ struct pipeinfer_spec_params {
     int32_t min_spec_iters;  /* speculation iterations to run even when the target is already back (0 = reference behaviour) */
     int32_t verbose;
     /* our addition (0 = off = the reference's behaviour): when `adaptive_window` accepted tokens in a row passed without a single
-     * speculative run being launched (the draft never got ahead of the target — the normal state when both share one GPU), the
+     * speculative run being launched *because the target run was already back when the speculation loop started* (the draft never got
+     * ahead of the target — the normal state when both share one GPU; an unsure draft or a lack of free partitions does not count), the
      * draft model is left alone for `adaptive_pause` tokens (doubling up to 16x while that keeps happening) and then caught up with
      * one batched decode before speculation is tried again.  Output tokens are unaffected (greedy verification is lossless).
      * adaptive_window < 0 (tests): pause after every |window| tokens whether or not speculation is happening. */

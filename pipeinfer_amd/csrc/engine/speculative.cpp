@@ -265,6 +265,7 @@ struct driver {
     // Called once per accepted token.  While the draft is paused its KV cache lags: the accepted tokens are remembered and decoded
     // in one batch (same cells, same sequence layout as the per-token begin_non_spec_run) right before drafting resumes.
     int pause_left = 0, pause_len = 0, win_tokens = 0, win_spec0 = 0;
+    bool loop_found_target_back = false;                                  // the last speculation loop could not start because the target run was already back
     std::vector<llama_token> lag_tokens;
     bool draft_paused() const { return pause_left > 0; }
     void adaptive_step() {
@@ -275,6 +276,7 @@ struct driver {
             return;
         }
         if (R.n_runs_spec != win_spec0) { win_tokens = 0; win_spec0 = R.n_runs_spec; pause_len = 0; return; }     // speculation is happening: keep drafting
+        if (!loop_found_target_back) { win_tokens = 0; return; }          // no run for another reason (an unsure draft, no free partition): that is not what the pause is for
         if (++win_tokens >= P.adaptive_window) {
             pause_len = pause_len == 0 ? P.adaptive_pause : std::min(pause_len * 2, P.adaptive_pause * 16);
             pause_left = pause_len;
@@ -301,6 +303,7 @@ struct driver {
     // first draft token, and tests need the accept / cancel paths exercised.
     void run_speculation_loop() {
         bool is_waiting = llama_mpi_iprobe(tgt);
+        loop_found_target_back = is_waiting;                              // (adaptive draft pause: the only reason it counts)
         const int forced = P.min_spec_iters;
         bool returned_offset = false;
         if (is_waiting && forced == 0) { free_offsets.push_back(current.seq_offset); returned_offset = true; }

@@ -466,7 +466,8 @@ def bench_main(args, rank, world):
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
                 ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")),
-                adaptive_window=args.adaptive_window, adaptive_pause=args.adaptive_pause)
+                # with the draft on a GPU of its own a pause has nothing to win; it stays on only when the ranks share one device (dry runs)
+                adaptive_window=args.adaptive_window if links.via_host else 0, adaptive_pause=args.adaptive_pause)
     rng = np.random.default_rng(0xBEEF)
     prompts = [[int(x) for x in rng.integers(3, mt.n_vocab, args.n_prompt)] for _ in range(args.warmup + args.steps + 1)]
 
