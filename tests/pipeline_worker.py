@@ -55,6 +55,32 @@ class OracleCompute:
         return ids, vals, sums, logits
 
 
+class Relay:
+    """first of two stages in the world_size-3 test: the oracle has no partial forward, so this stage computes nothing and hands the next
+    one an activation block derived from the run's tokens — the last stage checks it arrived intact (header hop, data hop, ordering)"""
+
+    @staticmethod
+    def pattern(n, meta, n_embd):
+        tok = np.asarray(meta[:n], np.float32)
+        return (tok[:, None] * 0.5 + np.arange(n_embd, dtype=np.float32)[None, :] * 0.25).astype(np.float32)
+
+    def __init__(self, n_embd):
+        self.n_embd = n_embd
+
+    def run(self, n, meta, x_in=None, x_out=None):
+        x_out.copy_(torch.from_numpy(self.pattern(n, meta, self.n_embd)))
+        return None
+
+
+class CheckedOracle(OracleCompute):
+    """last of two stages: verifies the relayed block, then runs the whole oracle model on the metadata"""
+
+    def run(self, n, meta, x_in=None, x_out=None):
+        want = Relay.pattern(n, np.ascontiguousarray(meta, np.int32), x_in.shape[1])
+        assert np.array_equal(x_in.numpy(), want), "activation block changed on its way between the stages"
+        return super().run(n, meta)
+
+
 class LocalOps:
     """struct pipeinfer_remote_ops served in-process (the draft context of the head)"""
 
@@ -91,14 +117,22 @@ def main():
     out_path, tgt, dft = sys.argv[1], sys.argv[2], sys.argv[3]
     links = P.init_links()
     rank = dist.get_rank()
-    assert dist.get_world_size() == 2 and links.device == "cpu"
-    if rank == 1:
-        comp = OracleCompute(tgt)
-        n_embd = comp.o.o_model_info(comp.h, 1)
-        st = P.stage_loop(links, comp, head=0, prev=0, nxt=None, n_embd=n_embd, n_vocab=comp.n_vocab, n_batch=64)
+    world = dist.get_world_size()
+    assert world in (2, 3) and links.device == "cpu"
+    if rank >= 1:
+        if world == 2:
+            comp = OracleCompute(tgt)
+        else:
+            comp = CheckedOracle(tgt) if rank == 2 else None
+        probe = comp if comp is not None else OracleCompute(tgt)
+        n_embd, n_vocab = probe.o.o_model_info(probe.h, 1), probe.n_vocab
+        if comp is None:
+            comp = Relay(n_embd)
+        st = P.stage_loop(links, comp, head=0, prev=rank - 1, nxt=None if rank == world - 1 else rank + 1, n_embd=n_embd, n_vocab=n_vocab, n_batch=64)
         dist.barrier()
-        print("stage served", st, file=sys.stderr)
+        print("stage", rank, "served", st, file=sys.stderr)
         return
+    world = dist.get_world_size() if 'world' not in dir() else world
     g = np.load(os.path.join(GOLD, tgt + ".npz"))
     prompt, _ = S.scenario_greedy(512, seed=int(sys.argv[4]), n_prompt=8)
     want = [int(x) for x in g["greedy_tokens"][:24]]
@@ -107,7 +141,7 @@ def main():
     remote = None
     for trial, (n_draft, n_parallel, min_spec) in enumerate(((3, 3, 1), (4, 2, 2), (2, 1, 0))):
         ct, cd = LL.Context(mt, n_ctx=N_CTX, n_batch=64), LL.Context(md, n_ctx=N_CTX, n_batch=64)
-        remote = remote if trial else P.RemoteTarget(links, 1, 1, [1], mt.n_vocab)     # one transport, several generations
+        remote = remote if trial else P.RemoteTarget(links, 1, world - 1, list(range(1, world)), mt.n_vocab)     # one transport, several generations
         remote.attach(ct)
         local = LocalOps(OracleCompute(dft))
         local.attach(cd)
