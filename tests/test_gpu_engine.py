@@ -178,6 +178,34 @@ def test_cpp_llama_h_caller_reproduces_the_reference(tmp_path):
     assert int(stats[1]) > 0                                      # speculation really ran
 
 
+def test_cli_driver_with_the_reference_flags(tmp_path):
+    """examples/speculative_amd.cpp: the reference's command line (-m -md -n --draft -np -pa -ps --ignore-eos ...) and closing report on top of
+    llama.h; the generated ids must be the golden continuation, results.csv gets the reference's four columns"""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, csv = str(tmp_path / "speculative_amd"), str(tmp_path / "results.csv")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "speculative_amd.cpp"),
+                    "-L" + os.path.join(root, "pipeinfer_amd"), "-lpipeinfer_amd", "-Wl,-rpath," + os.path.join(root, "pipeinfer_amd"), "-o", exe], check=True)
+    tgt, dft = "tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"
+    prompt, want = greedy_reference(tgt, 8, 24)
+    r = subprocess.run([exe, "-m", os.path.join(GOLD, tgt + ".gguf"), "-md", os.path.join(GOLD, dft + ".gguf"), "--prompt-tokens", ",".join(str(t) for t in prompt),
+                        "-n", "23", "--draft", "4", "-np", "2", "-pa", "0.05", "-ps", "0.9", "-c", "256", "-b", "64", "--results", csv],
+                       capture_output=True, text=True, errors="replace", timeout=300)        # (the fixture's token pieces are not valid UTF-8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    toks = [l for l in r.stdout.splitlines() if l.startswith("tokens:")][0].split()[1:]
+    assert [int(t) for t in toks][:24] == want, (toks, want)
+    for key in ("encoded", "decoded", "n_draft   = 4", "n_predict =", "n_drafted =", "n_accept  =", "accept    ="):
+        assert any(l.startswith(key) for l in r.stdout.splitlines()), (key, r.stdout[-1500:])
+    cols = open(csv).read().strip().split(",")
+    assert len(cols) == 4 and all(float(c) > 0 for c in cols)
+    # a text prompt goes through llama_tokenize (SPM vocabulary of the fixture); only that it runs and reports is checked here
+    r2 = subprocess.run([exe, "-m", os.path.join(GOLD, tgt + ".gguf"), "-md", os.path.join(GOLD, dft + ".gguf"), "-p", "hello world again", "-n", "8", "-c", "256", "-b", "64",
+                         "--ignore-eos", "--target-only"], capture_output=True, text=True, errors="replace", timeout=300)
+    assert r2.returncode == 0 and "decoded" in r2.stdout, r2.stderr[-2000:]
+
+
 def test_pipeinfer_driver_lossless_under_timing_jitter(LL):
     """the driver's control flow depends on which run finishes first, so repeat one configuration with fresh contexts
     (this caught target and draft contexts racing on a shared top-k scratch buffer)."""
