@@ -25,6 +25,9 @@
 #include <cstdlib>
 
 #define ATT_ROWS 8
+#ifndef PI_ATT_NO_JSPLIT
+#define PI_ATT_NO_JSPLIT 0
+#endif
 
 struct att_args {
     const uint16_t * q16; const uint16_t * kc; const uint16_t * vc; const uint32_t * mask;
@@ -73,18 +76,23 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     const int np = g.n_kv & ~31;
     const uint16_t * vbase = g.vc + hk * HD + 8 * ev;
     constexpr int PD = RW <= 2 ? 4 : 2;                      // 32-cell steps of V in flight
-    uint4 vb[PD][4];
+    // with a single row per workgroup (decode) the row-group slots would idle in phase 3, and the kernel is bound per CU: they take
+    // accumulator sets instead — slot rg owns j = rg*JPT .. rg*JPT + JPT - 1 of the four; the sets meet in LDS for the reference's fold
+    constexpr bool SPLIT = RW == 1 && NRG > 1 && !PI_ATT_NO_JSPLIT;
+    constexpr int JS = SPLIT ? NRG : 1, JPT = 4 / JS;
+    const int j0 = SPLIT ? rg * JPT : 0;
+    uint4 vb[PD][JPT];
 #pragma unroll
     for (int d = 0; d < PD; d++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) { const int c = 32 * d + 8 * j + l; vb[d][j] = *(const uint4 *) (vbase + (int64_t) (c < np ? c : 0) * n_gqa); }
+        for (int jj = 0; jj < JPT; jj++) { const int c = 32 * d + 8 * (j0 + jj) + l; vb[d][jj] = *(const uint4 *) (vbase + (int64_t) (c < np ? c : 0) * n_gqa); }
 
     // the n_kv % 32 leftover cells of phase 3 are summed sequentially in double (ggml_vec_dot_f16's tail loop): one dim per lane,
     // all of them requested now so that the tail costs arithmetic only
     constexpr int NTAIL = 31;
     const int n_tail = g.n_kv - np;
     uint16_t vt[NTAIL];
-    if (n_tail > 0 && rg < n_rows) {
+    if (n_tail > 0 && (SPLIT ? rg == 0 : rg < n_rows)) {
         const uint16_t * vtb = g.vc + hk * HD + 8 * ev + l;
 #pragma unroll
         for (int i = 0; i < NTAIL; i++) vt[i] = vtb[(int64_t) min(np + i, g.n_kv - 1) * n_gqa];
@@ -198,23 +206,23 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     return;
 #endif
     // ---- phase 3: out[row][e] = ggml_vec_dot_f16(n_kv, V[:, e], P[row, :]) ----
-    float acc[RPT][4][8];
+    float acc[RPT][JPT][8];
 #pragma unroll
     for (int i = 0; i < RPT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int jj = 0; jj < JPT; jj++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < 8; e++) acc[i][jj][e] = 0.0f;
     // ring of PD steps with a straight-line loop body: with branches inside, the compiler's wait counts drain every load before
     // each step; without, PD - 1 steps of loads stay in flight. Loads past np re-read cell 0 and are not used
     int srow[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; i++) { const int rr = rg + i * NRG; srow[i] = (rr < n_rows ? rr : 0) * s_stride; }
-    auto pv_step = [&](int cb, const uint4 (&vv)[4]) __attribute__((always_inline)) {
+    for (int i = 0; i < RPT; i++) { const int rr = SPLIT ? 0 : rg + i * NRG; srow[i] = (rr < n_rows ? rr : 0) * s_stride; }
+    auto pv_step = [&](int cb, const uint4 (&vv)[JPT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int c = cb + 8 * j + l;
-            const uint32_t w4[4] = { vv[j].x, vv[j].y, vv[j].z, vv[j].w };
+        for (int jj = 0; jj < JPT; jj++) {
+            const int c = cb + 8 * (j0 + jj) + l;
+            const uint32_t w4[4] = { vv[jj].x, vv[jj].y, vv[jj].z, vv[jj].w };
             float vf[8];
 #pragma unroll
             for (int u = 0; u < 4; u++) { vf[2 * u] = pi_h2f((uint16_t) (w4[u] & 0xffff)); vf[2 * u + 1] = pi_h2f((uint16_t) (w4[u] >> 16)); }
@@ -222,7 +230,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
             for (int i = 0; i < RPT; i++) {
                 const float p = S[srow[i] + c];
 #pragma unroll
-                for (int e = 0; e < 8; e++) acc[i][j][e] = fmaf(vf[e], p, acc[i][j][e]);
+                for (int e = 0; e < 8; e++) acc[i][jj][e] = fmaf(vf[e], p, acc[i][jj][e]);
             }
         }
     };
@@ -232,19 +240,39 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         for (int d = 0; d < PD; d++) {
             pv_step(c0 + 32 * d, vb[d]);
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const int cn = c0 + 32 * (d + PD) + 8 * j + l; vb[d][j] = *(const uint4 *) (vbase + (int64_t) (cn < np ? cn : 0) * n_gqa); }
+            for (int jj = 0; jj < JPT; jj++) { const int cn = c0 + 32 * (d + PD) + 8 * (j0 + jj) + l; vb[d][jj] = *(const uint4 *) (vbase + (int64_t) (cn < np ? cn : 0) * n_gqa); }
         }
     }
 #pragma unroll
     for (int d = 0; d < PD - 1; d++)                          // the last, partial group: its rows are already in the ring
         if (c0 + 32 * d < np) pv_step(c0 + 32 * d, vb[d]);
+    // decode: the accumulator sets of slots 1.. go to slot 0 through LDS ([slot - 1][set * 8 + dim][lane of the slot])
+    constexpr int LPR = 8 * TPC;                              // lanes of a row-group slot
+    __shared__ float xch[SPLIT ? (JS - 1) * JPT * 8 * LPR : 1];
+    if constexpr (SPLIT) {
+        const int ls = tid % LPR;
+        if (rg > 0) {
+#pragma unroll
+            for (int jj = 0; jj < JPT; jj++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) xch[((rg - 1) * JPT * 8 + jj * 8 + e) * LPR + ls] = acc[0][jj][e];
+        }
+        __syncthreads();
+        if (rg > 0) return;
+    }
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
-        const int rr = rg + i * NRG;
+        const int rr = SPLIT ? 0 : rg + i * NRG;
         float res[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            float s = (acc[i][0][e] + acc[i][2][e]) + (acc[i][1][e] + acc[i][3][e]);     // registers: 0+=2, 1+=3, 0+=1  (per lane l)
+            float a4[4];                                                                // the four accumulator sets of this lane and dim
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if constexpr (SPLIT) a4[j] = j < JPT ? acc[0][j % JPT][e] : xch[((j / JPT - 1) * JPT * 8 + (j % JPT) * 8 + e) * LPR + tid % LPR];
+                else a4[j] = acc[i][j % JPT][e];
+            }
+            float s = (a4[0] + a4[2]) + (a4[1] + a4[3]);                                  // registers: 0+=2, 1+=3, 0+=1  (per lane l)
             s = s + pi_xor4(s);                                                         // t[l] = x[l] + x[l+4]
             s = s + pi_partner<1>(s);                                                   // hadd
             s = s + pi_partner<2>(s);                                                   // hadd
@@ -313,7 +341,8 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > 128) rw *= 2;
     static const int rw_env = getenv("PI_ATT_RW") ? atoi(getenv("PI_ATT_RW")) : 0;      // tuning / tests
     if (rw_env == 1 || rw_env == 2 || rw_env == 4 || rw_env == 8) rw = rw_env;
-    if ((size_t) rw * (n_kv + g.mask_words) * sizeof(float) > 156 * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs more than 156 KiB of LDS", n_kv); return -1; }
+    // (the single-row instance also has 8 KiB of static LDS)
+    if ((size_t) rw * (n_kv + g.mask_words) * sizeof(float) > (size_t) (rw == 1 ? 146 : 156) * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs more than %d KiB of LDS", n_kv, rw == 1 ? 146 : 156); return -1; }
     if (hd == 128) att_launch<128>(g, rows, rw, (hipStream_t) stream);
     else if (hd == 64) att_launch<64>(g, rows, rw, (hipStream_t) stream);
     else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }
