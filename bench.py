@@ -181,6 +181,7 @@ def main():
         results.append(r)
     L.check(lib.pi_device_sync())
     t_total = time.time() - t_start
+    st_t, st_d = ct.stats(), cd.stats()                 # per-call GPU time and bytes of the timed steps only
 
     # on one GPU the driver (faithfully) finds the target back before the draft is ahead and launches no speculative run, so the timed
     # steps do not exercise draft trees, verification, acceptance and cancellation at the real model sizes: one extra, untimed
@@ -202,7 +203,6 @@ def main():
     acc_clean = sum(r["n_accept_clean"] for r in results)
     acc_ref = 100.0 * sum(r["n_accept"] for r in results) / max(1, sum(r["n_drafted"] for r in results))
 
-    st_t, st_d = ct.stats(), cd.stats()
     # roofline of the dominant kernel: the Q4_K single-token mat-vec (k_mmvq_kq<Q4_K, NT=1>), every 4th launch bracketed by HIP
     # events on its own stream.  Events recorded inside a captured graph cannot be read back on ROCm 7.2, so the sampling
     # pass replays the same decode step kernel by kernel (graphs off) right after the timed region, on the same context.
