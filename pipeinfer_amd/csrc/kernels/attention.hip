@@ -15,8 +15,8 @@
 // One workgroup (256 threads) per (kv head, chunk of RW query rows); a row is one (token, query head of the GQA group), so
 // K/V are read once per chunk for all query heads and verify tokens that share them.  RW is chosen so that a launch has
 // enough workgroups (decode has few rows: one workgroup per (kv head, row)).
-//   phase 1  16 lanes per cell: lane a owns accumulators a and a+16 of the reference's 32 (its q values stay in registers),
-//            folds them in the reference's order (in-lane, then DPP row shifts 8, 4 and the two hadd steps), scale, mask -> S
+//   phase 1  16 lanes per cell: lane a owns accumulators 2a and 2a+1 of the reference's 32 (one dword per 32-element step; its q values
+//            stay in registers), folds them in the reference's order (DPP row shifts 8, 4, 2, in-lane add, shift 1), scale, mask -> S
 //   phase 2  all threads: row max, table exp, exact integer sum, P = f16-rounded probability (kept as f32 in LDS)
 //   phase 3  lane (l, ev) owns cells c % 8 == l and dims 8ev..8ev+7: four accumulator sets j = (c / 8) % 4 per row, folded
 //            in the reference's order with lane shuffles; tail cells in double by lane l == 0
@@ -42,7 +42,7 @@ struct att_args {
 template <int CTRL> static __device__ __forceinline__ float dpp_add(float x) {
 #ifdef PI_ATT_NO_DPP
     const int lane = threadIdx.x & 63;
-    const int src = CTRL == 0x108 ? lane + 8 : CTRL == 0x104 ? lane + 4 : CTRL == 0xB1 ? (lane ^ 1) : (lane ^ 2);
+    const int src = CTRL == 0x108 ? lane + 8 : CTRL == 0x104 ? lane + 4 : CTRL == 0x102 ? lane + 2 : CTRL == 0x101 ? lane + 1 : CTRL == 0xB1 ? (lane ^ 1) : (lane ^ 2);
     return x + __shfl(x, src & 63, 64);
 #else
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
@@ -102,42 +102,44 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     {
         constexpr int NS = HD / 32;                         // 32-element steps
         const int a = lane & 15, cg = lane >> 4;
+        // lane a owns accumulators 2a and 2a+1 of the reference's 32 (one dword = two neighbouring f16 of every 32-element step:
+        // half the load instructions of the (a, a+16) mapping, and phase 1 is bound by their issue); q stays in registers
         float q[RW][2 * NS];                                // rows are token-major: row = t * r + gq -> query head hk * r + gq
 #pragma unroll
         for (int rr = 0; rr < RW; rr++) {
             const int row = row0 + (rr < n_rows ? rr : 0), t = row / r, gq = row % r;
-            const uint16_t * qp = g.q16 + (int64_t) t * n_embd + (hk * r + gq) * HD;
+            const uint32_t * qp = (const uint32_t *) (g.q16 + (int64_t) t * n_embd + (hk * r + gq) * HD);
 #pragma unroll
-            for (int st = 0; st < NS; st++) { q[rr][2 * st] = pi_h2f(qp[32 * st + a]); q[rr][2 * st + 1] = pi_h2f(qp[32 * st + 16 + a]); }
+            for (int st = 0; st < NS; st++) { const uint32_t w = qp[16 * st + a]; q[rr][2 * st] = pi_h2f((uint16_t) (w & 0xffff)); q[rr][2 * st + 1] = pi_h2f((uint16_t) (w >> 16)); }
         }
         constexpr int U = 4;                                // cells per 16-lane group and step; two steps are in flight
-        uint16_t kr[2][U][2 * NS];
-        auto load_k = [&](int c0, uint16_t (&dst)[U][2 * NS]) __attribute__((always_inline)) {
+        uint32_t kr[2][U][NS];
+        auto load_k = [&](int c0, uint32_t (&dst)[U][NS]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int c = c0 + 16 * u + wv * 4 + cg, cc = c < g.n_kv ? c : g.n_kv - 1;
-                const uint16_t * kp = g.kc + (int64_t) cc * n_gqa + hk * HD;
+                const uint32_t * kp = (const uint32_t *) (g.kc + (int64_t) cc * n_gqa + hk * HD);
 #pragma unroll
-                for (int st = 0; st < NS; st++) { dst[u][2 * st] = kp[32 * st + a]; dst[u][2 * st + 1] = kp[32 * st + 16 + a]; }
+                for (int st = 0; st < NS; st++) dst[u][st] = kp[16 * st + a];
             }
         };
-        auto score = [&](int c0, const uint16_t (&src)[U][2 * NS]) __attribute__((always_inline)) {
+        auto score = [&](int c0, const uint32_t (&src)[U][NS]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int c = c0 + 16 * u + wv * 4 + cg;
                 float kf[2 * NS];
 #pragma unroll
-                for (int i = 0; i < 2 * NS; i++) kf[i] = pi_h2f(src[u][i]);
+                for (int st = 0; st < NS; st++) { kf[2 * st] = pi_h2f((uint16_t) (src[u][st] & 0xffff)); kf[2 * st + 1] = pi_h2f((uint16_t) (src[u][st] >> 16)); }
 #pragma unroll
                 for (int rr = 0; rr < RW; rr++) {            // rows past n_rows are computed on row 0's q and not stored: no branch in the loop
-                    float x0 = 0.0f, x1 = 0.0f;
+                    float x0 = 0.0f, x1 = 0.0f;             // s[2a], s[2a+1]
 #pragma unroll
                     for (int st = 0; st < NS; st++) { x0 = fmaf(kf[2 * st], q[rr][2 * st], x0); x1 = fmaf(kf[2 * st + 1], q[rr][2 * st + 1], x1); }
-                    float x = x0 + x1;                      // s[l] += s[16+l], s[8+l] += s[24+l]
-                    x = dpp_add<0x108>(x);                  // s[l] += s[8+l]                      row_shl:8
-                    x = dpp_add<0x104>(x);                  // t[l] = s[l] + s[l+4]                row_shl:4
-                    x = dpp_add<0xB1>(x);                   // t0+t1, t2+t3                        quad_perm [1,0,3,2]
-                    x = dpp_add<0x4E>(x);                   // (t0+t1) + (t2+t3)                   quad_perm [2,3,0,1]
+                    x0 = dpp_add<0x108>(x0); x1 = dpp_add<0x108>(x1);      // s[l] += s[16+l]: lanes a, a+8        row_shl:8
+                    x0 = dpp_add<0x104>(x0); x1 = dpp_add<0x104>(x1);      // s[l] += s[8+l]:  lanes a, a+4        row_shl:4
+                    x0 = dpp_add<0x102>(x0); x1 = dpp_add<0x102>(x1);      // t[l] = s[l] + s[l+4]: lanes a, a+2   row_shl:2  (lane 0: t0, t1; lane 1: t2, t3)
+                    float x = x0 + x1;                                     // t0+t1 (lane 0), t2+t3 (lane 1)
+                    x = dpp_add<0x101>(x);                                 // (t0+t1) + (t2+t3)                    row_shl:1
                     if (a == 0 && c < g.n_kv && rr < n_rows) {
                         const bool vis = (M[rr * g.mask_words + (c >> 5)] >> (c & 31)) & 1;
                         S[(size_t) rr * s_stride + c] = vis ? x * g.scale : -INFINITY;
