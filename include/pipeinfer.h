@@ -102,7 +102,9 @@ struct pipeinfer_spec_params {
     float   p_decay;         /* -pd */
     float   temp;            /* --temp (<= 0: greedy; < 0 also computes probabilities) */
     int32_t ignore_eos;      /* --ignore-eos */
-    int32_t mode;            /* 0 = PipeInfer (async, continuous speculation), 2 = target only (greedy, no draft model) */
+    int32_t mode;            /* 0 = PipeInfer (async, continuous speculation: examples/speculative), 1 = synchronous tree speculation
+                              * (examples/speculative_orig: draft up to n_draft steps, verify the tree in one target batch),
+                              * 2 = target only (greedy, no draft model) */
     int32_t max_inflight;    /* cap on target runs in flight (0 = unlimited, the reference behaviour) */
     int32_t min_spec_iters;  /* speculation iterations to run even when the target is already back (0 = reference behaviour) */
     int32_t verbose;

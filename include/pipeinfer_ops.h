@@ -61,6 +61,9 @@ PI_API int     pi_vec_dot_type(int weight_type);
 PI_API size_t  pi_q8_nbytes(int vdt, int64_t k, int n_tok);
 /* byte offsets of the planes inside that buffer: qs (int8 [n_tok][k]), d (f32 [n_tok][k/256] | f16 [n_tok][k/32]), bsums (int16 [n_tok][k/16], Q8_K only) */
 PI_API void    pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size_t * off_d, size_t * off_bsums);
+/* Q8_K, n_tok >= 2: byte offsets of the MFMA operand planes the quantisers also write (f16 copies of qs in the lane order of
+ * v_mfma_f32_16x16x32_f16, two sub-block pairings, and per-token block sums / scales as floats); layout in runtime.hip */
+PI_API void    pi_q8_frag_layout(int64_t k, int n_tok, size_t * off_frag_a, size_t * off_frag_b, size_t * off_aux);
 
 PI_API int pi_op_get_rows(const pi_weight * w, const int32_t * tokens_dev, int n_tok, float * out_dev, void * stream);
 PI_API int pi_op_norm(const float * x_dev, const float * w_dev, const float * b_dev, float * y_dev, int n, int n_tok, float eps, int rms, void * stream);

@@ -69,6 +69,7 @@ struct driver {
     bool first_run = true;
     llama_token id = 0;
     host_batch batch_tgt, batch_dft;
+    bool failed = false;                                      // a decode could not be started: drain what is in flight and return an error
 
     // ---- sampling -----------------------------------------------------------------------------------------------------------------
     // top-8 candidates of row idx with probabilities over the full vocabulary (llama_sampling_sample with temp < 0:
@@ -121,6 +122,11 @@ struct driver {
         if (!is_spec) pipeinfer_kv_cache_seq_rm_range(ctx, 0, max_seq, n_past, n_past + 1);
         else          pipeinfer_kv_cache_seq_rm_range(ctx, seq_offset, seq_offset + n_seq_dft - 1, n_past, n_past + 1);
         run->ticket = llama_start_async_decode(ctx, run->batch.view());
+        if (!run->ticket) {                                               // no KV slot / n_tokens > n_batch / HIP error: the run never entered the context's queue
+            fprintf(stderr, "pipeinfer_speculative: llama_start_async_decode failed (%s run, %d tokens): %s\n", is_spec ? "speculative" : "non-speculative", run->batch.n_tokens(), pipeinfer_context_error(ctx));
+            failed = true;
+            return;
+        }
         if (P.verbose) {
             fprintf(stderr, "[spec] launch %s batch=%d ctx=%s off=%d n_past=%d n_past_max=%d prefix=%d tokens:", is_spec ? "SPEC" : "nonspec", batch_id, ctx == tgt ? "tgt" : "dft", seq_offset, n_past, n_past_max, prefix_n_past);
             for (int i = 0; i < run->batch.n_tokens(); i++) { fprintf(stderr, " %d@%d{", run->batch.token[i], run->batch.pos[i]); for (auto q : run->batch.seq[i]) fprintf(stderr, "%d,", q); fprintf(stderr, "}"); }
@@ -235,14 +241,14 @@ struct driver {
             }
             if (batch_dft.n_tokens() == 0) break;
             batch_dft.batch_id = batch_id;
-            llama_decode(dft, batch_dft.view());
+            if (llama_decode(dft, batch_dft.view()) != 0) { failed = true; break; }      // (stale top-k rows must not be sampled)
             ++n_past_cur;
             ++R.n_drafted;
             max_ran_seq = n_seq_cur;
             batch_dft.clear();
             if (batch_tgt.n_tokens() > P.n_draft) break;
         }
-        if (batch_tgt.n_tokens() == 0) {
+        if (batch_tgt.n_tokens() == 0 || failed) {
             free_offsets.push_back(off);
             n_rejected++;
             return true;
@@ -266,7 +272,7 @@ struct driver {
     // in one batch (same cells, same sequence layout as the per-token begin_non_spec_run) right before drafting resumes.
     int pause_left = 0, pause_len = 0, win_tokens = 0, win_spec0 = 0;
     bool loop_found_target_back = false;                                  // the last speculation loop could not start because the target run was already back
-    std::vector<llama_token> lag_tokens;
+    std::vector<std::pair<llama_token, int>> lag_tokens;                   // (token, position): drafted tokens accepted meanwhile keep their own cells
     bool draft_paused() const { return pause_left > 0; }
     void adaptive_step() {
         if (P.mode == 2 || P.adaptive_window == 0 || P.adaptive_pause <= 0) return;
@@ -284,15 +290,17 @@ struct driver {
     }
     bool draft_catch_up() {
         if (lag_tokens.empty()) return true;
-        const int n = (int) lag_tokens.size(), p0 = n_past_dft - n;
-        pipeinfer_kv_cache_seq_rm_range(dft, 0, max_seq, p0, n_past_dft);
+        // every lagged token is decoded at ITS position: a speculative run launched before the pause can be accepted while the draft sits
+        // out, which advances n_past_dft past cells that already hold the draft's K/V of those accepted tokens
+        const int n = (int) lag_tokens.size();
+        for (const auto & tp : lag_tokens) pipeinfer_kv_cache_seq_rm_range(dft, 0, max_seq, tp.second, tp.second + 1);
         const int n_batch = std::max(1, dft->n_batch);
         for (int i0 = 0; i0 < n; i0 += n_batch) {
             host_batch b;
-            for (int i = i0; i < std::min(n, i0 + n_batch); i++) b.add(lag_tokens[i], p0 + i, { 0 });
+            for (int i = i0; i < std::min(n, i0 + n_batch); i++) b.add(lag_tokens[i].first, lag_tokens[i].second, { 0 });
             if (llama_decode(dft, b.view()) != 0) return false;
         }
-        pipeinfer_kv_cache_seq_cp_range(dft, 0, 1, max_seq, p0, n_past_dft);
+        for (const auto & tp : lag_tokens) pipeinfer_kv_cache_seq_cp_range(dft, 0, 1, max_seq, tp.second, tp.second + 1);
         lag_tokens.clear();
         R.n_draft_catchups++;
         return true;
@@ -349,6 +357,16 @@ struct driver {
         eos = llama_token_eos(llama_get_model(tgt));
         const int n_input = n_prompt;
         if (n_input < 2 || n_input > llama_n_ctx(tgt) - 4) return -1;
+        // the KV cache must hold the prompt, the generation and the cells of the speculative runs that can be in flight at once
+        // (the reference aborts in find_slot when it cannot; say so before anything is launched)
+        {
+            const int inflight = P.mode == 2 ? 0 : (P.max_inflight > 0 ? P.max_inflight : 4);
+            const int need = n_input + P.n_predict + 2 + (P.mode == 2 ? 0 : (P.n_draft + 1) * n_seq_dft * inflight);
+            if (need > llama_n_ctx(tgt)) {
+                fprintf(stderr, "pipeinfer_speculative: n_ctx %d cannot hold %d prompt + %d generated tokens + %d speculative cells\n", llama_n_ctx(tgt), n_input, P.n_predict, need - n_input - P.n_predict - 2);
+                return -1;
+            }
+        }
         R.n_input = n_input;
 
         // ---- prompt: every token carries every sequence id (speculative.cpp:223-246) ----
@@ -385,6 +403,11 @@ struct driver {
         int n_out = 0;
 
         while (true) {
+            if (failed) {                                                 // drain and report (the output so far is valid, the generation is not complete)
+                while (!tgt_runs.empty()) { auto r = tgt_runs.back(); llama_finish_async_decode(tgt, r->batch.view(), r->ticket); tgt_runs.pop_back(); }
+                while (!dft_runs.empty()) { auto r = dft_runs.back(); llama_finish_async_decode(dft, r->batch.view(), r->ticket); dft_runs.pop_back(); }
+                return -3;
+            }
             int i_dft = 0, s_keep = 0;
             const bool is_waiting = llama_mpi_iprobe(tgt);
             if (!tgt_runs.empty() && is_waiting) {
@@ -477,7 +500,7 @@ struct driver {
                 dft_runs.pop_back();
                 llama_finish_async_decode(dft, d->batch.view(), d->ticket);
             } else {
-                if (P.mode != 2) { lag_tokens.push_back(id); R.n_draft_paused++; }      // the draft sits this token out (caught up later in one batch)
+                if (P.mode != 2) { lag_tokens.emplace_back(id, n_past_dft); R.n_draft_paused++; }      // the draft sits this token out (caught up later in one batch)
                 n_past_dft++;
             }
             spec_past_tgt = n_past_tgt; spec_past_dft = n_past_dft;
@@ -504,6 +527,144 @@ struct driver {
         R.itl_s = itl.empty() ? 0.0 : s / itl.size() / 1e6;
         return n_out;
     }
+
+    // ---- mode 1: synchronous tree speculation — examples/speculative_orig/speculative.cpp:150-520 restated ----------------------------
+    // One cycle = sample the target over the last verify batch (accepting drafted tokens while they match), tidy both KV caches down
+    // to the kept branch, draft up to n_draft steps (tree branches split at p_split), verify the whole tree in ONE target batch.
+    // Nothing runs concurrently: on a single GPU this is the schedule in which the draft never queues behind a target run.
+    // n_drafted / n_accept are deterministic functions of the two models.
+    int run_sync(const llama_token * prompt, int n_prompt, llama_token * out, int out_cap) {
+        memset(&R, 0, sizeof R);
+        n_seq_dft = std::max(1, P.n_parallel);
+        eos = llama_token_eos(llama_get_model(tgt));
+        const int n_input = n_prompt;
+        if (n_input < 2 || n_input > llama_n_ctx(tgt) - 4) return -1;
+        R.n_input = n_input;
+        std::vector<llama_seq_id> seq_ids(n_seq_dft + 1);
+        for (int i = 0; i <= n_seq_dft; i++) seq_ids[i] = i;
+
+        const int64_t t_enc_start = pi::time_us();
+        {   // speculative_orig:172-186
+            host_batch bt, bd;
+            for (int i = 0; i < n_input - 1; i++) { bt.add(prompt[i], i, seq_ids); bd.add(prompt[i], i, seq_ids); }
+            if (llama_decode(tgt, bt.view()) != 0) return -2;
+            bt.clear();
+            bt.add(prompt[n_input - 1], n_input - 1, seq_ids); bd.add(prompt[n_input - 1], n_input - 1, seq_ids);
+            if (llama_decode(tgt, bt.view()) != 0) return -2;
+            if (llama_decode(dft, bd.view()) != 0) return -2;
+        }
+        const int64_t t_enc_end = pi::time_us();
+
+        n_past_tgt = n_past_dft = n_input;
+        bool has_eos = false;
+        drafts.assign(n_seq_dft, seq_draft());
+        const int64_t t_dec_start = pi::time_us();
+        drafts[0].i_batch_tgt = { 0 };
+        int64_t ttft = pi::time_us(), itt_start = 0;
+        std::vector<int64_t> itl;
+        bool first_token = false, has_run_first_token = false;
+        int n_out = 0;
+
+        while (true) {
+            int i_dft = 0, s_keep = 0;
+            while (true) {
+                id = sample_greedy(tgt, drafts[s_keep].i_batch_tgt[i_dft]);
+                if (has_run_first_token) {
+                    if (first_token) { ttft = pi::time_us() - ttft; first_token = false; }
+                    else itl.push_back(pi::time_us() - itt_start);
+                    itt_start = pi::time_us();
+                }
+                if (n_out < out_cap) out[n_out++] = id;
+                if (id == eos) has_eos = true;
+                ++R.n_predict;
+                bool matches = false;
+                for (int s = 0; s < n_seq_dft; ++s) {
+                    if (!drafts[s].active) continue;
+                    if (i_dft < (int) drafts[s].tokens.size() && id == drafts[s].tokens[i_dft]) { s_keep = s; matches = true; }
+                    else drafts[s].active = false;
+                }
+                if (matches) { ++R.n_accept; ++R.n_accept_clean; ++n_past_tgt; ++n_past_dft; ++i_dft; continue; }
+
+                llama_kv_cache_seq_keep(dft, s_keep); cp(dft, s_keep, 0, -1, -1); llama_kv_cache_seq_keep(dft, 0);
+                rm(tgt, s_keep, n_past_tgt, -1);
+                llama_kv_cache_seq_keep(tgt, s_keep); cp(tgt, s_keep, 0, -1, -1); llama_kv_cache_seq_keep(tgt, 0);
+                for (int s = 0; s < n_seq_dft; ++s) { drafts[s].active = false; drafts[s].tokens.clear(); drafts[s].i_batch_tgt.clear(); }
+                drafts[0].tokens.push_back(id);                           // erased again after the speculation phase
+                drafts[0].i_batch_tgt.push_back(0);
+                batch_dft.clear();
+                batch_dft.add(id, n_past_dft, { 0 });
+                rm(dft, -1, n_past_dft, -1);
+                if (llama_decode(dft, batch_dft.view()) != 0) return -2;
+                ++n_past_dft;
+                break;
+            }
+            if (R.n_predict > P.n_predict || has_eos) break;
+
+            int n_seq_cur = 1, n_past_cur = n_past_dft;
+            for (int s = 0; s < n_seq_dft; ++s) { drafts[s].active = false; drafts[s].drafting = false; }
+            drafts[0].active = true; drafts[0].drafting = true; drafts[0].i_batch_dft = 0;
+            batch_tgt.clear();
+            batch_tgt.add(drafts[0].tokens[0], n_past_tgt, { 0 });
+
+            for (int i = 0; i < P.n_draft; ++i) {                          // tree drafting (speculative_orig:375-475)
+                batch_dft.clear();
+                for (int s = 0; s < n_seq_dft; ++s) drafts[s].skip = false;
+                for (int s = 0; s < n_seq_dft; ++s) {
+                    if (!drafts[s].drafting || drafts[s].skip) continue;
+                    cand cur[8]; int nc;
+                    top_candidates(dft, drafts[s].i_batch_dft, cur, nc);
+                    dft->n_sample++;
+                    if (nc == 0 || cur[0].p < P.p_accept) { drafts[s].drafting = false; continue; }
+                    std::vector<int> sa(1, s);
+                    for (int f = 1; f < 8 && f < nc; ++f) {
+                        if (n_seq_cur < n_seq_dft && cur[f].p > P.p_split) {
+                            rm(dft, n_seq_cur, -1, -1);
+                            cp(dft, s, n_seq_cur, -1, -1);
+                            for (auto & sq : batch_tgt.seq)              // earlier tokens of this branch also belong to the new one
+                                for (size_t q = 0; q < sq.size(); ++q) if (sq[q] == s) { sq.push_back(n_seq_cur); break; }
+                            drafts[n_seq_cur].active = true; drafts[n_seq_cur].drafting = true; drafts[n_seq_cur].skip = true;
+                            drafts[n_seq_cur].tokens = drafts[s].tokens;
+                            drafts[n_seq_cur].i_batch_dft = drafts[s].i_batch_dft;
+                            drafts[n_seq_cur].i_batch_tgt = drafts[s].i_batch_tgt;
+                            sa.push_back(n_seq_cur);
+                            n_seq_cur++;
+                        } else break;
+                    }
+                    for (size_t is = 0; is < sa.size(); ++is) {
+                        const llama_token tid = cur[is].id;
+                        const int sq = sa[is];
+                        drafts[sq].tokens.push_back(tid);
+                        drafts[sq].i_batch_tgt.push_back(batch_tgt.n_tokens());
+                        batch_tgt.add(tid, n_past_tgt + i + 1, { sq });
+                        drafts[sq].i_batch_dft = batch_dft.n_tokens();
+                        batch_dft.add(tid, n_past_cur, { sq });
+                        if (batch_tgt.n_tokens() > P.n_draft) drafts[sq].drafting = false;
+                    }
+                }
+                if (batch_dft.n_tokens() == 0) break;
+                if (llama_decode(dft, batch_dft.view()) != 0) return -2;
+                ++n_past_cur;
+                ++R.n_drafted;
+                if (batch_tgt.n_tokens() > P.n_draft) break;
+            }
+
+            llama_kv_cache_seq_keep(tgt, 0);                               // verify the tree in one target batch (speculative_orig:478-495)
+            for (int s = 1; s < n_seq_dft; ++s) cp(tgt, 0, s, -1, -1);
+            if (!has_run_first_token) { has_run_first_token = true; first_token = true; }
+            R.n_drafted_tokens += batch_tgt.n_tokens() - 1;
+            if (batch_tgt.n_tokens() > 1) R.n_runs_spec++; else R.n_runs_nonspec++;
+            if (llama_decode(tgt, batch_tgt.view()) != 0) return -2;
+            ++n_past_tgt;
+            for (int s = 0; s < n_seq_dft; ++s) { if (!drafts[s].active) continue; drafts[s].tokens.erase(drafts[s].tokens.begin()); }
+        }
+        const int64_t t_dec_end = pi::time_us();
+        R.t_enc_s = (t_enc_end - t_enc_start) / 1e6; R.t_dec_s = (t_dec_end - t_dec_start) / 1e6;
+        R.encode_tps = n_input / R.t_enc_s; R.decode_tps = R.n_predict / R.t_dec_s;
+        R.ttft_s = ttft / 1e6;
+        double sum = 0; for (int64_t v : itl) sum += (double) v;
+        R.itl_s = itl.empty() ? 0.0 : sum / itl.size() / 1e6;
+        return n_out;
+    }
 };
 
 }  // namespace
@@ -520,12 +681,13 @@ extern "C" int pipeinfer_speculative(struct llama_context * ctx_tgt, struct llam
                                      const llama_token * prompt, int32_t n_prompt, llama_token * out_tokens, int32_t out_cap, struct pipeinfer_spec_result * result) {
     driver d;
     d.tgt = ctx_tgt; d.dft = ctx_dft; d.P = *params;
+    if (params->mode < 0 || params->mode > 2) { fprintf(stderr, "pipeinfer_speculative: unknown mode %d\n", params->mode); return -1; }
     if (!ctx_tgt->cparams.logits_all || (params->mode != 2 && !ctx_dft->cparams.logits_all)) { fprintf(stderr, "pipeinfer_speculative: both contexts need logits_all (speculative.cpp:115)\n"); return -1; }
     ctx_tgt->canceled_batches.clear();                       // batch ids restart at 1 for every call
     if (ctx_dft) ctx_dft->canceled_batches.clear();
     for (llama_context * c : { ctx_tgt, ctx_dft })           // remote stages key their cancel notes by generation: -2 opens a new one
         if (c && c->remote && c->remote_ops.cancel) c->remote_ops.cancel(c->remote_ops.user, -2);
-    const int n = d.run(prompt, n_prompt, out_tokens, out_cap);
+    const int n = params->mode == 1 ? d.run_sync(prompt, n_prompt, out_tokens, out_cap) : d.run(prompt, n_prompt, out_tokens, out_cap);
     if (result) *result = d.R;
     return n;
 }

@@ -40,7 +40,7 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
             const float d = pi_h2f(blk[0] | (blk[1] << 8)), mn = pi_h2f(blk[2] | (blk[3] << 8));
             int sc, m; k4_scale_min(s, blk + 4, sc, m);
             const uint8_t * qs = blk + (w.type == PI_Q4_K ? 16 : 48);
-            const uint8_t qb = qs[(l >> 2) * 16 + j * 4 + (l & 3)];                               // k-major: lane k = l/4, dword j
+            const uint8_t qb = qs[(j >> 1) * 64 + (l >> 2) * 8 + (j & 1) * 4 + (l & 3)];          // p-half order: [p = j/2][lane k = l/4][e = j%2]
             int q = h ? qb >> 4 : qb & 0xF;
             if (w.type == PI_Q5_K) q += ((blk[16 + l] >> (2 * j + h)) & 1) << 4;
             const float d1 = d * sc, m1 = mn * m;
@@ -67,7 +67,7 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
         case PI_Q6_K: {
             const int64_t b = row * w.nb + (e >> 8);
             const int ee = (int) (e & 255), n = ee >> 7, g = (ee >> 5) & 3, l = ee & 31;
-            const uint8_t lo = w.p0[b * 192 + (l >> 2) * 16 + (2 * n + (g & 1)) * 4 + (l & 3)];   // ql[64n + 32(g&1) + l]
+            const uint8_t lo = w.p0[b * 192 + n * 64 + (l >> 2) * 8 + (g & 1) * 4 + (l & 3)];     // ql[64n + 32(g&1) + l]
             const uint8_t hb = w.p0[b * 192 + 128 + (l >> 2) * 8 + n * 4 + (l & 3)];               // qh[32n + l]
             const int q6 = ((g & 2) ? lo >> 4 : lo & 0xF) | (((hb >> (2 * g)) & 3) << 4);
             const int8_t q = (int8_t) (q6 - 32);
@@ -139,7 +139,26 @@ extern "C" int pi_op_norm(const float * x, const float * w, const float * b, flo
 //   Q8_0 (ggml-quants.c:702-760, AVX arm): d = amax/127 (stored f16); id = 127/amax; q = rne(x*id).
 // Output planes: see pi_q8_layout.
 // =================================================================================================================
-__global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums) {
+// MFMA operand planes (pi_q8_frag_layout): the lane that holds values 32j + 4k + (0..3) of a block writes them as f16 (i0, i2, i1, i3) into
+// the B-fragment slot of its token, for both sub-block pairings; lanes 16c write the pair sums of the block sums and the scale as floats
+struct q8k_frags { uint8_t * fa, * fb, * aux; };         // all null: not wanted (single-token calls)
+static __device__ __forceinline__ void wave_emit_frags(const q8k_frags & F, const int q[4], int s4, float d, int lane, int t, int64_t blk, int64_t nb) {
+    if (!F.fa) return;
+    const int k = lane & 7, j = lane >> 3, tl = t & 15;
+    const int64_t cb = (int64_t) (t >> 4) * nb + blk;                                       // (chunk, block)
+    const uint32_t h02 = (uint32_t) __half_as_ushort(__float2half_rn((float) q[0])) | (uint32_t) __half_as_ushort(__float2half_rn((float) q[2])) << 16;
+    const uint32_t h13 = (uint32_t) __half_as_ushort(__float2half_rn((float) q[1])) | (uint32_t) __half_as_ushort(__float2half_rn((float) q[3])) << 16;
+    const int ga = 2 * (j >> 2) + (j & 1), ea = (j >> 1) & 1, gb = 2 * (j >> 2) + ((j >> 1) & 1), eb = j & 1;
+    *(uint2 *) (F.fa + (((cb * 8 + k) * 64 + tl + 16 * ga) * 16 + ea * 8)) = make_uint2(h02, h13);
+    *(uint2 *) (F.fb + (((cb * 8 + k) * 64 + tl + 16 * gb) * 16 + eb * 8)) = make_uint2(h02, h13);
+    // s4: sum of the 16-group lane/4 (valid in every lane of the quad); pair sums like _mm_hadd_epi16 of the bsums
+    int s2 = s4 + pi_xor4(s4);                                                            // lanes 16c and 16c+8: groups (4c, 4c+1) and (4c+2, 4c+3)
+    const int sB = pi_partner<8>(s2);
+    if ((lane & 15) == 0) *(float2 *) (F.aux + cb * 1024 + 64 + (lane >> 4) * 128 + tl * 8) = make_float2((float) (short) s2, (float) (short) sB);
+    if (lane == 0) *(float *) (F.aux + cb * 1024 + tl * 4) = d;
+}
+
+__global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F) {
     const int t = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
     const int64_t nb = k >> 8;
     const float4 v = *(const float4 *) (x + (int64_t) t * k + (int64_t) blk * 256 + lane * 4);
@@ -167,6 +186,7 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__
     s += pi_partner<1>(s); s += pi_partner<2>(s);
     if ((lane & 3) == 0) bsums[((int64_t) t * nb + blk) * 16 + (lane >> 2)] = (int16_t) s;
     if (lane == 0) dd[(int64_t) t * nb + blk] = d;
+    wave_emit_frags(F, q, s, d, lane, t, blk, nb);
 }
 
 // one wave = 8 blocks of 32 = two groups of 4 blocks; values past k belong to the zero padding of the last group
@@ -190,7 +210,8 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__
 
 // ---- per-256 (Q8_K) / per-8x32 (Q8_0) quantisation of four consecutive values held by each lane of a wave ----------------
 // Same arithmetic as k_quantize_q8_K / k_quantize_q8_0 above; `blk` is the index of the 256-value chunk inside the row.
-static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int lane, int64_t row_blk, int8_t * qs, float * dd, int16_t * bsums) {
+static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int lane, int t, int64_t blk, int64_t nb, int8_t * qs, float * dd, int16_t * bsums, const q8k_frags & F) {
+    const int64_t row_blk = (int64_t) t * nb + blk;
     float amax = 0.0f, mx = 0.0f; int idx = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
@@ -213,6 +234,7 @@ static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int
     s += pi_partner<1>(s); s += pi_partner<2>(s);
     if ((lane & 3) == 0) bsums[row_blk * 16 + (lane >> 2)] = (int16_t) s;
     if (lane == 0) dd[row_blk] = d;
+    wave_emit_frags(F, q, s, d, lane, t, blk, nb);
 }
 static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int lane, int64_t tok_ng, int64_t e0, uint32_t * qs, uint16_t * dd) {
     float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
@@ -230,7 +252,7 @@ static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int
 // norm (rms / layer) * weight (+ bias) straight into the quantised activation planes; optionally also the fp32 result.
 // One workgroup per token; every wave normalises and quantises whole 256-value chunks (a Q8_K block, or eight Q8_0 blocks).
 __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ yf,
-                                                      int n, float eps, int rms, int vdt, int64_t ng, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums) {
+                                                      int n, float eps, int rms, int vdt, int64_t ng, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F) {
     __shared__ double sh[16];
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const float * xr = x + (int64_t) t * n;
@@ -322,9 +344,19 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
             }
             if (yf) *(float4 *) (yf + (int64_t) t * n + e0) = make_float4(ys[0], ys[1], ys[2], ys[3]);
         }
-        if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, (int64_t) t * (n >> 8) + (c0 >> 8), (int8_t *) qs, (float *) dd, bsums);
+        if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, t, c0 >> 8, n >> 8, (int8_t *) qs, (float *) dd, bsums, F);
         else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd);
     }
+}
+
+// where the quantisers put the MFMA operand planes of a Q8_K buffer (null for single-token calls and for Q8_0)
+static q8k_frags frags_of(int vdt, int64_t k, int n_tok, uint8_t * base) {
+    q8k_frags F = { nullptr, nullptr, nullptr };
+    if (vdt != PI_Q8_K || n_tok < pi_mmq_min_nt()) return F;
+    size_t fa, fb, fx;
+    pi_q8_frag_layout(k, n_tok, &fa, &fb, &fx);
+    F.fa = base + fa; F.fb = base + fb; F.aux = base + fx;
+    return F;
 }
 
 extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float * b, float * y_f32, int n, int n_tok, float eps, int rms, int vdt, void * q8, void * stream) {
@@ -336,14 +368,14 @@ extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float
     const int64_t ng = (n / 32 + 3) / 4;
     const int chunks = (int) ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const int threads = 64 * (chunks < 16 ? chunks : 16);
-    hipLaunchKernelGGL(k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob));
+    hipLaunchKernelGGL(k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base));
     PI_CHECK_LAUNCH();
     return 0;
 }
 
 // act(gate) [* up] straight into the quantised activation planes: which = 0 silu(gate)*up, 1 gelu(gate).  One wave per 256 values.
 __global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g, const float * __restrict__ u, int which, int64_t n, int vdt, int64_t ng,
-                                                    const uint16_t * __restrict__ tab, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums) {
+                                                    const uint16_t * __restrict__ tab, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F) {
     const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c0 = ((int64_t) blockIdx.x * 4 + wave) * 256, e0 = c0 + lane * 4;
     const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
@@ -357,7 +389,7 @@ __global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g,
 #pragma unroll
         for (int i = 0; i < 4; i++) { const float a = pi_h2f(tab[pi_f2h(gs[i])]); ys[i] = which == 0 ? a * us[i] : a; }
     }
-    if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, (int64_t) t * (n >> 8) + (c0 >> 8), (int8_t *) qs, (float *) dd, bsums);
+    if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, t, c0 >> 8, n >> 8, (int8_t *) qs, (float *) dd, bsums, F);
     else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd);
 }
 
@@ -371,7 +403,7 @@ extern "C" int pi_op_act_quantize(const float * gate, const float * up, int whic
     const int64_t chunks = ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const pi_tables & tb = pi_get_tables();
     hipLaunchKernelGGL(k_act_quant, dim3((unsigned) ((chunks + 3) / 4), n_tok), dim3(256), 0, (hipStream_t) stream, gate, up, which, n, vdt, ng,
-                       which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob));
+                       which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base));
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -383,7 +415,7 @@ extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, vo
     uint8_t * base = (uint8_t *) q8;
     if (vdt == PI_Q8_K) {
         if (k % 256) { pi_set_error("pi_op_quantize: Q8_K needs k %% 256 == 0 (k=%lld)", (long long) k); return -1; }
-        hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob));
+        hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob), frags_of(vdt, k, n_tok, base));
     } else if (vdt == PI_Q8_0) {
         if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 needs k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
         const int64_t ng = (k / 32 + 3) / 4;

@@ -1,0 +1,304 @@
+// Multi-token quantised mat-mat for verify batches and prompts (2 <= n_tok <= 16 per launch) on the matrix cores, BIT-EXACT with the
+// reference's x86 AVX2 arm — the same contract as mmvq.hip:
+//
+//   out[t][row] = residual[t][row] + vec_dot(W[row], act[t])
+//
+// Reference: ggml_compute_forward_mul_mat (ggml.c:9388-9597) -> ggml_vec_dot_q4_K_q8_K (ggml-quants.c:5318-5381), q5_K (:5967-6050),
+// q6_K (:6741-6810).  Per 256-block the AVX2 code forms eight int32 lane sums  sumi[k] = sum_j sc_j * sum_{i<4} w[32j+4k+i] * y[32j+4k+i]
+// (lane k = bytes 4k..4k+3 of every 32-value sub-block j), converts them to float and extends eight fp32 chains with ONE fma per block,
+// in block order:  acc[k] = fma(d_x * d_y, (float) sumi[k], acc[k]);  mins go through their own four (Q4_K) / one (Q5_K) chains.
+//
+// What is exact in any order is the integer part — and that part is a matrix product.  v_mfma_f32_16x16x32_f16 computes it without
+// rounding: one operand is (scale x weight) as f16 (<= 63*15 = 945 for Q4_K, <= 63*31 = 1953 for Q5_K; for Q6_K the int8 scale is split
+// sc = 16*sh + sl so that both 16*sh*w' and sl*w' are f16 integers), the other the int8 activation as f16; products and partial sums are
+// integers below 2^24, so every fp32 accumulation inside the MFMA is exact (tools_dev/mfma_exact.hip checks the instruction on hardware
+// at these magnitudes).  One MFMA per (block, lane k): K = 32 = the (j, i) index; A = 16 tokens, B = 16 weight rows.  The fp32 chains
+// stay on the VALU, one fma per block in block order: the reference's rounding points are kept, so the result has the same bits as the
+// VALU kernel and as the reference.
+//
+// Mapping.  The MFMA is issued "transposed" (tokens are the rows of A, weight rows the columns of B) so that the C tile puts weight row
+// r on lane (r, g) with tokens 4g..4g+3 in its four registers: the block scalars of the row (d, dmin, 6-bit scales, mins) are then in the
+// lane that loaded the row's block header, and the chains run straight from the MFMA result registers.
+// A workgroup is R row groups of 16 rows x S waves; wave s of a row group owns accumulator lanes k in [s*8/S, (s+1)*8/S) and mins lanes
+// c in [s*4/S, (s+1)*4/S) for ALL blocks of the row (the p-half weight order makes a wave's share of a block contiguous), so waves never
+// exchange anything until the final fold — no per-block barrier — and a row group streams S waves deep.  What IS shared is the
+// activation side: the f16 fragments, the tokens' d and block sums (written by the quantisers in exactly this image, elementwise.hip:
+// wave_emit_frags) are copied global -> LDS by DMA one tile of TB blocks ahead, once per workgroup.
+// Weights: each wave keeps a ring of 2*TB blocks in registers (its share: 8/S + 16 bytes per lane and block), refilled right after use.
+#include "mmvq_args.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+using pi_half8 = __attribute__((ext_vector_type(8))) _Float16;
+using pi_half2 = __attribute__((ext_vector_type(2))) _Float16;
+using pi_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+int pi_mmq_min_nt() {
+    static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 2; return n < 2 ? 2 : n; }();
+    return v;
+}
+bool pi_mmq_supported(int type) { return type == PI_Q4_K; }
+
+static __device__ __forceinline__ pi_half2 h2_from_bits(uint32_t u) { return __builtin_bit_cast(pi_half2, u); }
+static __device__ __forceinline__ uint32_t h2_bits(pi_half2 v) { return __builtin_bit_cast(uint32_t, v); }
+static __device__ __forceinline__ uint32_t pk_fma(uint32_t a, uint32_t b, uint32_t c) { return h2_bits(__builtin_elementwise_fma(h2_from_bits(a), h2_from_bits(b), h2_from_bits(c))); }
+static __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return h2_bits(h2_from_bits(a) * h2_from_bits(b)); }
+static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return h2_bits(h2_from_bits(a) + h2_from_bits(b)); }
+
+#define MQ_BLK_LDS 9216                         // LDS image of one block of activations: 8 fragments of 1 KB + 1 KB aux
+// s_waitcnt vmcnt(n) only
+#define MQ_STR_(x) #x
+#define MQ_STR(x) MQ_STR_(x)
+#define MQ_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+
+template <int TYPE, int S> struct mq_w { uint4 hdr; uint4 q[4 / S]; };                  // one lane's share of one block (Q4_K)
+
+template <int TYPE, int S, int R, int TB>
+__global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
+    static_assert(TYPE == PI_Q4_K, "types are added one by one");
+    static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = 1 + 4 / S;       // LW: vector loads per block of weights
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
+    const int r = lane & 15, gq = lane >> 4, p = gq >> 1, h = gq & 1;                     // weight row r, K-slice gq = (p, h): sub-blocks {4p+h, 4p+2+h}; C tile: tokens 4 gq ..
+    const int rg_raw = (int) blockIdx.x * R + rgl;
+    const bool active = rg_raw < n_groups;
+    const int rg = active ? rg_raw : n_groups - 1;
+    const int si = (rg >= g.seg[1].wave0) + (rg >= g.seg[2].wave0);
+    const mmvq_seg & sg = g.seg[si];
+    const int64_t row0 = (int64_t) (rg - sg.wave0) * 16;
+    const int rows = sg.M - row0 < 16 ? (int) (sg.M - row0) : 16;
+    const int64_t row = row0 + (r < rows ? r : rows - 1);
+    const int nb = g.nb, nt = g.nt, ntile = (nb + TB - 1) / TB;
+
+    // lane constants of the nibble-half: h = 0 takes (q & 0x000F000F) | 0x6400 = 1024 + n, scaled by s; h = 1 takes (q & 0x00F000F0) | 0x6400
+    // = 1024 + 16 n, scaled by s / 16 (exact: a power of two) — no shift, and (1024 + x n) * s' - 1024 * s' == n * s in one v_pk_fma_f16
+    const uint32_t nib_mask = h ? 0x00F000F0u : 0x000F000Fu;
+    const uint32_t h_scale = h ? 0x2C002C00u : 0x3C003C00u;                               // f16 pair (1/16, 1/16) : (1, 1)
+    uint32_t magic = 0x64006400u;                                                         // f16 pair (1024, 1024); kept in a VGPR so that (q & mask) | magic is one v_and_or_b32
+    asm volatile("" : "+v"(magic));
+
+    float acc[KS][4], accm[CS][4];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[kk][i] = 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < CS; cc++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) accm[cc][i] = 0.0f;
+
+    // a lane's share of a block: k in [s*KS, ..) of half p.  Uniform base + 32-bit lane offset (one VGPR per load instead of a 64-bit pointer)
+    const uint8_t * const wbase = sg.p0;
+    const uint32_t lane_off = (uint32_t) ((size_t) row * nb * 144);
+    constexpr int QOFF = 16;
+    const uint32_t share_off = QOFF + 64 * p + (64 / S) * s;
+    auto load_w = [&](int b, mq_w<TYPE, S> & W) __attribute__((always_inline)) {
+        const uint32_t bo = lane_off + (uint32_t) (b < nb ? b : nb - 1) * 144u;           // unconditional, clamped (see mmvq.hip on branches between a load and its use)
+        W.hdr = *(const uint4 *) (wbase + bo);
+#pragma unroll
+        for (int i = 0; i < 4 / S; i++) W.q[i] = *(const uint4 *) (wbase + (uint32_t) (bo + share_off + 16 * i));
+    };
+    // activation tile T -> LDS buffer: 9 pieces of 1 KB per block, dealt round-robin to the workgroup's waves, one DMA instruction each
+    // (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l).  Issued from inline asm: the compiler's wait-count pass drains
+    // vmcnt before every LDS read once it sees an LDS-DMA, which would serialise the weight ring; the wave counts its DMAs itself (MQ_WAIT_VM)
+    auto dma_tile = [&](int T, uint32_t buf) __attribute__((always_inline)) {
+        if (T < ntile) {
+#pragma unroll
+            for (int i = 0; i < (9 * TB + NW - 1) / NW; i++) {
+                const int piece = i * NW + wave;
+                if (piece < 9 * TB) {
+                    const int u = piece / 9, part = piece % 9;
+                    const int b = T * TB + u < nb ? T * TB + u : nb - 1;
+                    const uint8_t * src = (part < 8 ? g.frag + ((size_t) b * 8 + part) * 1024 : g.aux + (size_t) b * 1024) + lane * 16;
+                    const uint32_t dst = buf + u * MQ_BLK_LDS + part * 1024;
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
+            }
+        }
+    };
+    // workgroup barrier without the fence of __syncthreads (which waits for every outstanding load): LDS reads of this wave have returned
+    // (lgkmcnt), the DMA writes it issued have landed (the caller's MQ_WAIT_VM)
+    auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
+        // ---- block scalars from the row's header: d, dmin, this lane's two 6-bit scales (sub-blocks 4p+h, 4p+2+h), this wave's mins ----
+        const uint4 hdr = W.hdr;
+        const float dx = pi_h2f((uint16_t) (hdr.x & 0xffff)), dminx = pi_h2f((uint16_t) (hdr.x >> 16));
+        const uint32_t scA = hdr.y & 0x3f3f3f3fu, mA = hdr.z & 0x3f3f3f3fu;                               // get_scale_min_k4 (ggml-quants.c:1446-1453), four at a time
+        const uint32_t scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
+        const uint32_t mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
+        const uint32_t scw = (p ? scB : scA) >> (8 * h);
+        // integer scale -> f16 pair without a conversion: 0x6400 | s == 1024 + s
+        const uint32_t S1 = pk_mul(pk_add(__umul24(scw & 0xff, 0x00010001u) | 0x64006400u, 0xE400E400u), h_scale);            // (s1, s1) or (s1/16, s1/16)
+        const uint32_t S2 = pk_mul(pk_add(__umul24((scw >> 16) & 0xff, 0x00010001u) | 0x64006400u, 0xE400E400u), h_scale);
+        const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);                         // -1024 * s'
+        const float4 dy4 = *(const float4 *) (blk + 8192 + 16 * gq);                                       // d of tokens 4 gq .. 4 gq + 3
+        const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = dy[i] * dx;                                                     // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+            const uint4 qv = W.q[kk / 2];
+            const uint32_t q0 = (kk & 1) ? qv.z : qv.x, q1 = (kk & 1) ? qv.w : qv.y;                       // dwords (k, m = 2p) and (k, m = 2p + 1)
+            uint4 bw;
+            bw.x = pk_fma((q0 & nib_mask) | magic, S1, C1);                                                // sub-block 4p+h: bytes (i0, i2)
+            bw.y = pk_fma(((q0 >> 8) & nib_mask) | magic, S1, C1);                                         //                  bytes (i1, i3)
+            bw.z = pk_fma((q1 & nib_mask) | magic, S2, C2);                                                // sub-block 4p+2+h
+            bw.w = pk_fma(((q1 >> 8) & nib_mask) | magic, S2, C2);
+            const uint4 af = *(const uint4 *) (blk + (s * KS + kk) * 1024 + lane * 16);                    // tokens' fragment of accumulator lane k
+            const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[kk][i] = fmaf(d[i], c[i], acc[kk][i]);                         // (float) sumi[k] of row r, token 4 gq + i
+        }
+        // mins: acc_m[c] = fma(-y.d * dmin, (float) (m[2c]*(bs[4c]+bs[4c+1]) + m[2c+1]*(bs[4c+2]+bs[4c+3])), acc_m[c])   (ggml-quants.c:5339-5345)
+        float nd[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) nd[i] = -dy[i] * dminx;
+#pragma unroll
+        for (int cc = 0; cc < CS; cc++) {
+            const int c = s * CS + cc;
+            const uint32_t mw = ((c & 2) ? mB : mA) >> (16 * (c & 1));
+            const float m0 = (float) (mw & 0xff), m1 = (float) ((mw >> 8) & 0xff);
+            const float4 f01 = *(const float4 *) (blk + 8192 + 64 + c * 128 + gq * 32), f23 = *(const float4 *) (blk + 8192 + 64 + c * 128 + gq * 32 + 16);
+            const float fa[4] = { f01.x, f01.z, f23.x, f23.z }, fb[4] = { f01.y, f01.w, f23.y, f23.w };
+#pragma unroll
+            for (int i = 0; i < 4; i++) accm[cc][i] = fmaf(nd[i], fmaf(m0, fa[i], m1 * fb[i]), accm[cc][i]);   // the products are integers below 2^24: exact in any form
+        }
+    };
+
+    // ---- main loop: super-tiles of two tiles (LDS buffers 0 and 1); ring slot u is refilled for block b + D right after block b is consumed ----
+    mq_w<TYPE, S> ring[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) load_w(u, ring[u]);
+    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
+    const uint32_t dbuf0 = lds0, dbuf1 = lds0 + TB * MQ_BLK_LDS;
+    const uint8_t * buf0 = lds, * buf1 = lds + TB * MQ_BLK_LDS;
+    dma_tile(0, dbuf0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    for (int T0 = 0; T0 < ntile; T0 += 2) {
+        dma_tile(T0 + 1, dbuf1);
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const int b = T0 * TB + u;
+            if (b < nb) compute(ring[u], buf0 + u * MQ_BLK_LDS);
+            load_w(b + D, ring[u]);
+        }
+        MQ_WAIT_VM(TB * LW);                                               // everything older than this tile's refills has landed: the DMA of the next tile too
+        wg_barrier();
+        if (T0 + 1 >= ntile) break;
+        dma_tile(T0 + 2, dbuf0);
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const int b = (T0 + 1) * TB + u;
+            if (b < nb) compute(ring[TB + u], buf1 + u * MQ_BLK_LDS);
+            load_w(b + D, ring[TB + u]);
+        }
+        MQ_WAIT_VM(TB * LW);
+        wg_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (no DMA may still be writing LDS when the fold reuses it)
+    __syncthreads();
+
+    // ---- fold: the eight chains of every (row, token) like hsum_float_8, the four mins chains like the reference's two hadds ----
+    float * F = (float *) lds + (size_t) rgl * (8 * 16 * 17 + 4 * 16 * 17 + 256);       // [8 k][16 rows][17]
+    float * FM = F + 8 * 16 * 17;                                                         // [4 c][16 rows][17]
+    float * X = FM + 4 * 16 * 17;                                                         // [16 rows][16 tokens] results (RoPE epilogue)
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) F[((s * KS + kk) * 16 + r) * 17 + 4 * gq + i] = acc[kk][i];
+#pragma unroll
+    for (int cc = 0; cc < CS; cc++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) FM[((s * CS + cc) * 16 + r) * 17 + 4 * gq + i] = accm[cc][i];
+    __syncthreads();
+    const int tid_g = s * 64 + lane;                                                      // thread inside the row group
+    if (active) {
+        for (int idx = tid_g; idx < 256; idx += 64 * S) {
+            const int rr = idx >> 4, t = idx & 15;
+            float a[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = F[(k * 16 + rr) * 17 + t];
+            float v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+            const float m0 = FM[(0 * 16 + rr) * 17 + t], m1 = FM[(1 * 16 + rr) * 17 + t], m2 = FM[(2 * 16 + rr) * 17 + t], m3 = FM[(3 * 16 + rr) * 17 + t];
+            v = v + ((m0 + m2) + (m1 + m3));
+            if (rr < rows && t < nt) {
+                if (sg.store) X[rr * 16 + t] = v;
+                else {
+                    const int64_t o = (int64_t) t * sg.M + row0 + rr;
+                    sg.out[o] = sg.res ? sg.res[o] + v : v;
+                }
+            }
+        }
+    }
+    if (g.seg[0].store) {                                                                 // (a launch either stores all its segments through the epilogue or none)
+        // llm_build_kv_store / ggml_rope mode 0 (llama.cpp:3546-3577, ggml.c:11062-11163) as the epilogue of the projection, exactly as in
+        // k_mmvq_kq: rows 2i, 2i+1 of a head are neighbours in this row group; the rounding points are those of k_rope_kv
+        __syncthreads();
+        if (active) {
+            const int kvh = g.dyn ? g.dyn[0] : g.kv_head;
+            if (sg.store == 3) {
+                for (int j = tid_g; j < rows * nt; j += 64 * S) {
+                    const int rr = j / nt, t = j % nt;
+                    sg.dst16[(int64_t) (kvh + g.tok0 + t) * sg.stride16 + row0 + rr] = pi_f2h(X[rr * 16 + t]);
+                }
+            } else {
+                for (int j = tid_g; j < (rows / 2) * nt; j += 64 * S) {
+                    const int pr = j / nt, t = j % nt;
+                    const float x0 = X[(2 * pr) * 16 + t], x1 = X[(2 * pr + 1) * 16 + t];
+                    const int64_t rw = row0 + 2 * pr;
+                    const int i = (int) (rw % g.hd) >> 1;
+                    const float2 cs = *(const float2 *) (g.rope_cs + ((int64_t) g.pos[g.tok0 + t] * (g.hd / 2) + i) * 2);
+                    uint16_t * dd = sg.dst16 + (int64_t) ((sg.store == 2 ? kvh : 0) + g.tok0 + t) * sg.stride16 + rw;
+                    dd[0] = pi_f2h(x0 * cs.x - x1 * cs.y);
+                    dd[1] = pi_f2h(x0 * cs.y + x1 * cs.x);
+                }
+            }
+        }
+    }
+}
+
+#include <hip/hip_ext.h>
+
+template <int TYPE, int S, int R, int TB>
+static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr size_t tiles = (size_t) 2 * TB * MQ_BLK_LDS, fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
+    constexpr size_t lds = tiles > fold ? tiles : fold;
+    static bool attr_done = false;
+    if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_done = true; }
+    const unsigned grid = (unsigned) ((groups + R - 1) / R);
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
+    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
+}
+
+int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    mmvq_args & g = L.g;
+    int groups = 0;
+    for (int i = 0; i < MMVQ_MAX_SEG; i++) {
+        if (i < L.nseg) { g.seg[i].wave0 = groups; groups += (g.seg[i].M + 15) / 16; }
+        else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
+    }
+    if (type != PI_Q4_K) { pi_set_error("pi_mmq_launch: weight type %d has no MFMA kernel", type); return -1; }
+    // (waves per row group, row groups per workgroup): more waves per group for short matrices (enough waves to fill 256 CUs), more groups
+    // per workgroup for tall ones (the staged activations are shared by the workgroup).  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
+    static const int cfg_env = getenv("PI_MMQ_CFG") ? atoi(getenv("PI_MMQ_CFG")) : 0;
+    int cfg = groups >= 2048 ? 24 : groups >= 1024 ? 44 : 42;
+    if (cfg_env) cfg = cfg_env;
+    switch (cfg) {
+        case 14: mmq_go<PI_Q4_K, 1, 4, 2>(g, groups, stream, ea, eb); break;
+        case 22: mmq_go<PI_Q4_K, 2, 2, 3>(g, groups, stream, ea, eb); break;
+        case 24: mmq_go<PI_Q4_K, 2, 4, 3>(g, groups, stream, ea, eb); break;
+        case 41: mmq_go<PI_Q4_K, 4, 1, 3>(g, groups, stream, ea, eb); break;
+        case 44: mmq_go<PI_Q4_K, 4, 4, 3>(g, groups, stream, ea, eb); break;
+        default: mmq_go<PI_Q4_K, 4, 2, 3>(g, groups, stream, ea, eb); break;
+    }
+    PI_CHECK_LAUNCH();
+    return 0;
+}

@@ -23,33 +23,7 @@
 
 #define MMVQ_TILE 16            // groups of four 32-blocks staged in LDS per step (Q4_0/Q8_0 kernel)
 
-// up to three weight matrices of one type and width share a launch (wq/wk/wv, ffn_up/ffn_gate): one activation, more bytes
-// per kernel — at decode sizes a launch costs ~3.5 us before HBM is streaming, so fewer, larger launches matter.
-#define MMVQ_MAX_SEG 3
-struct mmvq_seg {
-    const uint8_t * p0, * p1, * p2;
-    float *         out;        // [n_tok][M]
-    const float *   res;        // nullable
-    int             M;
-    int             wave0;      // first wave (K-quant kernel) of this segment
-    // K-quant kernel, attention projections: where the rows go instead of `out` (pi_op_mul_mat_qkv_rope)
-    //   1  RoPE (pairs 2i, 2i+1), f16, query buffer  dst16[(tok0 + t) * stride16 + row]
-    //   2  RoPE, f16, K cache cell                   dst16[(kv_head + tok0 + t) * stride16 + row]
-    //   3  f16, V cache cell                         dst16[(kv_head + tok0 + t) * stride16 + row]
-    int             store;
-    uint16_t *      dst16;
-    int             stride16;
-};
-struct mmvq_args {
-    mmvq_seg seg[MMVQ_MAX_SEG];
-    const uint8_t * aq;         // activation planes (pi_q8_layout)
-    const uint8_t * ad;
-    const uint8_t * abs_;
-    int K, nb;                  // nb: super-blocks (K-quants) or groups of 4 blocks (Q4_0/Q8_0) per row
-    // RoPE + KV-store epilogue (seg.store != 0): positions of the launch's tokens, (cos, sin) table [pos][hd/2][2], {kv_head, n_kv} in device memory
-    const int32_t * pos; const float * rope_cs; const int32_t * dyn;
-    int kv_head, hd, tok0;
-};
+#include "mmvq_args.h"
 
 static __device__ __forceinline__ int bytes_sub(int v, int c) {            // per-byte v - c for bytes whose result fits int8 (no borrow across bytes)
     return (int) ((((uint32_t) v | 0x80808080u) - (uint32_t) c) ^ 0x80808080u);
@@ -93,8 +67,10 @@ static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk,
         constexpr int BS = TYPE == PI_Q4_K ? 144 : 176, QOFF = TYPE == PI_Q4_K ? 16 : 48;
         const uint8_t * p = w.p0 + (size_t) blk * BS;
         o.hdr = *(const uint4 *) p;
-        o.qa  = *(const uint4 *) (p + QOFF + 32 * c);
-        o.qb  = *(const uint4 *) (p + QOFF + 32 * c + 16);
+        // p-half order (runtime.hip: k_repack_k45): vector p holds dwords m = 2p, 2p+1 of accumulator lanes k = 2c and 2c+1
+        const uint4 l0 = *(const uint4 *) (p + QOFF + 16 * c), l1 = *(const uint4 *) (p + QOFF + 64 + 16 * c);
+        o.qa = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        o.qb = make_uint4(l0.z, l0.w, l1.z, l1.w);
         if constexpr (TYPE == PI_Q5_K) { const uint2 hh = *(const uint2 *) (p + 16 + 8 * c); o.h.x = hh.x; o.h.y = hh.y; }
     } else if constexpr (TYPE == PI_Q2_K) {                                  // runtime.hip: k_repack_q2_K
         o.qa  = *(const uint4 *) (w.p0 + (size_t) blk * 64 + 16 * c);        // qs: half 0 (elements 8c.., 8c+4..), half 1 (same)
@@ -108,8 +84,9 @@ static __device__ __forceinline__ void kq_load(const mmvq_seg & w, uint32_t blk,
         o.d   = ((const uint16_t *) w.p2)[blk];
     } else {
         const uint8_t * p = w.p0 + (size_t) blk * 192;
-        o.qa  = *(const uint4 *) (p + 32 * c);
-        o.qb  = *(const uint4 *) (p + 32 * c + 16);
+        const uint4 l0 = *(const uint4 *) (p + 16 * c), l1 = *(const uint4 *) (p + 64 + 16 * c);      // halves n = 0, 1: (ql[64n + 4k], ql[64n + 32 + 4k]) of k = 2c, 2c+1
+        o.qa  = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        o.qb  = make_uint4(l0.z, l0.w, l1.z, l1.w);
         o.h   = *(const uint4 *) (p + 128 + 16 * c);
         o.hdr = *(const uint4 *) (w.p1 + (size_t) blk * 16);
         o.d   = ((const uint16_t *) w.p2)[blk];
@@ -696,27 +673,40 @@ extern "C" int pi_kernel_timing_report(int type, int nt, double * avg_us, double
     return 0;
 }
 
-// host-side description of one launch: segments + bytes for the roofline report
-struct mmvq_launch { mmvq_args g; int nseg; int64_t m_total, m_min; double wbytes; bool any_res; bool rope = false; };
+
+// decides whether this launch of instance (type, nt) is one of the sampled ones; hands out its event pair
+static bool kt_begin(int type, int nt, hipEvent_t & ea, hipEvent_t & eb) {
+    bool sample = false;
+    const int ntc = nt <= 8 ? nt : 8;                      // (statistics keep one bucket for all wider batches)
+    pi_kt_sink * sink = g_kt_sink;
+    if (sink) {                                            // being captured into a graph: count per graph, no sampling (events of a graph cannot be read back)
+        bool found = false;
+        for (auto & c : sink->launches) if (c.type == type && c.nt == ntc) { c.count++; found = true; break; }
+        if (!found) sink->launches.push_back(pi_kt_count{ type, ntc, 1 });
+        return false;
+    }
+    if (g_kt_on) {
+        std::lock_guard<std::mutex> lk(g_kt_mu);
+        sample = (g_kt_launches[type & 15][ntc]++ % g_kt_every) == 0;
+        if (sample) { ea = kt_event(); eb = kt_event(); }
+    }
+    return sample;
+}
+// algorithmic bytes of a sampled launch: the weight matrices once + quantised activations + fp32 output (+ residual)
+static void kt_end(int type, int nt, const mmvq_launch & L, hipEvent_t ea, hipEvent_t eb) {
+    const double abytes = (double) nt * ((type == PI_Q4_0 || type == PI_Q8_0) ? (double) L.g.K / 32 * 34 : (double) L.g.K / 256 * 292);
+    const double obytes = (double) nt * L.m_total * 4 * (L.any_res ? 2 : 1);
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    g_kt.push_back(pi_kt_sample{ ea, eb, type, nt <= 8 ? nt : 8, L.wbytes + abytes + obytes });
+}
 
 template <int TYPE, int NT>
 static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
     mmvq_args & g = L.g;
-    bool sample = false; hipEvent_t ea = nullptr, eb = nullptr;
-    pi_kt_sink * sink = g_kt_sink;
-    if (sink) {                                            // being captured into a graph: count per graph, sample a fixed subset
-        bool found = false;
-        for (auto & c : sink->launches) if (c.type == TYPE && c.nt == NT) { sample = (c.count++ % sink->every) == 0; found = true; break; }
-        if (!found) { sink->launches.push_back(pi_kt_count{ TYPE, NT, 1 }); sample = true; }
-        if (sample) { std::lock_guard<std::mutex> lk(g_kt_mu); ea = kt_event(); eb = kt_event(); }
-    } else if (g_kt_on) {
-        std::lock_guard<std::mutex> lk(g_kt_mu);
-        sample = (g_kt_launches[TYPE & 15][NT]++ % g_kt_every) == 0;
-        if (sample) { ea = kt_event(); eb = kt_event(); }
-    }
     // sampled launches go through hipExtLaunchKernelGGL: its start/stop events carry the kernel's own begin/end timestamps (what
     // rocprofv3 reports as the duration); events recorded around a launch would add the dispatch gap (~3 us) to every sample
-    if (sink) sample = false;                                  // being captured into a graph: no sampling (events of a graph cannot be read back)
+    hipEvent_t ea = nullptr, eb = nullptr;
+    const bool sample = kt_begin(TYPE, NT, ea, eb);
     if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
         const int64_t M = g.seg[0].M;
         bool launched = false;
@@ -790,13 +780,7 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         };
         if (R == 1) go(std::integral_constant<int, 1>{}); else if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
     }
-    if (sample) {
-        // algorithmic bytes of this launch: the weight matrices once + quantised activations + fp32 output (+ residual)
-        const double abytes = (double) NT * ((TYPE == PI_Q4_0 || TYPE == PI_Q8_0) ? (double) g.K / 32 * 34 : (double) g.K / 256 * 292);
-        const double obytes = (double) NT * L.m_total * 4 * (L.any_res ? 2 : 1);
-        if (sink) sink->samples.push_back(pi_kt_sample{ ea, eb, TYPE, NT, L.wbytes + abytes + obytes });
-        else { std::lock_guard<std::mutex> lk(g_kt_mu); g_kt.push_back(pi_kt_sample{ ea, eb, TYPE, NT, L.wbytes + abytes + obytes }); }
-    }
+    if (sample) kt_end(TYPE, NT, L, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -839,13 +823,20 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     const uint8_t * base = (const uint8_t *) q8;
     const int64_t K = w0->ne0;
     const int64_t nbq = vdt == PI_Q8_K ? K / 256 : w0->ng;
-    for (int t0 = 0; t0 < n_tok; t0 += 8) {                   // verify batches are <= 8 wide; prompts loop over chunks of 8
-        const int nt = n_tok - t0 < 8 ? n_tok - t0 : 8;
+    // batches of PI_MMQ_MIN_NT tokens and more go to the matrix cores, 16 tokens per pass over the weights (mmq_mfma.hip); everything else
+    // (single tokens, types without an MFMA kernel) takes the VALU mat-vec, 8 tokens per pass
+    const bool mfma = vdt == PI_Q8_K && n_tok >= pi_mmq_min_nt() && pi_mmq_supported(w0->type);
+    size_t ofa = 0, ofb = 0, oax = 0;
+    if (mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
+    const int step = mfma ? 16 : 8;
+    for (int t0 = 0; t0 < n_tok; t0 += step) {
+        const int nt = n_tok - t0 < step ? n_tok - t0 : step;
         mmvq_launch L;
         L.nseg = n_w; L.m_total = 0; L.m_min = 1 << 30; L.wbytes = 0.0; L.any_res = false;
         L.g.K = (int) K; L.g.nb = (int) nbq;
         L.g.pos = rope ? rope->pos : nullptr; L.g.rope_cs = rope ? rope->cs : nullptr; L.g.dyn = rope ? rope->dyn : nullptr;
         L.g.kv_head = rope ? rope->kv_head : 0; L.g.hd = rope ? rope->hd : 2; L.g.tok0 = t0;
+        L.g.frag = nullptr; L.g.aux = nullptr; L.g.nt = nt;
         L.rope = rope != nullptr;
         for (int i = 0; i < n_w; i++) {
             const pi_weight * w = ws[i];
@@ -863,6 +854,17 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             L.g.aq = base + oq + (size_t) t0 * nbq * 128; L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr;
         }
         int rc = -1;
+        if (mfma) {
+            L.g.frag = base + (w0->type == PI_Q6_K ? ofb : ofa) + (size_t) (t0 / 16) * nbq * 8192;
+            L.g.aux = base + oax + (size_t) (t0 / 16) * nbq * 1024;
+            L.g.nt = nt;
+            hipEvent_t ea = nullptr, eb = nullptr;
+            const bool sample = kt_begin(w0->type, nt, ea, eb);
+            rc = pi_mmq_launch(w0->type, L, stream, ea, eb);
+            if (sample) kt_end(w0->type, nt, L, ea, eb);
+            if (rc) return rc;
+            continue;
+        }
         switch (w0->type) {
             case PI_Q2_K: rc = dispatch_nt<PI_Q2_K>(L, nt, stream); break;
             case PI_Q3_K: rc = dispatch_nt<PI_Q3_K>(L, nt, stream); break;

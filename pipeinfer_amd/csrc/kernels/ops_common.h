@@ -11,9 +11,9 @@
 // A weight matrix in HBM.  Bytes are only re-ordered at load time (never changed) so that lane k of an 8-lane row group —
 // the lane that owns bytes 4k..4k+3 of every 32-value group, exactly like lane k of the reference's AVX2 accumulators —
 // reads its share of a block with one or two 16-byte loads ("k-major" layouts):
-//   Q4_K (144 B)  [d,dmin,scales 16 B][qs: 8 lanes x 16 B]            lane k: dword j = original qs[32j + 4k .. +3], j = 0..3
-//   Q5_K (176 B)  [hdr 16 B][qh 32 B natural][qs: 8 lanes x 16 B]     same qs permutation; lane k also reads qh[4k .. +3]
-//   Q6_K (210 B)  p0: [blocks][192 B] = [8 lanes][16 B: ql[4k], ql[32+4k], ql[64+4k], ql[96+4k]] + [8 lanes][8 B: qh[4k], qh[32+4k]]   p1: scales [blocks][16]   p2: d [blocks] f16
+//   Q4_K (144 B)  [d,dmin,scales 16 B][qs: 2 halves p x 8 lanes k x 2 dwords e]   dword (p, k, e) = original qs[32(2p+e) + 4k .. +3]
+//   Q5_K (176 B)  [hdr 16 B][qh 32 B natural][qs as for Q4_K]          lane k also reads qh[4k .. +3]
+//   Q6_K (210 B)  p0: [blocks][192 B] = [2 halves n][8 lanes k][8 B: ql[64n+4k], ql[64n+32+4k]] + [8 lanes][8 B: qh[4k], qh[32+4k]]   p1: scales [blocks][16]   p2: d [blocks] f16
 //   Q4_0 (18 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][4 dwords c][4 blocks b]   p1: d [groups][4] f16
 //   Q8_0 (34 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][8 lanes k][4 blocks b]    p1: d [groups][4] f16
 //   F32 / F16     native rows
@@ -47,6 +47,10 @@ const pi_tables & pi_get_tables();
             return -1;                                                                       \
         }                                                                                    \
     } while (0)
+
+// smallest batch width that takes the MFMA kernel (mmq_mfma.hip) instead of the VALU mat-vec; the quantisers write its operand
+// planes from the same width on.  PI_MMQ_MIN_NT overrides (tuning / A-B tests; read once).
+int pi_mmq_min_nt();
 
 static inline int pi_type_blck(int t) {
     switch (t) { case PI_F32: case PI_F16: return 1; case PI_Q4_0: case PI_Q8_0: return 32; default: return 256; }

@@ -111,16 +111,19 @@ __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restr
     const uint8_t * s = src + i * bsize; uint8_t * d = dst + i * bsize;
     for (int b = 0; b < qs_off; b++) d[b] = s[b];
     const uint32_t * sq = (const uint32_t *) (s + qs_off); uint32_t * dq = (uint32_t *) (d + qs_off);
-    for (int k = 0; k < 8; k++) for (int j = 0; j < 4; j++) dq[k * 4 + j] = sq[j * 8 + k];
+    // "p-half" order: dword (k, m) — bytes 4k..4k+3 of the m-th 32-byte qs group — goes to [p = m >> 1][k][e = m & 1].  The decode kernel's quad
+    // lane c still reads two 16-byte vectors (p = 0, 1) that hold all four dwords of its accumulator lanes 2c, 2c+1; the MFMA kernel's lane
+    // (row, p, h) reads the 64 contiguous bytes of half p and takes nibble-half h of every dword (mmq_mfma.hip)
+    for (int k = 0; k < 8; k++) for (int m = 0; m < 4; m++) dq[(m >> 1) * 16 + k * 2 + (m & 1)] = sq[m * 8 + k];
 }
 __global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint16_t * d, int64_t nblocks) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks) return;
     const uint8_t * b = src + i * 210;                       // 2-byte aligned only: assemble dwords from bytes
     auto ld = [&](int off) { return (uint32_t) b[off] | (uint32_t) b[off + 1] << 8 | (uint32_t) b[off + 2] << 16 | (uint32_t) b[off + 3] << 24; };
-    uint32_t * o = (uint32_t *) (a + i * 192);                // [8 lanes][4 dwords of ql] then [8 lanes][2 dwords of qh]
+    uint32_t * o = (uint32_t *) (a + i * 192);                // ql: [2 halves n][8 lanes k][2 dwords x] (p-half order, like Q4_K), then qh: [8 lanes][2 dwords n]
     for (int k = 0; k < 8; k++) {
-        o[k * 4 + 0] = ld(4 * k); o[k * 4 + 1] = ld(32 + 4 * k); o[k * 4 + 2] = ld(64 + 4 * k); o[k * 4 + 3] = ld(96 + 4 * k);
+        for (int n = 0; n < 2; n++) { o[n * 16 + k * 2 + 0] = ld(64 * n + 4 * k); o[n * 16 + k * 2 + 1] = ld(64 * n + 32 + 4 * k); }
         o[32 + k * 2 + 0] = ld(128 + 4 * k); o[32 + k * 2 + 1] = ld(160 + 4 * k);
     }
     for (int k = 0; k < 16; k++) sc[i * 16 + k] = b[192 + k];
@@ -254,8 +257,29 @@ extern "C" void pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, siz
     if (off_bsums) *off_bsums = qs + d;
 }
 
+// Q8_K only — operand planes of the multi-token MFMA kernel (mmq_mfma.hip), written by the quantisers beside the planes above when
+// n_tok >= PI_MMQ_MIN_NT, in chunks of 16 tokens:
+//   frag_a, frag_b [chunk][K/256][8 k][64 lanes][8 x f16]   the int8 values as f16, already in the B-operand lane order of
+//                  v_mfma_f32_16x16x32_f16: lane = (token % 16) + 16 g holds the eight values (sub-block j, bytes 4k..4k+3) of the two
+//                  sub-blocks of K-slice g, in the order (i0, i2, i1, i3).  frag_a: slice g = (p, h) = sub-blocks {4p+h, 4p+2+h}
+//                  (Q4_K / Q5_K nibble pairing), frag_b: slice g = (n, hh) = {4n+2hh, 4n+2hh+1} (Q6_K pairing)
+//   aux            [chunk][K/256][1 KB]: d of the 16 tokens (16 floats), then for c = 0..3 the 16 tokens' float2
+//                  { bsums[4c]+bsums[4c+1], bsums[4c+2]+bsums[4c+3] } (the int16 pair sums of _mm_hadd_epi16, as floats) at 64 + 128 c; rest unused
+extern "C" void pi_q8_frag_layout(int64_t k, int n_tok, size_t * off_fa, size_t * off_fb, size_t * off_aux) {
+    size_t oq, od, ob;
+    pi_q8_layout(PI_Q8_K, k, n_tok, &oq, &od, &ob);
+    const size_t chunks = (size_t) (n_tok + 15) / 16, nb = (size_t) (k / 256);
+    const size_t fa = ob + align256((size_t) n_tok * (k / 16) * 2), frag = chunks * nb * 8 * 1024;
+    if (off_fa) *off_fa = fa;
+    if (off_fb) *off_fb = fa + frag;
+    if (off_aux) *off_aux = fa + 2 * frag;
+}
+
 extern "C" size_t pi_q8_nbytes(int vdt, int64_t k, int n_tok) {
     size_t oq, od, ob;
     pi_q8_layout(vdt, k, n_tok, &oq, &od, &ob);
-    return ob + (vdt == PI_Q8_K ? align256((size_t) n_tok * (k / 16) * 2) : 0);
+    if (vdt != PI_Q8_K) return ob;
+    size_t oa;
+    pi_q8_frag_layout(k, n_tok, nullptr, nullptr, &oa);
+    return oa + (size_t) ((n_tok + 15) / 16) * (size_t) (k / 256) * 1024;
 }

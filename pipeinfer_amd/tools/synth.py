@@ -339,7 +339,7 @@ def _vocab_kv(w, arch, n_vocab, vocab=None):
 
 
 def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random", noise=1.0, quantizer=None, vocab=None,
-                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0, only=None):
+                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0, only=None, pi_flip=0.0):
     """quantizer(ttype, f32 [rows,k]) -> uint8 blocks: when given (tests: the REAL reference quantiser), every weight is
     drawn as N(0,std^2) floats and quantised with it; otherwise blocks are filled directly (see module docstring).
     only(name) -> bool: tensors for which it is False become holes in the file (every tensor has its own seed, so a pipeline
@@ -363,6 +363,15 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
     _vocab_kv(w, arch, n_vocab, vocab)
 
     pi = np.random.default_rng(pi_seed).permutation(n_vocab) if structure == "bigram" else None
+    if pi is not None and pi_flip > 0.0:
+        # a DRAFT model that is wrong about a fixed fraction of the vocabulary: for those tokens its bigram points somewhere else.  The
+        # target (pi_flip = 0) follows pi, so the draft's per-token acceptance is ~ 1 - pi_flip BY CONSTRUCTION, with large logit margins in
+        # both models — unlike disagreement produced by layer noise, which only appears where the target's top two logits are nearly tied
+        # (and a near tie can flip with the KV-cell layout, see DESIGN.md on losslessness)
+        fr = np.random.default_rng(pi_seed ^ 0xF11B)
+        wrong = fr.random(n_vocab) < pi_flip
+        pi = pi.copy()
+        pi[wrong] = (pi[wrong] + 1 + fr.integers(0, n_vocab - 1, int(wrong.sum()))) % n_vocab
     depth_scale = min(1.0, float(np.sqrt((11008.0 * 4096.0 * 32.0) / (float(n_ff) * n_embd * n_layer))))
     emb_cache = {}
 
@@ -386,8 +395,12 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
                 if role == "embd":
                     mat = e * np.float32(signal)
                 else:
-                    mat = np.empty_like(e)
-                    mat[pi] = e * np.float32(head_gain / np.sqrt(n_embd))   # logit of pi[t] ~ head_gain*sqrt(n_embd)*cos(h, e_t); unrelated logits ~ N(0, head_gain^2)
+                    if pi_flip > 0.0:                                        # not a permutation any more: rows with several predecessors add up, rows with none stay zero
+                        mat = np.zeros_like(e)
+                        np.add.at(mat, pi, e * np.float32(head_gain / np.sqrt(n_embd)))
+                    else:
+                        mat = np.empty_like(e)
+                        mat[pi] = e * np.float32(head_gain / np.sqrt(n_embd))   # logit of pi[t] ~ head_gain*sqrt(n_embd)*cos(h, e_t); unrelated logits ~ N(0, head_gain^2)
                 return (quantizer or quantize_simple)(ttype, mat) if quantizer else quantize_simple(ttype, mat)
             # "bigram": the residual-writing tensors (wo, ffn_down) carry the noise.  What a layer adds to the stream grows like
             # sqrt(n_ff * n_embd) and accumulates over n_layer, so the knob is normalised to the Llama-2-7B shape (never upwards:
