@@ -8,12 +8,17 @@ PipeInfer driver (reference recipe examples/speculative/scripts/dolphin_tinyllam
 -np 3 -c 1024 -n 128, greedy, --ignore-eos).  `value` = accepted tokens per second of decode time over the K timed steps
 (speculative.cpp:697 definition, summed over steps), with every weight already resident in HBM.
 
-Workload at N=1 (BASELINE.json configs[1]): Llama-2-7B Q4_K_M target + TinyLlama-1.1B Q4_K_M draft, both on one MI355X,
-draft and target contexts on separate HIP streams.  Weights are shape-exact synthetic GGUFs (no network): see
-pipeinfer_amd/tools/synth.py — "bigram" structure so that draft and target agree on a realistic fraction of tokens.
+Workload at N=1: the configuration BASELINE.json's metric is quoted on — Llama-2-70B Q4_K_M target + TinyLlama-1.1B Q4_K_M
+draft; both fit one MI355X (41 GB + 0.7 GB), draft and target contexts on separate HIP streams.  `value` is the
+reference-faithful PipeInfer driver (mode 0: asynchronous continuous speculation, no additions).  The same prompts are also
+run target-only (mode 2) and with the reference's synchronous tree speculation (mode 1, examples/speculative_orig): those rates
+are reported under `other_schedules`, never as `value`.  Weights are shape-exact synthetic GGUFs (no network): see
+pipeinfer_amd/tools/synth.py — "bigram" structure, the draft is wrong about a fixed fraction of the vocabulary so that the
+acceptance rate is a controlled quantity with large logit margins in both models.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -29,50 +34,72 @@ from pipeinfer_amd import llama as LL  # noqa: E402
 from pipeinfer_amd.tools import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+METRIC = "accepted tokens/sec + acceptance rate, 70B Q4_K target / 1.1B draft"
 WORKLOADS = {
     # name: (target spec, target ftype, draft spec, draft ftype)
-    "7b": ("llama-2-7b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),
-    "70b": ("llama-2-70b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),
+    "70b": ("llama-2-70b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),             # the configuration the metric is quoted on
+    "7b": ("llama-2-7b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),               # BASELINE configs[1]
     "tiny": ("tiny-llama-b", "q4_k_m", "tiny-llama", "q4_k_m"),
     "1b": ("tinyllama-1.1b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),          # the draft model on its own (use with --mode 2)
     "70b-q3km": ("llama-2-70b", "q3_k_m", "tinyllama-1.1b", "q4_k_m"),       # the paper's Dolphin-70B Q3_K_M setup (README.md:165)
 }
+TYPE_NAMES = {10: "Q2_K", 11: "Q3_K", 12: "Q4_K", 13: "Q5_K", 14: "Q6_K", 2: "Q4_0", 8: "Q8_0"}
 
 
-def model_path(cache, spec, ftype, seed, signal, noise):
-    return os.path.join(cache, f"{spec}-{ftype}-bigram-s{seed}-g{signal}-n{noise}.gguf")
+def model_path(cache, spec, ftype, seed, signal, noise, flip=0.0, layers=None):
+    tag = f"-f{flip}" if flip else ""
+    tag += f"-l{layers[0]}+{layers[1]}" if layers else ""
+    return os.path.join(cache, f"{spec}-{ftype}-bigram-s{seed}-g{signal}-n{noise}{tag}.gguf")
 
 
-def ensure_model(cache, spec, ftype, seed, signal, noise):
+def ensure_model(cache, spec, ftype, seed, signal, noise, flip=0.0, layers=None):
     os.makedirs(cache, exist_ok=True)
-    path = model_path(cache, spec, ftype, seed, signal, noise)
+    path = model_path(cache, spec, ftype, seed, signal, noise, flip, layers)
     if not os.path.exists(path):
         tmp = path + f".tmp{os.getpid()}"
         t0 = time.time()
-        synth.write_model(tmp, spec, ftype, seed=seed, structure="bigram", signal=signal, noise=noise)
+        synth.write_model(tmp, spec, ftype, seed=seed, structure="bigram", signal=signal, noise=noise, pi_flip=flip, layers=layers)
         os.replace(tmp, path)
         print(f"[bench] generated {path} ({os.path.getsize(path) / 1e9:.2f} GB) in {time.time() - t0:.1f}s", file=sys.stderr)
     return path
 
 
-def cpu_baseline(tgt_path, n_tokens, n_prompt):
-    """Reference CPU kernels (oracle/_ref: the reference's ggml compiled from its own sources) decoding the SAME target model
-    token by token on the host cores; falls back to our C port of them (oracle/liboracle.so).  Test infrastructure: only this
-    leg of bench.py touches oracle/."""
+def kernel_source_sha():
+    """sha of the kernel sources: profiles/ files carry the sha of the code they were measured on, and are only quoted when it matches"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pipeinfer_amd", "csrc", "kernels")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(workload, kernel_key):
+    """HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): bench.py cannot
+    run the profiler on itself.  The file is only quoted if it was measured on THIS kernel source (sha) and workload."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_fetch_size_{workload}.json")))
+    except Exception:
+        return None, f"no committed PMC pass for workload {workload}"
+    if pmc.get("kernel_src_sha16") != kernel_source_sha():
+        return None, f"profiles/r02_pmc_fetch_size_{workload}.json was measured on kernel sources {pmc.get('kernel_src_sha16')}, these are {kernel_source_sha()}: not quoted"
+    k = pmc.get("kernels", {}).get(kernel_key)
+    if not k:
+        return None, f"profiles/r02_pmc_fetch_size_{workload}.json has no entry for {kernel_key}"
+    return k["avg_fetch_bytes_per_launch"], f"profiles/r02_pmc_fetch_size_{workload}.json"
+
+
+def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):
     from tests import oracle_lib as O
-    # ggml's spin-waiting thread pool stops scaling long before a 256-thread host is full: use at most 32 threads and say so
-    cores = min(os.cpu_count() or 1, int(os.environ.get("PIPEINFER_CPU_THREADS", "32")))
-    rng = np.random.default_rng(7)
-    n_vocab = None
     if O.have_ref() and O.ref() is not None:
-        m = O.RefModel(tgt_path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2, n_threads=cores)
+        m = O.RefModel(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2, n_threads=cores)
         kind = "reference"
     else:
         O.oracle().o_set_threads(cores)
-        m = O.OracleModel(tgt_path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2)
+        m = O.OracleModel(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2)
         kind = "port"
-    n_vocab = m.n_vocab
-    prompt = [int(x) for x in rng.integers(3, n_vocab, n_prompt)]
+    rng = np.random.default_rng(7)
+    prompt = [int(x) for x in rng.integers(3, m.n_vocab, n_prompt)]
     lg = m.decode(prompt, list(range(n_prompt)), [[0]] * n_prompt)
     cur = int(np.argmax(lg[-1]))
     t0 = time.time()
@@ -81,20 +108,44 @@ def cpu_baseline(tgt_path, n_tokens, n_prompt):
         lg = m.decode([cur], [n_prompt + i], [[0]])
         cur = int(np.argmax(lg[0]))
         done += 1
-        if time.time() - t0 > 25.0:          # bounded sample
+        if time.time() - t0 > budget_s:          # bounded sample
             break
     dt = time.time() - t0
-    n_tokens = done
     m.close()
-    return {"value": n_tokens / dt, "unit": "tokens/s", "cores": cores, "kind": kind,
-            "sample": f"target-only greedy decode of {n_tokens} tokens after a {n_prompt}-token prompt, same synthetic GGUF, n_threads={cores}"}
+    return dt / done, done, kind
+
+
+def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_prompt=4):
+    """Reference CPU kernels (oracle/_ref: the reference's ggml compiled from its own sources) decoding the target model token by
+    token on the host cores; falls back to our C port of them (oracle/liboracle.so).  Test infrastructure: only this leg of bench.py
+    touches oracle/.  Models that fit the time budget are decoded whole; the 70B target is timed on two depth-truncated copies (4 and 8
+    layers with the tensor types of layers 8..15 of the 80 — half of them "more bits" layers, like the whole model) and extrapolated
+    linearly in the layer count (decode cost is additive per layer: BASELINE.md section 2, method B1)."""
+    # ggml's spin-waiting thread pool stops scaling long before a 256-thread host is full: use at most 32 threads and say so
+    cores = min(os.cpu_count() or 1, int(os.environ.get("PIPEINFER_CPU_THREADS", "32")))
+    n_layer = synth.SPECS[tspec][1]
+    if n_layer <= 32:
+        spt, done, kind = _time_cpu_model(tgt_path, n_tokens, 16, cores, 25.0)
+        return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "kind": kind,
+                "sample": f"target-only greedy decode of {done} tokens after a 16-token prompt, same synthetic GGUF, n_threads={cores}"}
+    p4 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 4))
+    p8 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 8))
+    t4, d4, kind = _time_cpu_model(p4, n_tokens, n_prompt, cores, 10.0)
+    t8, d8, _ = _time_cpu_model(p8, n_tokens, n_prompt, cores, 15.0)
+    per_layer = max(1e-9, (t8 - t4) / 4.0)
+    head = max(0.0, t4 - 4.0 * per_layer)
+    spt = head + n_layer * per_layer
+    return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "kind": kind,
+            "sample": f"target-only greedy decode, reference kernels on {cores} threads: {d4}+{d8} tokens on 4- and 8-layer copies of the {n_layer}-layer model (tensor types of "
+                      f"layers 8..15, embedding + lm_head included) -> {per_layer * 1e3:.2f} ms per layer + {head * 1e3:.2f} ms head, extrapolated linearly to {n_layer} layers "
+                      f"= {spt * 1e3:.0f} ms per token"}
 
 
 def lossless_diagnostic(ct, prompt, ref_tokens, spec_tokens, n_predict):
     """Speculative and target-only output differ: report where, and how close the call was.  Every run of the engine equals the
-    reference arithmetic bit for bit (tests/trace_compare_worker.py), but that arithmetic depends on the KV-cell layout (attention
-    sums run in cell order), and f16 / Q8 re-quantisation amplifies the last-bit differences; on random-weight models a different
-    layout can flip a close argmax.  The logits below are those of the common prefix evaluated as one batch."""
+    reference arithmetic bit for bit (tests/test_gpu_engine.py: per-run oracle comparison at these shapes), but that arithmetic depends
+    on the KV-cell layout (attention sums run in cell order), and f16 / Q8 re-quantisation amplifies the last-bit differences; on
+    random-weight models a different layout can flip a close argmax.  The logits below are those of the common prefix evaluated as one batch."""
     bad = next(i for i in range(n_predict) if ref_tokens[i] != spec_tokens[i])
     ct.kv_clear()
     seq = list(prompt) + [int(t) for t in ref_tokens[:bad]]
@@ -107,12 +158,40 @@ def lossless_diagnostic(ct, prompt, ref_tokens, spec_tokens, n_predict):
                     "speculative generation places tokens in other cells than a target-only one: on random-weight models a near tie can flip (DESIGN.md section 7)"}
 
 
+def summarize(results):
+    n_tok = sum(r["n_predict"] for r in results)
+    t_dec = sum(r["t_dec_s"] for r in results)
+    drafted = sum(r["n_drafted_tokens"] for r in results)
+    acc_clean = sum(r["n_accept_clean"] for r in results)
+    acc_ref = 100.0 * sum(r["n_accept"] for r in results) / max(1, sum(r["n_drafted"] for r in results))
+    spec_runs = sum(r["n_runs_spec"] for r in results)
+    return {"tokens_per_s": round(n_tok / t_dec, 2),
+            "accepted_draft_tokens": acc_clean, "drafted_tokens": drafted,
+            "rate": round(acc_clean / drafted, 4) if spec_runs > 0 and drafted > 0 else None,          # undefined without speculation
+            "reference_formula_pct": round(acc_ref, 2) if spec_runs > 0 else None,
+            "spec_runs": spec_runs, "nonspec_runs": sum(r["n_runs_nonspec"] for r in results), "canceled_runs": sum(r["n_runs_canceled"] for r in results),
+            "draft_paused_tokens": sum(r["n_draft_paused"] for r in results), "draft_catchups": sum(r["n_draft_catchups"] for r in results)}
+
+
+def kernel_timing_table(lib):
+    """per (weight type, batch width) statistics of the sampled mat-vec / mat-mat launches: (type, nt, avg us, avg bytes, sampled, launches)"""
+    rows = []
+    for t in TYPE_NAMES:
+        for nt in range(1, 9):
+            us, by, ns, nl = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
+            lib.pi_kernel_timing_report(t, nt, C.byref(us), C.byref(by), C.byref(ns), C.byref(nl))
+            if ns.value:
+                rows.append({"type": TYPE_NAMES[t], "n_tok": nt if nt < 8 else "8+", "avg_us": round(us.value, 3), "alg_bytes": round(by.value), "sampled": int(ns.value),
+                             "launches": int(nl.value), "GBps": round(by.value / (us.value * 1e-6) / 1e9, 1), "gpu_ms_total": round(us.value * nl.value * 1e-3, 3)})
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("PIPEINFER_WORKLOAD", "7b"), choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("PIPEINFER_WORKLOAD", "70b"), choices=list(WORKLOADS))
     ap.add_argument("--n-predict", type=int, default=128)
     ap.add_argument("--n-prompt", type=int, default=128)
     ap.add_argument("--n-draft", type=int, default=3)
@@ -121,14 +200,18 @@ def main():
     ap.add_argument("--p-split", type=float, default=0.9)
     ap.add_argument("--n-ctx", type=int, default=1024)
     ap.add_argument("--signal", type=float, default=float(os.environ.get("PIPEINFER_SIGNAL", "1.0")))
-    ap.add_argument("--noise", type=float, default=float(os.environ.get("PIPEINFER_NOISE", "0.8")))
+    ap.add_argument("--noise", type=float, default=float(os.environ.get("PIPEINFER_NOISE", "0.25")))
+    ap.add_argument("--draft-miss", type=float, default=float(os.environ.get("PIPEINFER_DRAFT_MISS", "0.3")),
+                    help="fraction of the vocabulary the synthetic draft model predicts wrongly (acceptance ~ 1 - this)")
     ap.add_argument("--cache", default=os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-schedules", action="store_true", help="skip the untimed-for-`value` runs of modes 1 and 2")
     ap.add_argument("--cpu-tokens", type=int, default=8)
-    ap.add_argument("--mode", type=int, default=0, help="0 PipeInfer, 2 target only")
+    ap.add_argument("--mode", type=int, default=0, help="schedule of the timed steps: 0 PipeInfer (reference-faithful, the default), 1 synchronous speculation, 2 target only")
     ap.add_argument("--min-spec-iters", type=int, default=0)
-    ap.add_argument("--adaptive-window", type=int, default=4, help="accepted tokens without a speculative run before the draft is paused (0: never, the reference behaviour)")
-    ap.add_argument("--adaptive-pause", type=int, default=64, help="tokens the draft sits out once paused (doubles up to 16x while no speculation happens)")
+    ap.add_argument("--max-inflight", type=int, default=0)
+    ap.add_argument("--adaptive-window", type=int, default=0, help="our adaptive draft pause (0: off = the reference behaviour)")
+    ap.add_argument("--adaptive-pause", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,23 +222,21 @@ def main():
 
     tspec, tft, dspec, dft = WORKLOADS[args.workload]
     tgt_path = ensure_model(args.cache, tspec, tft, 0x5EED, args.signal, args.noise)
-    dft_path = ensure_model(args.cache, dspec, dft, 0xD4AF, args.signal, args.noise)
+    dft_path = ensure_model(args.cache, dspec, dft, 0xD4AF, args.signal, args.noise, flip=args.draft_miss)
 
     lib = L.load()
     L.check(lib.pi_device_init(0), "pi_device_init")
     t0 = time.time()
     mt, md = LL.Model(tgt_path), LL.Model(dft_path)
     ct, cd = LL.Context(mt, n_ctx=args.n_ctx, n_batch=512), LL.Context(md, n_ctx=args.n_ctx, n_batch=512)
-    cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "0")))
+    cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "1")))
     ct.set_priority(int(os.environ.get("PIPEINFER_TARGET_PRIORITY", "0")))
-    n_draft_cus = int(os.environ.get("PIPEINFER_DRAFT_CUS", "0"))
-    if n_draft_cus > 0 and args.mode == 0:
-        cd.set_cu_range(0, n_draft_cus); ct.set_cu_range(n_draft_cus, 256)
     ct.prepare(); cd.prepare()
     print(f"[bench] models resident in HBM after {time.time() - t0:.1f}s", file=sys.stderr)
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
-                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, adaptive_window=args.adaptive_window, adaptive_pause=args.adaptive_pause)
+                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, max_inflight=args.max_inflight,
+                adaptive_window=args.adaptive_window, adaptive_pause=args.adaptive_pause)
     rng = np.random.default_rng(0xBEEF)
     prompts = [[int(x) for x in rng.integers(3, mt.n_vocab, args.n_prompt)] for _ in range(args.warmup + args.steps + 1)]
 
@@ -164,7 +245,7 @@ def main():
         kw = dict(spec); kw.update(over)
         return LL.speculative(ct, cd, prompts[i], **kw)
 
-    # lossless check (also the first warm-up): target-only greedy == speculative output on the same prompt
+    # lossless check (also the first warm-up): target-only greedy == the timed schedule's output on the same prompt
     ref_tokens, _ = generation(0, mode=2)
     spec_tokens, _ = generation(0)
     lossless = ref_tokens[:args.n_predict] == spec_tokens[:args.n_predict]
@@ -182,77 +263,68 @@ def main():
     L.check(lib.pi_device_sync())
     t_total = time.time() - t_start
     st_t, st_d = ct.stats(), cd.stats()                 # per-call GPU time and bytes of the timed steps only
+    main_sum = summarize(results)
 
-    # on one GPU the driver (faithfully) finds the target back before the draft is ahead and launches no speculative run, so the timed
-    # steps do not exercise draft trees, verification, acceptance and cancellation at the real model sizes: one extra, untimed
-    # generation forces a speculation iteration per token (min_spec_iters, never part of `value`) and is checked for losslessness
-    forced = None
-    if args.mode == 0:
-        f_tokens, f_res = generation(0, min_spec_iters=1, adaptive_window=0, adaptive_pause=0)
-        forced = {"tokens_per_s": round(f_res["n_predict"] / f_res["t_dec_s"], 2), "spec_runs": f_res["n_runs_spec"], "canceled_runs": f_res["n_runs_canceled"],
-                  "drafted_tokens": f_res["n_drafted_tokens"], "accepted_draft_tokens": f_res["n_accept_clean"],
-                  "acceptance_rate": round(f_res["n_accept_clean"] / max(1, f_res["n_drafted_tokens"]), 4),
-                  "lossless_vs_target_only": bool(ref_tokens[:args.n_predict] == f_tokens[:args.n_predict])}
-        if not forced["lossless_vs_target_only"]:
-            forced["first_difference"] = lossless_diagnostic(ct, prompts[0], ref_tokens, f_tokens, args.n_predict)
+    # the other two schedules of the reference's comparison (plot.py:6-7) on the same prompts; never `value`
+    other = {}
+    if not args.no_other_schedules:
+        for mode, name in ((2, "target_only"), (1, "speculative_orig")):
+            if mode == args.mode:
+                continue
+            outs = [generation(1 + args.warmup + i, mode=mode) for i in range(min(args.steps, 2))]
+            s = summarize([r for _, r in outs])
+            s["lossless_vs_target_only"] = bool(generation(0, mode=mode)[0][:args.n_predict] == ref_tokens[:args.n_predict]) if mode != 2 else True
+            other[name] = s
 
-    n_tok = sum(r["n_predict"] for r in results)
-    t_dec = sum(r["t_dec_s"] for r in results)
-    value = n_tok / t_dec
-    drafted = sum(r["n_drafted_tokens"] for r in results)
-    acc_clean = sum(r["n_accept_clean"] for r in results)
-    acc_ref = 100.0 * sum(r["n_accept"] for r in results) / max(1, sum(r["n_drafted"] for r in results))
-
-    # roofline of the dominant kernel: the Q4_K single-token mat-vec (k_mmvq_kq<Q4_K, NT=1>), every 4th launch bracketed by HIP
-    # events on its own stream.  Events recorded inside a captured graph cannot be read back on ROCm 7.2, so the sampling
-    # pass replays the same decode step kernel by kernel (graphs off) right after the timed region, on the same context.
+    # roofline of the dominant kernel.  Events recorded inside a captured graph cannot be read back on ROCm 7.2, so the sampling pass
+    # replays one generation of the timed schedule kernel by kernel (graphs off) right after the timed region, on the same contexts;
+    # every 5th launch of each (type, width) instance goes through hipExtLaunchKernelGGL whose events carry the kernel's own timestamps.
     ct.set_graphs(0)
     lib.pi_kernel_timing(1, 5)          # 5 is coprime to the 3- and 4-launch periods of a layer: every launch shape gets sampled
-    generation(1 + args.warmup, mode=2, n_predict=min(32, args.n_predict))
+    generation(1 + args.warmup, n_predict=min(32, args.n_predict))
     L.check(lib.pi_device_sync())
     ct.set_graphs(1)
-    avg_us, avg_bytes, n_s, n_l = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
-    lib.pi_kernel_timing_report(12, 1, C.byref(avg_us), C.byref(avg_bytes), C.byref(n_s), C.byref(n_l))
-    achieved = (avg_bytes.value / (avg_us.value * 1e-6) / 1e9) if avg_us.value > 0 else 0.0
-    # HBM traffic of the same kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): bench.py cannot
-    # run the profiler on itself, so the number comes from profiles/ (same workload, same launches) and says so
-    traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")))
-        if args.workload == "7b":
-            traffic, traffic_src = pmc["dominant_kernel"]["avg_fetch_bytes_per_launch"], "profiles/r01_pmc_fetch_size.json"
-    except Exception:
-        pass
-    roofline = {"bound": "hbm", "kernel": "k_mmvq_kq<Q4_K,NT=1>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_us": round(avg_us.value, 3), "alg_bytes_per_launch": round(avg_bytes.value), "launches": int(n_l.value), "sampled": int(n_s.value),
-                # single-token decode calls only (prompt batches excluded): GPU time between the call's first and last event
-                "target_decode_call": {"calls": st_t["n_calls_1"], "gpu_ms_per_call": round(st_t["gpu_ms_1"] / max(1, st_t["n_calls_1"]), 4),
-                                       "alg_GB_per_call": round(st_t["alg_bytes_1"] / max(1, st_t["n_calls_1"]) / 1e9, 4),
-                                       "GBps": round(st_t["alg_bytes_1"] / max(1e-9, st_t["gpu_ms_1"] * 1e-3) / 1e9, 1)},
-                "draft_decode_call": {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
-                                      "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}}
+    table = kernel_timing_table(lib)
     lib.pi_kernel_timing(0, 8)
+    q4 = [r for r in table if r["type"] == "Q4_K"]
+    dom = max(q4 or table, key=lambda r: r["gpu_ms_total"]) if table else None
+    if dom:
+        kname = f"k_mmvq_kq<Q4_K,NT=1>" if dom["n_tok"] == 1 else f"k_mmq_kq<{dom['type']}> (matrix cores, {dom['n_tok']} tokens)"
+        traffic, traffic_src = committed_traffic(args.workload, f"{dom['type']}_nt{dom['n_tok']}")
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel_src_sha16": kernel_source_sha(),
+                    "avg_launch_us": dom["avg_us"], "alg_bytes_per_launch": dom["alg_bytes"], "launches": dom["launches"], "sampled": dom["sampled"]}
+    else:
+        roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+    roofline["per_instance"] = table
+    # whole decode calls of the timed steps (prompt batches excluded): GPU time between the call's first and last event
+    roofline["target_decode_call"] = {"calls": st_t["n_calls_1"], "gpu_ms_per_call": round(st_t["gpu_ms_1"] / max(1, st_t["n_calls_1"]), 4),
+                                      "alg_GB_per_call": round(st_t["alg_bytes_1"] / max(1, st_t["n_calls_1"]) / 1e9, 4),
+                                      "GBps": round(st_t["alg_bytes_1"] / max(1e-9, st_t["gpu_ms_1"] * 1e-3) / 1e9, 1)}
+    roofline["target_all_calls"] = {"calls": st_t["n_calls"], "gpu_ms_per_call": round(st_t["gpu_ms"] / max(1, st_t["n_calls"]), 4),
+                                    "GBps": round(st_t["alg_bytes"] / max(1e-9, st_t["gpu_ms"] * 1e-3) / 1e9, 1)}
+    roofline["draft_decode_call"] = {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
+                                     "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}
 
-    out = {"metric": "accepted tokens/sec + acceptance rate, 70B Q4_K target / 1.1B draft", "value": round(value, 2), "unit": "tokens/s",
+    sched = {0: "PipeInfer (asynchronous continuous speculation, examples/speculative)", 1: "synchronous tree speculation (examples/speculative_orig)", 2: "target only"}[args.mode]
+    out = {"metric": METRIC if args.workload == "70b" else f"accepted tokens/sec + acceptance rate, {tspec} {tft} target / {dspec} draft", "value": main_sum["tokens_per_s"], "unit": "tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_total / args.steps, 2), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "int8 x int4/6 dot, fp32 accumulate (f16 KV)", "data": "synthetic",
-           "config": {"workload": f"{tspec} {tft} target + {dspec} {dft} draft on 1xMI355X, two HIP streams (BASELINE configs[1])",
+           "config": {"workload": f"{tspec} {tft} target + {dspec} {dft} draft on 1xMI355X, two HIP streams", "schedule": sched,
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel,
-                      "p_accept": args.p_accept, "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}",
-                      "adaptive_draft": {"window": args.adaptive_window, "pause": args.adaptive_pause}},
-           "acceptance": {"accepted_draft_tokens": acc_clean, "drafted_tokens": drafted, "rate": round(acc_clean / max(1, drafted), 4),
-                          "reference_formula_pct": round(acc_ref, 2), "spec_runs": sum(r["n_runs_spec"] for r in results),
-                          "canceled_runs": sum(r["n_runs_canceled"] for r in results),
-                          "draft_paused_tokens": sum(r["n_draft_paused"] for r in results), "draft_catchups": sum(r["n_draft_catchups"] for r in results)},
-           "lossless_vs_target_only": bool(lossless), "first_difference": first_diff, "forced_speculation_check": forced, "ttft_s": round(float(np.mean([r["ttft_s"] for r in results])), 5),
+                      "p_accept": args.p_accept, "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy",
+                      "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}, draft wrong on {args.draft_miss:.0%} of the vocabulary",
+                      "driver_additions": {"adaptive_window": args.adaptive_window, "adaptive_pause": args.adaptive_pause, "min_spec_iters": args.min_spec_iters, "max_inflight": args.max_inflight}},
+           "acceptance": {k: v for k, v in main_sum.items() if k != "tokens_per_s"},
+           "lossless_vs_target_only": bool(lossless), "first_difference": first_diff, "other_schedules": other,
+           "ttft_s": round(float(np.mean([r["ttft_s"] for r in results])), 5),
            "itl_s": round(float(np.mean([r["itl_s"] for r in results])), 6), "encode_tps": round(float(np.mean([r["encode_tps"] for r in results])), 1),
            "roofline": roofline}
     if not args.no_cpu_baseline:
         for c in (ct, cd):
             c.free()
         try:
-            out["cpu_baseline"] = cpu_baseline(tgt_path, args.cpu_tokens, 16)
+            out["cpu_baseline"] = cpu_baseline(tspec, tft, tgt_path, args.cache, args.signal, args.noise, args.cpu_tokens)
         except Exception as e:  # the GPU result stands on its own; say why the CPU leg is missing
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": repr(e)}
     print(json.dumps(out))

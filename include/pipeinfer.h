@@ -25,6 +25,11 @@ LLAMA_API int  pipeinfer_context_set_priority(struct llama_context * ctx, int pr
 /* restricts the context's stream to compute units [cu_lo, cu_hi) of the 256 (hipExtStreamCreateWithCUMask); before the first decode.
  * Draft and target contexts on one GPU get disjoint slices so that their kernels overlap instead of alternating. */
 LLAMA_API int  pipeinfer_context_set_cu_range(struct llama_context * ctx, int cu_lo, int cu_hi);
+/* before the first decode: capture this context's stage as segments of `layers_per_segment` layers (0 = one graph for the whole stage, the
+ * default) and launch them from a feeder thread, at most two ahead of the GPU.  A run cancelled by llama_cancel_run while it is in flight
+ * then stops at the next segment boundary (the reference aborts between graph nodes, llama.cpp:5665-5687), and contexts with a higher
+ * stream priority (pipeinfer_context_set_priority) on the same GPU are served between segments instead of after the whole run. */
+LLAMA_API int  pipeinfer_context_set_segments(struct llama_context * ctx, int layers_per_segment);
 /* 0: launch the decode kernels one by one instead of replaying the captured HIP graph (profiling / per-kernel event timing) */
 LLAMA_API void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable);
 LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
@@ -67,6 +72,7 @@ struct pipeinfer_stats {
     uint64_t n_calls_1;          /* the same three counters restricted to single-token calls (prompt batches excluded) */
     double   gpu_ms_1;
     uint64_t alg_bytes_1;
+    uint64_t n_segments, n_segments_skipped;   /* segmented launch: segments launched / dropped by a mid-run cancel */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
 LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);

@@ -8,6 +8,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -15,6 +16,11 @@
 #define OP_OK(expr)  do { if ((expr) != 0) { ctx->last_error = std::string(#expr) + ": " + pi_last_error(); return false; } } while (0)
 
 llama_context::~llama_context() {
+    if (feeder.joinable()) {
+        { std::lock_guard<std::mutex> lk(fmu); fstop = true; }
+        fcv.notify_all();
+        feeder.join();
+    }
     if (stream) (void) hipStreamSynchronize(stream);
     for (pi_run * r : inflight) pool.push_back(r);
     for (pi_run * r : pool) {
@@ -25,6 +31,7 @@ llama_context::~llama_context() {
         delete r;
     }
     for (auto & kv : graphs) if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
+    for (hipEvent_t e : seg_events) if (e) (void) hipEventDestroy(e);
     void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, q8c, tokens_dev, pos_dev, dyn_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev, topk_scratch_dev };
     for (void * b : bufs) pi_free(b);
     if (rope) pi_rope_table_free(rope);
@@ -47,8 +54,15 @@ size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv) {
     return b;
 }
 
+static bool context_prepare_impl(llama_context * ctx, std::string & err);
 bool context_prepare(llama_context * ctx, std::string & err) {
-    if (ctx->x || ctx->remote) return true;                                  // the head of a remote pipeline owns no device state
+    if (ctx->prepared || ctx->remote) return true;                           // the head of a remote pipeline owns no device state
+    if (ctx->prepare_failed) { err = "an earlier attempt to allocate this context's device state failed: " + ctx->last_error; return false; }
+    if (!context_prepare_impl(ctx, err)) { ctx->prepare_failed = true; ctx->last_error = err; return false; }      // (a half-built context must never launch kernels)
+    ctx->prepared = true;
+    return true;
+}
+static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     llama_model * m = ctx->model;
     const pi_hparams & hp = m->hparams;
     if (pi_device_init(m->device) != 0) { err = pi_last_error(); return false; }
@@ -87,7 +101,7 @@ bool context_prepare(llama_context * ctx, std::string & err) {
         !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev(64)))
         return false;
     ctx->use_graphs = getenv("PI_NO_GRAPHS") == nullptr;
-    if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0) { err = pi_last_error(); return false; }
+    if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0 || pi_op_mul_mat_reserve() != 0) { err = pi_last_error(); return false; }
     ctx->mask_cap_words = (size_t) nb * ((ctx->n_ctx + 31) / 32);
     if (!(ctx->mask_dev = (uint32_t *) dev(ctx->mask_cap_words * 4))) return false;
     if (ctx->is_last) {
@@ -165,15 +179,16 @@ static bool mul_mat_grouped(int n, const pi_weight * const * ws, const void * co
     return true;
 }
 
-static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
+// layers [la, lb) of this stage; `head`: the embedding lookup goes first, `tail`: final norm + lm_head + top-k go last
+static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int la, int lb, bool head, bool tail) {
     llama_model * m = ctx->model;
     const pi_hparams & hp = m->hparams;
     const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, hd = hp.head_dim();
     hipStream_t s = ctx->stream;
     float * x = ctx->x, * x2 = ctx->x2;
-    if (ctx->is_first) OP_OK(pi_op_get_rows(m->tok_embd, ctx->tokens_dev, n_tok, x, s));
+    if (head && ctx->is_first) OP_OK(pi_op_get_rows(m->tok_embd, ctx->tokens_dev, n_tok, x, s));
     const size_t kv_layer = (size_t) ctx->n_ctx * n_gqa;
-    for (int il = ctx->l0; il < ctx->l1; il++) {
+    for (int il = la; il < lb; il++) {
         const pi_layer & L = m->layers[il];
         uint16_t * kc = ctx->k_cache + (size_t) (il - ctx->l0) * kv_layer, * vc = ctx->v_cache + (size_t) (il - ctx->l0) * kv_layer;
         if (hp.arch == PI_ARCH_LLAMA) {
@@ -235,7 +250,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
             trace(ctx, "lout", il, x, n_embd, n_tok);
         }
     }
-    if (ctx->is_last) {
+    if (tail && ctx->is_last) {
         const int vo = vdt_of(m->output);
         if (hp.arch == PI_ARCH_LLAMA) { if (!norm_for(ctx, x, m->output_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vo, ctx->q8a)) return false; }
         else                          { if (!norm_for(ctx, x, m->output_norm, m->output_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vo, ctx->q8a)) return false; }
@@ -245,30 +260,43 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv) {
     return true;
 }
 
-// metadata block -> device, then the stage's forward pass: replay of the captured graph for this batch width, or eager launches.
-// x_in (device, [n_tokens][n_embd]) replaces the embedding lookup on stages after the first.
-static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta, const float * x_in, pi_kt_sink ** sink_out) {
+// ---- launching a run: metadata block -> device, then the stage's forward pass as `n_segments` graph replays (or eager launches) ------------
+static int n_segments(const llama_context * ctx) {
+    const int nl = ctx->l1 - ctx->l0;
+    return ctx->seg_layers > 0 && nl > 0 ? (nl + ctx->seg_layers - 1) / ctx->seg_layers : 1;
+}
+// x_in (device, [n_tokens][n_embd]) replaces the embedding lookup on stages after the first
+static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, const float * x_in) {
     const int words = (ctx->n_ctx + 31) / 32;
     const int32_t * h_tok = (const int32_t *) meta, * h_pos = h_tok + n_tokens, * h_dyn = h_pos + n_tokens; const uint32_t * h_mask = (const uint32_t *) (h_dyn + 4);
-    const int kv_head = h_dyn[0];
     hipStream_t s = ctx->stream;
     bool ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
     if (ok && x_in) ok = hipMemcpyAsync(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDeviceToDevice, s) == hipSuccess;
-    if (!ok) { ctx->last_error = "H2D of batch metadata failed"; return false; }
-    if (ctx->use_graphs && !getenv("PI_TRACE")) {
-        // one HIP graph per batch width: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device
-        // memory that the copies above refresh, so replaying the graph IS this call's forward pass
-        llama_context::graph_entry & ge = ctx->graphs[n_tokens];
+    if (!ok) ctx->last_error = "H2D of batch metadata failed";
+    return ok;
+}
+// segment `seg` of the forward pass: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device memory that
+// launch_inputs refreshed, so replaying the captured graph IS this call's segment
+static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out) {
+    static const bool tracing = getenv("PI_TRACE") != nullptr;
+    const int nseg = n_segments(ctx);
+    const int la = ctx->seg_layers > 0 ? ctx->l0 + seg * ctx->seg_layers : ctx->l0;
+    const int lb = ctx->seg_layers > 0 ? std::min(ctx->l1, la + ctx->seg_layers) : ctx->l1;
+    const bool head = seg == 0, tail = seg == nseg - 1;
+    hipStream_t s = ctx->stream;
+    if (ctx->use_graphs && !tracing) {
+        llama_context::graph_entry & ge = ctx->graphs[std::make_pair(n_tokens, seg)];
+        bool ok = true;
         if (!ge.exec) {
             hipGraph_t graph = nullptr;
             ge.sink.every = 16;
             ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
-                pi_kt_set_sink(&ge.sink);                          // sample points are part of the graph; they are only read while timing is on
-                const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx);
+                pi_kt_set_sink(&ge.sink);                          // launch counts are part of the graph; they are only read while timing is on
+                const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
                 pi_kt_set_sink(nullptr);
                 ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
             }
@@ -277,10 +305,80 @@ static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta,
             if (!ok) { ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error; ge.exec = nullptr; }
         }
         if (ok) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
-        if (ok && sink_out) *sink_out = &ge.sink;
+        if (ok && sink_out && seg == 0) *sink_out = &ge.sink;
         return ok;
     }
-    return forward(ctx, n_tokens, kv_head, ctx->n_ctx);
+    return forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+}
+static bool launch_outputs(llama_context * ctx, pi_run * run) {
+    if (!ctx->is_last) return true;
+    hipStream_t s = ctx->stream;
+    const size_t nv = ctx->model->hparams.n_vocab; const int n_tokens = run->n_tokens;
+    const bool ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(run->topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(run->topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(run->topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (!ok) ctx->last_error = "D2H of logits failed";
+    return ok;
+}
+static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta, const float * x_in, pi_kt_sink ** sink_out) {
+    if (!launch_inputs(ctx, n_tokens, meta, x_in)) return false;
+    const int kv_head = ((const int32_t *) meta)[2 * n_tokens];
+    for (int seg = 0, n = n_segments(ctx); seg < n; seg++) if (!launch_segment(ctx, n_tokens, kv_head, seg, sink_out)) return false;
+    return true;
+}
+
+// ---- device arbiter: contexts with a positive stream priority (the draft of a single-GPU run) go first ---------------------------------------
+// A feeder only hands the GPU its next segment while no such context has a run pending and none finished one in the last `grace` microseconds
+// (the driver issues draft steps back to back: a target segment slipped into the gap would delay every one of them).
+static std::atomic<int> g_urgent{0};
+static std::atomic<int64_t> g_urgent_until{0};
+static int64_t urgent_grace_us() { static const int64_t v = getenv("PI_YIELD_GRACE_US") ? atoll(getenv("PI_YIELD_GRACE_US")) : 150; return v; }
+static void urgent_begin(llama_context * ctx) { if (ctx->stream_priority > 0) g_urgent.fetch_add(1); }
+static void urgent_end(llama_context * ctx) { if (ctx->stream_priority > 0) { g_urgent_until.store(time_us() + urgent_grace_us()); g_urgent.fetch_sub(1); } }
+static void yield_to_urgent(const llama_context * ctx) {
+    if (ctx->stream_priority > 0) return;
+    while (g_urgent.load() > 0 || time_us() < g_urgent_until.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+}
+
+// ---- feeder thread of a segmented context ---------------------------------------------------------------------------------------------------
+static void feed_run(llama_context * ctx, pi_run * run) {
+    run->state.store(1);
+    bool ok = hipEventRecord(run->begin, ctx->stream) == hipSuccess, full = false;
+    hipEvent_t seg_done[2] = { ctx->seg_events[0], ctx->seg_events[1] };
+    if (!run->canceled && !run->cancel_req.load()) {
+        const int nseg = n_segments(ctx), kv_head = ((const int32_t *) run->meta_host)[2 * run->n_tokens];
+        ok = launch_inputs(ctx, run->n_tokens, run->meta_host, nullptr);
+        int seg = 0;
+        for (; ok && seg < nseg; seg++) {
+            if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
+            yield_to_urgent(ctx);
+            if (run->cancel_req.load()) break;                                  // llama_cancel_run arrived while the run was in flight
+            ok = launch_segment(ctx, run->n_tokens, kv_head, seg, &run->sink);
+            if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
+        }
+        run->segments_run = seg;
+        ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
+        full = ok && seg == nseg;
+        if (full) ok = launch_outputs(ctx, run);
+    }
+    run->launched = ok && full;
+    if (hipEventRecord(run->done, ctx->stream) != hipSuccess) ok = false;
+    if (!ok) fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.c_str());
+    run->state.store(2);
+}
+static void feeder_main(llama_context * ctx) {
+    (void) hipSetDevice(ctx->model->device);
+    while (true) {
+        pi_run * run = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(ctx->fmu);
+            ctx->fcv.wait(lk, [&] { return ctx->fstop || !ctx->fqueue.empty(); });
+            if (ctx->fqueue.empty()) return;                                   // fstop and drained
+            run = ctx->fqueue.front(); ctx->fqueue.pop_front();
+        }
+        feed_run(ctx, run);
+    }
 }
 
 pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & rc) {
@@ -311,7 +409,8 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     pi_run * run = acquire_run(ctx, n_tokens, meta_bytes);
     if (!run) { ctx->last_error = "out of pinned host memory"; return nullptr; }
     run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us(); run->sink = nullptr;
-    if (!ctx->remote && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
+    // (a segmented context's stream belongs to its feeder thread: the begin event is recorded there, in stream order with the run's segments)
+    if (!ctx->remote && ctx->seg_layers == 0 && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
     // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
     run->want_logits.assign(n_tokens, 1);
     run->last_only = false;
@@ -339,24 +438,44 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         rc = 0;
         return run;
     }
-    if (!run->canceled) {                                                     // a cancelled run still occupies its cells and completes "empty" (llama.cpp:5627-5716)
-        hipStream_t s = ctx->stream;
-        ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
-        if (ok && ctx->is_last) {
-            const size_t nv = ctx->model->hparams.n_vocab;
-            ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                 hipMemcpyAsync(run->topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                 hipMemcpyAsync(run->topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                 hipMemcpyAsync(run->topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
-            if (!ok) ctx->last_error = "D2H of logits failed";
+    run->state.store(0); run->cancel_req.store(false); run->segments_run = 0;
+    urgent_begin(ctx);
+    if (ctx->seg_layers > 0) {                                                // segmented: the feeder thread launches (and may cut short) the run
+        if (!ctx->feeder.joinable()) {
+            if (hipEventCreateWithFlags(&ctx->seg_events[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->seg_events[1], hipEventDisableTiming) != hipSuccess) {
+                ctx->last_error = "hipEventCreate failed"; urgent_end(ctx); ctx->pool.push_back(run); return nullptr;
+            }
+            ctx->feeder = std::thread(feeder_main, ctx);
         }
+        if (!run->canceled) {
+            ctx->stat_calls++;
+            ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, n_kv);
+            if (n_tokens == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
+        }
+        ctx->inflight.push_back(run);
+        { std::lock_guard<std::mutex> lk(ctx->fmu); ctx->fqueue.push_back(run); }
+        ctx->fcv.notify_one();
+        rc = 0;
+        return run;
+    }
+    if (!run->canceled) {                                                     // a cancelled run still occupies its cells and completes "empty" (llama.cpp:5627-5716)
+        ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
+        if (ok) ok = launch_outputs(ctx, run);
         run->launched = ok;
         ctx->stat_calls++;
         ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, n_kv);
         if (n_tokens == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
     }
     if (ok) ok = hipEventRecord(run->done, ctx->stream) == hipSuccess;
-    if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); ctx->pool.push_back(run); return nullptr; }
+    run->state.store(2);
+    if (!ok) {
+        // the cells find_slot handed to this run go back: nothing was (or will be) written to them
+        fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str());
+        for (int i = 0; i < n_tokens; i++) ctx->cells->seq_rm(-1, pos[i], pos[i] + 1);
+        urgent_end(ctx);
+        ctx->pool.push_back(run);
+        return nullptr;
+    }
     ctx->inflight.push_back(run);
     rc = 0;
     return run;
@@ -367,11 +486,13 @@ bool context_poll_oldest(llama_context * ctx) {
     if (ctx->remote) return !ctx->inflight.front()->launched || ctx->remote_ops.poll(ctx->remote_ops.user) != 0;
     static const int64_t dbg_delay_us = getenv("PI_DEBUG_RUN_LATENCY_US") ? atoll(getenv("PI_DEBUG_RUN_LATENCY_US")) : 0;   // tests: pretend every run takes at least this long
     if (dbg_delay_us > 0 && time_us() - ctx->inflight.front()->t_start_us < dbg_delay_us) return false;
+    if (ctx->inflight.front()->state.load() != 2) return false;                // the feeder has not recorded its completion event yet
     return hipEventQuery(ctx->inflight.front()->done) == hipSuccess;
 }
 
 bool context_wait(llama_context * ctx, pi_run * run) {
     if (ctx->remote) return true;                                             // context_finish blocks in the transport's wait()
+    while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
     return hipEventSynchronize(run->done) == hipSuccess;
 }
 
@@ -417,7 +538,11 @@ int context_finish(llama_context * ctx, pi_run * run) {
             if (rc < 0) { ctx->last_error = "remote wait failed"; return -1; }
             run->launched = rc == 1;                                          // 0: a stage skipped the run after a cancel
         }
-    } else if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; return -1; }
+    } else {
+        while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; urgent_end(ctx); return -1; }
+        urgent_end(ctx);
+    }
     const size_t nv = ctx->model->hparams.n_vocab;
     const int n = run->n_tokens;
     if (ctx->is_last) {

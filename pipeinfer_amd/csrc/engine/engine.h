@@ -6,10 +6,14 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <deque>
 #include <map>
 #include <memory>
+#include <random>
 #include <set>
 #include <string>
 #include <vector>
@@ -72,6 +76,10 @@ struct pi_run {                                // one llama_start_async_decode .
     pi_kt_sink * sink = nullptr;            // kernel-timing samples of the graph this run replayed
     int32_t run_seq = 0;                    // remote contexts: sequence number of the run on the wire
     bool host_plain = false;                // buffers come from malloc (remote contexts never touch the GPU)
+    // feeder contexts (segmented launch): the caller thread only places the run in the queue; the feeder thread enqueues its segments
+    std::atomic<int>  state{0};             // 0 queued, 1 being launched, 2 completion event recorded (the run's fields are final)
+    std::atomic<bool> cancel_req{false};    // llama_cancel_run after the start: the feeder stops launching its segments
+    int segments_run = 0;                   // segments that were launched before a cancel took effect (statistics)
 };
 
 struct llama_context {
@@ -98,8 +106,19 @@ struct llama_context {
     void * q8a = nullptr, * q8b = nullptr, * q8c = nullptr;
     int32_t * tokens_dev = nullptr, * pos_dev = nullptr, * dyn_dev = nullptr; uint32_t * mask_dev = nullptr;
     struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; };
-    std::map<int, graph_entry> graphs;       // one captured forward pass per n_tokens (kv_head / n_kv come from dyn_dev)
+    std::map<std::pair<int, int>, graph_entry> graphs;   // one captured graph per (n_tokens, segment) (kv_head / n_kv come from dyn_dev)
     bool use_graphs = true;
+    // Segmented launch (pipeinfer_context_set_segments): the stage's layers are captured as segments of `seg_layers` layers and a feeder
+    // thread enqueues them one or two ahead of the GPU.  Between segments it (a) drops the rest of a run that has been cancelled meanwhile
+    // — the reference polls its abort callback between graph nodes (llama.cpp:5665-5687, ggml.c:15748-15811) — and (b) lets contexts of
+    // higher stream priority go first: on ONE GPU a kernel of another queue is only dispatched between this queue's kernels once its
+    // workgroups have all been placed, so a draft step behind a queued 70B run takes as long as that run; with at most two segments
+    // queued it waits for two segments.
+    int seg_layers = 0;                      // 0: the whole stage is one graph, launched by the caller (no feeder)
+    std::thread feeder; std::mutex fmu; std::condition_variable fcv; std::deque<pi_run *> fqueue; bool fstop = false;
+    uint64_t stat_segments = 0, stat_segments_skipped = 0;
+    hipEvent_t seg_events[2] = { nullptr, nullptr };
+    bool prepared = false, prepare_failed = false;      // device state fully allocated / an attempt failed half-way (never retried)
     int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr; void * topk_scratch_dev = nullptr;
     size_t mask_cap_words = 0;
 
@@ -116,6 +135,7 @@ struct llama_context {
     uint64_t stat_calls = 0; double stat_gpu_ms = 0.0; uint64_t stat_alg_bytes = 0;
     uint64_t stat_calls_1 = 0; double stat_gpu_ms_1 = 0.0; uint64_t stat_alg_bytes_1 = 0;      // single-token calls only (the decode rate)
 
+    std::mt19937 rng;                          // llama_set_rng_seed / llama_sample_token (llama.cpp:1488)
     std::string last_error;
     ~llama_context();
 };

@@ -51,13 +51,16 @@ extern "C" void llama_set_n_threads(struct llama_context *, uint32_t, uint32_t) 
 
 // ---- PipeInfer pipeline control -------------------------------------------------------------------------------------------
 // One process drives every stage of its pipeline, so the calling thread is always the root of whichever communicator is
-// current; the only driver-visible state is llama_node_id (-1 after llama_split_comm(ctx, <0), llama.cpp:8915-8927).
+// current; the only driver-visible state is llama_node_id (llama.cpp:8915-8927).
 extern "C" int llama_node_id(struct llama_context * ctx) { return ctx->node_id; }
-extern "C" void llama_split_comm(struct llama_context * ctx, int color) { ctx->comm_color = color; ctx->node_id = color < 0 ? -1 : 0; }
+// One process plays every MPI rank of the reference: it is the head of the target pipeline AND the root of the draft pipeline, so it stays
+// a member (node 0) of whatever communicator the driver splits off — examples/speculative/speculative.cpp:118-132 hands rank 0 a negative
+// colour for the draft's model communicator because there another rank computes the draft; here this process does.
+extern "C" void llama_split_comm(struct llama_context * ctx, int color) { ctx->comm_color = color; ctx->node_id = 0; }
 extern "C" void llama_swap_comm(struct llama_context * ctx) {
     std::swap(ctx->comm_color, ctx->comm_color_alt);
     ctx->comm_swapped = !ctx->comm_swapped;
-    ctx->node_id = ctx->comm_color < 0 ? -1 : 0;
+    ctx->node_id = 0;
 }
 extern "C" void llama_sync_token(struct llama_context *, llama_token *, int) {}                   // MPI_Bcast among roots (llama.cpp:8901-8906): one process
 extern "C" void llama_sync_token_data(struct llama_context *, llama_token_data *, int) {}
@@ -72,6 +75,7 @@ extern "C" bool llama_mpi_iprobe(struct llama_context * ctx) { return pi::contex
 extern "C" void llama_cancel_run(struct llama_context * ctx, int32_t * canceled, int count) {
     for (int i = 0; i < count; i++) {
         ctx->canceled_batches.insert(canceled[i]);                                                     // llama.cpp:9981-9993
+        for (pi_run * r : ctx->inflight) if (r->batch_id == canceled[i]) r->cancel_req.store(true);      // already started: stops at its next segment boundary (segmented contexts)
         if (ctx->remote && ctx->remote_ops.cancel) ctx->remote_ops.cancel(ctx->remote_ops.user, canceled[i]);
     }
 }
@@ -240,6 +244,13 @@ extern "C" int pipeinfer_context_set_cu_range(struct llama_context * ctx, int cu
     return 0;
 }
 
+extern "C" int pipeinfer_context_set_segments(struct llama_context * ctx, int layers_per_segment) {
+    if (ctx->prepared || ctx->feeder.joinable()) { ctx->last_error = "pipeinfer_context_set_segments: the context has already decoded"; return -1; }
+    if (ctx->remote) { ctx->last_error = "pipeinfer_context_set_segments: a remote head owns no layers"; return -1; }
+    ctx->seg_layers = layers_per_segment > 0 ? layers_per_segment : 0;
+    return 0;
+}
+
 extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }
 
 extern "C" void pipeinfer_context_set_remote(struct llama_context * ctx, const struct pipeinfer_remote_ops * ops) {
@@ -292,8 +303,9 @@ extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer
     out->n_calls_1 = ctx->stat_calls_1; out->gpu_ms_1 = ctx->stat_gpu_ms_1; out->alg_bytes_1 = ctx->stat_alg_bytes_1;
     out->weight_bytes = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, 1);
     out->kv_bytes_per_cell = (uint64_t) 4 * ctx->model->hparams.n_embd_gqa() * (uint64_t) (ctx->l1 - ctx->l0);
+    out->n_segments = ctx->stat_segments; out->n_segments_skipped = ctx->stat_segments_skipped;
 }
-extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; }
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; }
 
 // ---- stand-alone KV-cell table (host logic tests) ---------------------------------------------------------------------------------
 struct pi_kvcells { pi::kv_cells cells; explicit pi_kvcells(int n) : cells(n) {} };

@@ -20,14 +20,17 @@
 // r on lane (r, g) with tokens 4g..4g+3 in its four registers: the block scalars of the row (d, dmin, 6-bit scales, mins) are then in the
 // lane that loaded the row's block header, and the chains run straight from the MFMA result registers.
 // A workgroup is R row groups of 16 rows x S waves; wave s of a row group owns accumulator lanes k in [s*8/S, (s+1)*8/S) and mins lanes
-// c in [s*4/S, (s+1)*4/S) for ALL blocks of the row (the p-half weight order makes a wave's share of a block contiguous), so waves never
-// exchange anything until the final fold — no per-block barrier — and a row group streams S waves deep.  What IS shared is the
+// c in [s*4/S, (s+1)*4/S) for ALL blocks of the row, so waves never exchange anything until the final fold — no per-block barrier —
+// and a row group streams S waves deep.  Weights come from a TILE-MAJOR copy (16 rows x one block = 2304 contiguous bytes, runtime.hip:
+// k_repack_mq_q4_K): reading 16 rows x one block per step from the row-major planes of the decode kernel streams at 1.3-1.6 TB/s with no
+// arithmetic at all, the same bytes tile-major at ~5 TB/s (tools_dev/pattern.hip).  What IS shared is the
 // activation side: the f16 fragments, the tokens' d and block sums (written by the quantisers in exactly this image, elementwise.hip:
 // wave_emit_frags) are copied global -> LDS by DMA one tile of TB blocks ahead, once per workgroup.
 // Weights: each wave keeps a ring of 2*TB blocks in registers (its share: 8/S + 16 bytes per lane and block), refilled right after use.
 #include "mmvq_args.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 using pi_half8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -35,7 +38,9 @@ using pi_half2 = __attribute__((ext_vector_type(2))) _Float16;
 using pi_f32x4 = __attribute__((ext_vector_type(4))) float;
 
 int pi_mmq_min_nt() {
-    static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 2; return n < 2 ? 2 : n; }();
+    // measured on 70B shapes (tools_dev/perf_mmvq.py): the VALU mat-vec costs 1.35x / 1.6x / 1.8x / 3.4x a single-token launch at 2 / 3 / 4 / 8
+    // tokens, the matrix-core kernel 1.6-1.9x at any width up to 16: it takes over from 4 tokens
+    static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 4; return n < 2 ? 2 : n; }();
     return v;
 }
 bool pi_mmq_supported(int type) { return type == PI_Q4_K; }
@@ -46,7 +51,8 @@ static __device__ __forceinline__ uint32_t pk_fma(uint32_t a, uint32_t b, uint32
 static __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return h2_bits(h2_from_bits(a) * h2_from_bits(b)); }
 static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return h2_bits(h2_from_bits(a) + h2_from_bits(b)); }
 
-#define MQ_BLK_LDS 9216                         // LDS image of one block of activations: 8 fragments of 1 KB + 1 KB aux
+// LDS image of one block of activations: 8 fragments + 1 KB aux.  A fragment is 1 KB (16 tokens) or, for batches of <= 8 tokens (NT8), the 512 bytes
+// of tokens 0..7: lane (token, g) at (8 g + token) * 16
 // s_waitcnt vmcnt(n) only
 #define MQ_STR_(x) #x
 #define MQ_STR(x) MQ_STR_(x)
@@ -54,12 +60,13 @@ static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { retu
 
 template <int TYPE, int S> struct mq_w { uint4 hdr; uint4 q[4 / S]; };                  // one lane's share of one block (Q4_K)
 
-template <int TYPE, int S, int R, int TB>
+template <int TYPE, int S, int R, int TB, bool NT8>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
     static_assert(TYPE == PI_Q4_K, "types are added one by one");
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = 1 + 4 / S;       // LW: vector loads per block of weights
+    constexpr int FRAG = NT8 ? 512 : 1024, MQ_BLK_LDS = 8 * FRAG + 1024, NP = NT8 ? 5 : 9;   // NP: DMA pieces of 1 KB per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
     const int r = lane & 15, gq = lane >> 4, p = gq >> 1, h = gq & 1;                     // weight row r, K-slice gq = (p, h): sub-blocks {4p+h, 4p+2+h}; C tile: tokens 4 gq ..
@@ -70,7 +77,6 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     const mmvq_seg & sg = g.seg[si];
     const int64_t row0 = (int64_t) (rg - sg.wave0) * 16;
     const int rows = sg.M - row0 < 16 ? (int) (sg.M - row0) : 16;
-    const int64_t row = row0 + (r < rows ? r : rows - 1);
     const int nb = g.nb, nt = g.nt, ntile = (nb + TB - 1) / TB;
 
     // lane constants of the nibble-half: h = 0 takes (q & 0x000F000F) | 0x6400 = 1024 + n, scaled by s; h = 1 takes (q & 0x00F000F0) | 0x6400
@@ -90,29 +96,31 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 #pragma unroll
         for (int i = 0; i < 4; i++) accm[cc][i] = 0.0f;
 
-    // a lane's share of a block: k in [s*KS, ..) of half p.  Uniform base + 32-bit lane offset (one VGPR per load instead of a 64-bit pointer)
-    const uint8_t * const wbase = sg.p0;
-    const uint32_t lane_off = (uint32_t) ((size_t) row * nb * 144);
-    constexpr int QOFF = 16;
-    const uint32_t share_off = QOFF + 64 * p + (64 / S) * s;
+    // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = 2304 contiguous bytes = [16 headers][4 parts of 512 B]; this
+    // wave's parts are s*4/S .., lane (r, p, h) reads 16 bytes of each (both nibble-halves h read the same bytes)
+    const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * 2304;
+    const uint32_t hdr_off = 16 * r, share_off = 256 + (4 / S) * s * 512 + (r * 2 + p) * 16;
     auto load_w = [&](int b, mq_w<TYPE, S> & W) __attribute__((always_inline)) {
-        const uint32_t bo = lane_off + (uint32_t) (b < nb ? b : nb - 1) * 144u;           // unconditional, clamped (see mmvq.hip on branches between a load and its use)
-        W.hdr = *(const uint4 *) (wbase + bo);
+        const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * 2304u;                     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
+        W.hdr = *(const uint4 *) (wbase + (bo + hdr_off));
 #pragma unroll
-        for (int i = 0; i < 4 / S; i++) W.q[i] = *(const uint4 *) (wbase + (uint32_t) (bo + share_off + 16 * i));
+        for (int i = 0; i < 4 / S; i++) W.q[i] = *(const uint4 *) (wbase + (bo + share_off + 512 * i));
     };
     // activation tile T -> LDS buffer: 9 pieces of 1 KB per block, dealt round-robin to the workgroup's waves, one DMA instruction each
     // (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l).  Issued from inline asm: the compiler's wait-count pass drains
     // vmcnt before every LDS read once it sees an LDS-DMA, which would serialise the weight ring; the wave counts its DMAs itself (MQ_WAIT_VM)
     auto dma_tile = [&](int T, uint32_t buf) __attribute__((always_inline)) {
-        if (T < ntile) {
+        if (T < ntile && !(g.dbg & 2)) {
 #pragma unroll
-            for (int i = 0; i < (9 * TB + NW - 1) / NW; i++) {
+            for (int i = 0; i < (NP * TB + NW - 1) / NW; i++) {
                 const int piece = i * NW + wave;
-                if (piece < 9 * TB) {
-                    const int u = piece / 9, part = piece % 9;
+                if (piece < NP * TB) {
+                    const int u = piece / NP, part = piece % NP;
                     const int b = T * TB + u < nb ? T * TB + u : nb - 1;
-                    const uint8_t * src = (part < 8 ? g.frag + ((size_t) b * 8 + part) * 1024 : g.aux + (size_t) b * 1024) + lane * 16;
+                    const uint8_t * src;
+                    if (part == NP - 1) src = g.aux + (size_t) b * 1024 + lane * 16;
+                    else if (NT8) src = g.frag + (((size_t) b * 8 + 2 * part + (lane >> 5)) * 64 + (lane & 7) + 16 * ((lane & 31) >> 3)) * 16;   // two fragments per piece, tokens 0..7 only
+                    else src = g.frag + ((size_t) b * 8 + part) * 1024 + lane * 16;
                     const uint32_t dst = buf + u * MQ_BLK_LDS + part * 1024;
                     uint32_t keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -122,7 +130,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     };
     // workgroup barrier without the fence of __syncthreads (which waits for every outstanding load): LDS reads of this wave have returned
     // (lgkmcnt), the DMA writes it issued have landed (the caller's MQ_WAIT_VM)
-    auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto wg_barrier = [&]() __attribute__((always_inline)) { if (!(g.dbg & 6)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
         // ---- block scalars from the row's header: d, dmin, this lane's two 6-bit scales (sub-blocks 4p+h, 4p+2+h), this wave's mins ----
@@ -136,7 +144,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         const uint32_t S1 = pk_mul(pk_add(__umul24(scw & 0xff, 0x00010001u) | 0x64006400u, 0xE400E400u), h_scale);            // (s1, s1) or (s1/16, s1/16)
         const uint32_t S2 = pk_mul(pk_add(__umul24((scw >> 16) & 0xff, 0x00010001u) | 0x64006400u, 0xE400E400u), h_scale);
         const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);                         // -1024 * s'
-        const float4 dy4 = *(const float4 *) (blk + 8192 + 16 * gq);                                       // d of tokens 4 gq .. 4 gq + 3
+        const float4 dy4 = *(const float4 *) (blk + 8 * FRAG + 16 * gq);                                       // d of tokens 4 gq .. 4 gq + 3
         const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
         float d[4];
 #pragma unroll
@@ -150,12 +158,14 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             bw.y = pk_fma(((q0 >> 8) & nib_mask) | magic, S1, C1);                                         //                  bytes (i1, i3)
             bw.z = pk_fma((q1 & nib_mask) | magic, S2, C2);                                                // sub-block 4p+2+h
             bw.w = pk_fma(((q1 >> 8) & nib_mask) | magic, S2, C2);
-            const uint4 af = *(const uint4 *) (blk + (s * KS + kk) * 1024 + lane * 16);                    // tokens' fragment of accumulator lane k
+            const uint4 af = *(const uint4 *) (blk + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));   // tokens' fragment of accumulator lane k
             const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
             const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
+            if (g.dbg & 8) { acc[kk][0] += c[0] + c[1] + c[2] + c[3]; continue; }
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[kk][i] = fmaf(d[i], c[i], acc[kk][i]);                         // (float) sumi[k] of row r, token 4 gq + i
         }
+        if (g.dbg & 8) return;
         // mins: acc_m[c] = fma(-y.d * dmin, (float) (m[2c]*(bs[4c]+bs[4c+1]) + m[2c+1]*(bs[4c+2]+bs[4c+3])), acc_m[c])   (ggml-quants.c:5339-5345)
         float nd[4];
 #pragma unroll
@@ -165,43 +175,49 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             const int c = s * CS + cc;
             const uint32_t mw = ((c & 2) ? mB : mA) >> (16 * (c & 1));
             const float m0 = (float) (mw & 0xff), m1 = (float) ((mw >> 8) & 0xff);
-            const float4 f01 = *(const float4 *) (blk + 8192 + 64 + c * 128 + gq * 32), f23 = *(const float4 *) (blk + 8192 + 64 + c * 128 + gq * 32 + 16);
+            const float4 f01 = *(const float4 *) (blk + 8 * FRAG + 64 + c * 128 + gq * 32), f23 = *(const float4 *) (blk + 8 * FRAG + 64 + c * 128 + gq * 32 + 16);
             const float fa[4] = { f01.x, f01.z, f23.x, f23.z }, fb[4] = { f01.y, f01.w, f23.y, f23.w };
 #pragma unroll
             for (int i = 0; i < 4; i++) accm[cc][i] = fmaf(nd[i], fmaf(m0, fa[i], m1 * fb[i]), accm[cc][i]);   // the products are integers below 2^24: exact in any form
         }
     };
 
-    // ---- main loop: super-tiles of two tiles (LDS buffers 0 and 1); ring slot u is refilled for block b + D right after block b is consumed ----
+    // ---- main loop: NB LDS buffers in rotation, the activations of tile T + NB - 1 are requested while tile T is computed (an LDS-DMA takes
+    //      about 1.1 us from issue to landing — longer than a tile of two or three blocks computes, so one tile of look-ahead stalls every
+    //      tile); ring slot u is refilled for block b + D right after block b is consumed ----
+    constexpr int NB = 3;
+    static_assert(D == 2 * TB, "ring = two tiles");
     mq_w<TYPE, S> ring[D];
 #pragma unroll
     for (int u = 0; u < D; u++) load_w(u, ring[u]);
     const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
-    const uint32_t dbuf0 = lds0, dbuf1 = lds0 + TB * MQ_BLK_LDS;
-    const uint8_t * buf0 = lds, * buf1 = lds + TB * MQ_BLK_LDS;
-    dma_tile(0, dbuf0);
+#pragma unroll
+    for (int j = 0; j < NB - 1; j++) dma_tile(j, lds0 + j * TB * MQ_BLK_LDS);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
-    for (int T0 = 0; T0 < ntile; T0 += 2) {
-        dma_tile(T0 + 1, dbuf1);
+    // after the DMAs of tile T + NB - 1 a wave issues TB * LW refills in tile T; when tile T ends, the DMAs of tile T + 1 are older than
+    // (NB - 2) tiles of refills + this tile's refills + at least floor(9 TB / NW) DMAs of each younger tile
+    constexpr int DMA_MIN = (NP * TB) / NW, WAIT_N = (NB - 1) * TB * LW + (NB - 2) * DMA_MIN;
+    for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {                            // 2 NB tiles per trip: buffer (T % NB) and ring half (T % 2) are compile-time
 #pragma unroll
-        for (int u = 0; u < TB; u++) {
-            const int b = T0 * TB + u;
-            if (b < nb) compute(ring[u], buf0 + u * MQ_BLK_LDS);
-            load_w(b + D, ring[u]);
-        }
-        MQ_WAIT_VM(TB * LW);                                               // everything older than this tile's refills has landed: the DMA of the next tile too
-        wg_barrier();
-        if (T0 + 1 >= ntile) break;
-        dma_tile(T0 + 2, dbuf0);
+        for (int j = 0; j < 2 * NB; j++) {
+            const int T = T0 + j;
+            if (T < ntile) {
+                dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
+                const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
 #pragma unroll
-        for (int u = 0; u < TB; u++) {
-            const int b = (T0 + 1) * TB + u;
-            if (b < nb) compute(ring[TB + u], buf1 + u * MQ_BLK_LDS);
-            load_w(b + D, ring[TB + u]);
+                for (int u = 0; u < TB; u++) {
+                    const int b = T * TB + u;
+                    mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
+                    if (b < nb && !(g.dbg & 1)) compute(W, buf + u * MQ_BLK_LDS); else if (g.dbg & 1) acc[0][0] += __builtin_bit_cast(float, W.hdr.x ^ W.q[0].y);
+                    load_w(b + D, W);
+                }
+                if (!(g.dbg & 2)) {
+                    if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);      // (the last tiles request nothing new)
+                }
+                wg_barrier();
+            }
         }
-        MQ_WAIT_VM(TB * LW);
-        wg_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (no DMA may still be writing LDS when the fold reuses it)
     __syncthreads();
@@ -267,18 +283,39 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 
 #include <hip/hip_ext.h>
 
-template <int TYPE, int S, int R, int TB>
-static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    constexpr size_t tiles = (size_t) 2 * TB * MQ_BLK_LDS, fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
+template <int TYPE, int S, int R, int TB, bool NT8>
+static void mmq_go2(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr size_t tiles = (size_t) 3 * TB * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
-    static bool attr_done = false;
-    if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); attr_done = true; }
+    static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB, NT8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
     const unsigned grid = (unsigned) ((groups + R - 1) / R);
-    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
-    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
+    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
+}
+// batches of <= 8 tokens stage half the fragment bytes and take twice the blocks per tile (TB8) in the same LDS
+template <int TYPE, int S, int R, int TB16, int TB8>
+static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (g.nt <= 8) mmq_go2<TYPE, S, R, TB8, true>(g, groups, stream, ea, eb);
+    else           mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
+}
+
+static void mmq_dispatch(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    mmq_dispatch(g, groups, cfg, stream, ea, eb);
+}
+// dynamic-LDS limits of every instance, set once and outside any stream capture (a launch inside a captured graph must not change function attributes)
+extern "C" int pi_op_mul_mat_reserve(void) {
+    static bool done = false;
+    if (done) return 0;
+    mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
+    for (int cfg : { 22, 24, 25, 41, 44, 43, 42 }) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(g, 0, cfg, nullptr, nullptr, nullptr); }
+    done = true;
+    PI_CHECK_LAUNCH();
+    return 0;
 }
 
 int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (pi_op_mul_mat_reserve() != 0) return -1;
     mmvq_args & g = L.g;
     int groups = 0;
     for (int i = 0; i < MMVQ_MAX_SEG; i++) {
@@ -286,19 +323,14 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
         else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
     }
     if (type != PI_Q4_K) { pi_set_error("pi_mmq_launch: weight type %d has no MFMA kernel", type); return -1; }
+    static const int dbg_env = getenv("PI_MMQ_DBG") ? atoi(getenv("PI_MMQ_DBG")) : 0;
+    g.dbg = dbg_env;
     // (waves per row group, row groups per workgroup): more waves per group for short matrices (enough waves to fill 256 CUs), more groups
     // per workgroup for tall ones (the staged activations are shared by the workgroup).  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
     static const int cfg_env = getenv("PI_MMQ_CFG") ? atoi(getenv("PI_MMQ_CFG")) : 0;
-    int cfg = groups >= 2048 ? 24 : groups >= 1024 ? 44 : 42;
+    int cfg = groups >= 1024 ? 24 : 42;
     if (cfg_env) cfg = cfg_env;
-    switch (cfg) {
-        case 14: mmq_go<PI_Q4_K, 1, 4, 2>(g, groups, stream, ea, eb); break;
-        case 22: mmq_go<PI_Q4_K, 2, 2, 3>(g, groups, stream, ea, eb); break;
-        case 24: mmq_go<PI_Q4_K, 2, 4, 3>(g, groups, stream, ea, eb); break;
-        case 41: mmq_go<PI_Q4_K, 4, 1, 3>(g, groups, stream, ea, eb); break;
-        case 44: mmq_go<PI_Q4_K, 4, 4, 3>(g, groups, stream, ea, eb); break;
-        default: mmq_go<PI_Q4_K, 4, 2, 3>(g, groups, stream, ea, eb); break;
-    }
+    mmq_dispatch(g, groups, cfg, stream, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;
 }

@@ -825,7 +825,8 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     const int64_t nbq = vdt == PI_Q8_K ? K / 256 : w0->ng;
     // batches of PI_MMQ_MIN_NT tokens and more go to the matrix cores, 16 tokens per pass over the weights (mmq_mfma.hip); everything else
     // (single tokens, types without an MFMA kernel) takes the VALU mat-vec, 8 tokens per pass
-    const bool mfma = vdt == PI_Q8_K && n_tok >= pi_mmq_min_nt() && pi_mmq_supported(w0->type);
+    bool mfma = vdt == PI_Q8_K && n_tok >= pi_mmq_min_nt() && pi_mmq_supported(w0->type);
+    for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
     if (mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
     const int step = mfma ? 16 : 8;
@@ -841,7 +842,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         for (int i = 0; i < n_w; i++) {
             const pi_weight * w = ws[i];
             mmvq_seg & sg = L.g.seg[i];
-            sg.p0 = w->p0; sg.p1 = w->p1; sg.p2 = w->p2; sg.M = (int) w->ne1; sg.wave0 = 0;
+            sg.p0 = w->p0; sg.p1 = w->p1; sg.p2 = w->p2; sg.mq = w->mq; sg.M = (int) w->ne1; sg.wave0 = 0;
             sg.store = rope ? rope->store[i] : 0; sg.dst16 = rope ? rope->dst16[i] : nullptr; sg.stride16 = rope ? rope->stride16[i] : 0;
             sg.out = outs && outs[i] ? outs[i] + (int64_t) t0 * w->ne1 : nullptr;
             sg.res = ress && ress[i] ? ress[i] + (int64_t) t0 * w->ne1 : nullptr;

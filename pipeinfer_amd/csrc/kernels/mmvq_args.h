@@ -7,6 +7,7 @@
 #define MMVQ_MAX_SEG 3
 struct mmvq_seg {
     const uint8_t * p0, * p1, * p2;
+    const uint8_t * mq;         // tile-major copy (MFMA kernel), may be null
     float *         out;        // [n_tok][M]
     const float *   res;        // nullable
     int             M;
@@ -30,6 +31,7 @@ struct mmvq_args {
     int kv_head, hd, tok0;
     // multi-token MFMA kernel (mmq_mfma.hip): operand planes of this launch's chunk of <= 16 tokens (pi_q8_frag_layout), tokens in the chunk
     const uint8_t * frag; const uint8_t * aux; int nt;
+    int dbg;                    // tuning only (PI_MMQ_DBG): 1 = skip the arithmetic, 2 = skip the activation staging and its barriers (results are then garbage)
 };
 
 

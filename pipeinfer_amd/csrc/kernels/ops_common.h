@@ -25,6 +25,11 @@ struct pi_weight {
     void *   base;         // allocation
     size_t   nbytes;       // == ggml_nbytes of the tensor (padding of Q4_0/Q8_0 tails not counted)
     const uint8_t * p0, * p1, * p2, * p3;
+    // second, TILE-MAJOR copy for the multi-token MFMA kernel (mmq_mfma.hip), null when the type has none or copies are off (PI_MMQ_COPIES=0):
+    // that kernel reads 16 rows x one block per step, which streams at 1.3-1.6 TB/s from the row-major planes above and at ~5 TB/s when the
+    // 16 blocks are contiguous (tools_dev/pattern.hip).  [row group of 16][block][2304 B]; same bytes, re-ordered (layout in runtime.hip)
+    const uint8_t * mq;
+    void *   mq_base;
 };
 
 void pi_set_error(const char * fmt, ...);

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -116,6 +117,27 @@ __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restr
     // (row, p, h) reads the 64 contiguous bytes of half p and takes nibble-half h of every dword (mmq_mfma.hip)
     for (int k = 0; k < 8; k++) for (int m = 0; m < 4; m++) dq[(m >> 1) * 16 + k * 2 + (m & 1)] = sq[m * 8 + k];
 }
+// Q4_K, tile-major copy for the MFMA kernel: tile (row group g, block b) = 16 row headers of 16 B, then four parts of 512 B; part t holds,
+// for row r and half p, the dwords (k = 2t, m = 2p), (2t, 2p+1), (2t+1, 2p), (2t+1, 2p+1) of the block (dword (k, m) = bytes 4k..4k+3 of the
+// m-th 32-byte qs group) — the 16 bytes lane (r, p, h) of wave-part t loads.  Rows past the end of the matrix are zero (d = 0: they add nothing).
+__global__ void k_repack_mq_q4_K(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t rows, int64_t nb) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;                  // (row group, block, row in group)
+    const int64_t n_rg = (rows + 15) / 16;
+    if (i >= n_rg * nb * 16) return;
+    const int r = (int) (i & 15); const int64_t gb = i >> 4, g = gb / nb, b = gb % nb, row = g * 16 + r;
+    uint8_t * tile = dst + gb * 2304;
+    uint32_t * hd = (uint32_t *) (tile + 16 * r);
+    if (row >= rows) {
+        for (int j = 0; j < 4; j++) hd[j] = 0;
+        for (int t = 0; t < 4; t++) for (int p = 0; p < 2; p++) for (int j = 0; j < 4; j++) ((uint32_t *) (tile + 256 + t * 512 + (r * 2 + p) * 16))[j] = 0;
+        return;
+    }
+    const uint32_t * s = (const uint32_t *) (src + (row * nb + b) * 144);
+    for (int j = 0; j < 4; j++) hd[j] = s[j];
+    const uint32_t * sq = s + 4;
+    for (int k = 0; k < 8; k++) for (int m = 0; m < 4; m++)
+        ((uint32_t *) (tile + 256 + (k >> 1) * 512 + (r * 2 + (m >> 1)) * 16))[(k & 1) * 2 + (m & 1)] = sq[m * 8 + k];
+}
 __global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint16_t * d, int64_t nblocks) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks) return;
@@ -194,7 +216,7 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
                        : type == PI_Q3_K ? (size_t) nblocks * (96 + 16 + 2) + 512 : w->nbytes + 512;        // (Q2_K: 64 + 16 + 4 = its 84 bytes)
     if (hipMalloc(&w->base, alloc) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", alloc); delete w; return nullptr; }
     uint8_t * base = (uint8_t *) w->base;
-    w->p0 = base; w->p1 = w->p2 = w->p3 = nullptr;
+    w->p0 = base; w->p1 = w->p2 = w->p3 = nullptr; w->mq = nullptr; w->mq_base = nullptr;
     auto fail = [&](const char * what) { pi_set_error("pi_weight_upload: %s", what); (void) hipFree(w->base); delete w; return (pi_weight *) nullptr; };
     if (type == PI_F32 || type == PI_F16) {
         if (hipMemcpyAsync(base, host, w->nbytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return fail("H2D copy failed");
@@ -223,13 +245,21 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
         if (type == PI_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
         else                 hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
     }
+    w->mq = nullptr; w->mq_base = nullptr;
+    static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
+    if (mq_on && type == PI_Q4_K) {
+        const int64_t n_rg = (ne1 + 15) / 16;
+        if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * 2304 + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
+        w->mq = (const uint8_t *) w->mq_base;
+        hipLaunchKernelGGL(k_repack_mq_q4_K, dim3((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads)), dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
+    }
     const hipError_t e = hipStreamSynchronize(stream);
     (void) hipFree(staging);
-    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    if (e != hipSuccess) { if (w->mq_base) (void) hipFree(w->mq_base); return fail(hipGetErrorString(e)); }
     return w;
 }
 
-extern "C" void pi_weight_free(pi_weight * w) { if (w) { (void) hipFree(w->base); delete w; } }
+extern "C" void pi_weight_free(pi_weight * w) { if (w) { (void) hipFree(w->base); if (w->mq_base) (void) hipFree(w->mq_base); delete w; } }
 extern "C" size_t pi_weight_nbytes(const pi_weight * w) { return w->nbytes; }
 extern "C" int pi_weight_type(const pi_weight * w) { return w->type; }
 

@@ -35,7 +35,7 @@ def _stale():
 
 
 def declared_symbols():
-    """every PI_API / LLAMA_API function name declared in include/*.h"""
+    """every PI_API / LLAMA_API / GGML_API function name declared in include/*.h"""
     names = []
     inc = os.path.join(ROOT, "include")
     for f in sorted(os.listdir(inc)):
@@ -44,7 +44,8 @@ def declared_symbols():
             text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
             text = re.sub(r"//[^\n]*", "", text)
             text = re.sub(r"#define[^\n]*", "", text)
-            names += re.findall(r"(?:PI_API|LLAMA_API)\s+[^;{]*?\b(\w+)\s*\(", text)
+            text = text.replace("DEPRECATED(", "")
+            names += re.findall(r"(?:PI_API|LLAMA_API|GGML_API)\s+[^;{]*?\b(\w+)\s*\(", text)
     return sorted(set(names))
 
 

@@ -48,7 +48,7 @@ class pipeinfer_spec_result(C.Structure):
 
 class pipeinfer_stats(C.Structure):
     _fields_ = [("n_calls", C.c_uint64), ("gpu_ms", C.c_double), ("alg_bytes", C.c_uint64), ("weight_bytes", C.c_uint64), ("kv_bytes_per_cell", C.c_uint64),
-                ("n_calls_1", C.c_uint64), ("gpu_ms_1", C.c_double), ("alg_bytes_1", C.c_uint64)]
+                ("n_calls_1", C.c_uint64), ("gpu_ms_1", C.c_double), ("alg_bytes_1", C.c_uint64), ("n_segments", C.c_uint64), ("n_segments_skipped", C.c_uint64)]
 
 
 _api = None
@@ -197,6 +197,11 @@ class Context:
         if self.lib.pipeinfer_context_set_cu_range(self.h, int(lo), int(hi)) != 0:
             raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
 
+    def set_segments(self, layers_per_segment):
+        self.lib.pipeinfer_context_set_segments.argtypes = [C.c_void_p, C.c_int]
+        if self.lib.pipeinfer_context_set_segments(self.h, int(layers_per_segment)) != 0:
+            raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
+
     def set_graphs(self, enable):
         self.lib.pipeinfer_context_set_graphs.argtypes = [C.c_void_p, C.c_int]
         self.lib.pipeinfer_context_set_graphs.restype = None
@@ -224,6 +229,10 @@ class Context:
         t, b = ticket
         assert self.lib.llama_finish_async_decode(self.h, b.c, t) == 1
         return self.logits(b.c.n_tokens)
+
+    def cancel(self, batch_ids):
+        arr = (C.c_int32 * len(batch_ids))(*batch_ids)
+        self.lib.llama_cancel_run(self.h, arr, len(batch_ids))
 
     def iprobe(self):
         return bool(self.lib.llama_mpi_iprobe(self.h))

@@ -36,8 +36,10 @@ def use_more_bits(i, n):
     return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
 
 
-def tensor_plan(spec_name, ftype, falcon_two_norms=None):
-    """-> list of (name, ne(ggml order), ttype, role). Roles drive the synthetic fill."""
+def tensor_plan(spec_name, ftype, falcon_two_norms=None, layers=None):
+    """-> list of (name, ne(ggml order), ttype, role). Roles drive the synthetic fill.
+    layers = (offset, count): a depth-truncated copy — `count` layers named blk.0.. that carry the tensor types of layers offset.. of the full model
+    (the quantiser's mixture rules depend on the layer index); used for the per-layer CPU baseline of models too slow to decode whole."""
     arch, n_layer, n_embd, n_head, n_head_kv, n_ff, n_vocab, _ = SPECS[spec_name]
     hd = n_embd // n_head
     n_gqa = hd * n_head_kv
@@ -93,8 +95,10 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None):
 
     plan = [("token_embd.weight", (n_embd, n_vocab), fix(base, n_embd), "embd")]
     two_norms = falcon_two_norms if falcon_two_norms is not None else (arch == "falcon" and n_head_kv > 1)
-    for i in range(n_layer):
-        p = f"blk.{i}."
+    l_off, l_cnt = layers if layers else (0, n_layer)
+    for li in range(l_cnt):
+        p = f"blk.{li}."
+        i = l_off + li                                                    # index the type rules see
         if arch == "llama":
             plan += [
                 (p + "attn_norm.weight", (n_embd,), G.T_F32, "ones"),
@@ -339,7 +343,7 @@ def _vocab_kv(w, arch, n_vocab, vocab=None):
 
 
 def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random", noise=1.0, quantizer=None, vocab=None,
-                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0, only=None, pi_flip=0.0):
+                falcon_two_norms=None, pi_seed=1234, signal=1.0, head_gain=1.0, only=None, pi_flip=0.0, layers=None):
     """quantizer(ttype, f32 [rows,k]) -> uint8 blocks: when given (tests: the REAL reference quantiser), every weight is
     drawn as N(0,std^2) floats and quantised with it; otherwise blocks are filled directly (see module docstring).
     only(name) -> bool: tensors for which it is False become holes in the file (every tensor has its own seed, so a pipeline
@@ -351,7 +355,7 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
     w.add("general.file_type", G.U32, FTYPE_IDS.get(ftype.lower(), 0))
     w.add(f"{arch}.context_length", G.U32, n_ctx_train)
     w.add(f"{arch}.embedding_length", G.U32, n_embd)
-    w.add(f"{arch}.block_count", G.U32, n_layer)
+    w.add(f"{arch}.block_count", G.U32, layers[1] if layers else n_layer)
     w.add(f"{arch}.feed_forward_length", G.U32, n_ff)
     w.add(f"{arch}.attention.head_count", G.U32, n_head)
     w.add(f"{arch}.attention.head_count_kv", G.U32, n_head_kv)
@@ -381,7 +385,7 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
             emb_cache["e"] = r.standard_normal((n_vocab, n_embd), dtype=np.float32)
         return emb_cache["e"]
 
-    for idx, (name, ne, ttype, role) in enumerate(tensor_plan(spec_name, ftype, falcon_two_norms)):
+    for idx, (name, ne, ttype, role) in enumerate(tensor_plan(spec_name, ftype, falcon_two_norms, layers)):
         def make(name=name, ne=ne, ttype=ttype, role=role, idx=idx):
             rng = np.random.default_rng(seed + idx)
             n = int(np.prod(ne))

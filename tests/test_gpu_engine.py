@@ -288,3 +288,115 @@ def test_full_size_properties_llama_7b(LL, tmp_path_factory):
     for c in (a, b):
         c.free()
     m.free()
+
+
+@pytest.mark.parametrize("tgt,dft", [("tiny_llama_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0"),
+                                      ("tiny_llama_q3_k_m", "tiny_llama_q4_0")])
+@pytest.mark.parametrize("n_draft,n_parallel,p_split", [(3, 1, 0.9), (5, 3, 0.05), (8, 2, 0.3)])
+def test_synchronous_speculation_mode_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split):
+    """mode 1 = examples/speculative_orig restated (draft a tree, verify it in ONE target batch): accepted tokens == the reference target's
+    greedy continuation; with an identical draft every drafted token is accepted (n_accept is a deterministic function of the two models)."""
+    prompt, want = greedy_reference(tgt, 8, 24)
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
+    out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=p_split, ignore_eos=0, mode=1)
+    assert out[:24] == want, (out, want, res)
+    assert res["n_predict"] >= 24 and res["n_drafted"] > 0
+    if tgt == dft and n_parallel == 1:
+        assert res["n_accept"] == res["n_drafted_tokens"], res        # the draft IS the target: nothing is ever rejected
+    out2, res2 = None, None
+    ct.kv_clear(); cd.kv_clear()
+    out2, res2 = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=p_split, ignore_eos=0, mode=1)
+    assert out2 == out and (res2["n_drafted"], res2["n_accept"]) == (res["n_drafted"], res["n_accept"])      # deterministic counters
+    for c in (ct, cd):
+        c.free()
+    mt.free(); md.free()
+
+
+def test_reference_driver_binary_runs_on_the_engine(LL, tmp_path):
+    """oracle/_ref/speculative_ref = the reference's UNMODIFIED examples/speculative/speculative.cpp + common/*.cpp, compiled in the build
+    container against include/llama.h and linked to libpipeinfer_amd.so (make -C oracle refdriver).  It must generate, on this GPU, exactly
+    the text of the reference CPU kernels' greedy continuation of the same prompt."""
+    import subprocess
+    from tests import oracle_lib as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "speculative_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/speculative_ref was not built (needs the reference sources)")
+    tgt, dft = "tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"
+    text, n_gen = "hello world again and again", 24
+    m = LL.Model(os.path.join(GOLD, tgt + ".gguf"))
+    prompt = m.tokenize(text, add_bos=True, special=True)
+    ref = O.RefModel(os.path.join(GOLD, tgt + ".gguf"), n_ctx=256, max_seq=2, n_threads=2) if O.have_ref() and O.ref() is not None else O.OracleModel(os.path.join(GOLD, tgt + ".gguf"), n_ctx=256, max_seq=2)
+    lg = ref.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
+    want = [int(np.argmax(lg[-1]))]
+    for i in range(n_gen):
+        want.append(int(np.argmax(ref.decode([want[-1]], [len(prompt) + i], [[0]])[0])))
+    ref.close()
+    want_text = b"".join(m.token_to_piece(t) for t in want[:n_gen + 1])
+    m.free()
+    r = subprocess.run([exe, "-m", os.path.join(GOLD, tgt + ".gguf"), "-md", os.path.join(GOLD, dft + ".gguf"), "-p", text, "-n", str(n_gen), "-c", "256", "-b", "64",
+                        "--draft", "3", "-np", "3", "-pa", "0.05", "-ps", "0.9", "-pr", "0.0", "--temp", "0", "--repeat-last-n", "0", "--mpi-layer-split", "1.0/1.0",
+                        "-t", "1", "-tb", "1", "--log-disable"], capture_output=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.startswith(want_text[:len(r.stdout)]) and len(r.stdout) >= len(want_text) - 8, (r.stdout, want_text)
+    assert b"n_drafted" in r.stderr and b"n_accept" in r.stderr, r.stderr[-1500:]
+    assert os.path.exists(os.path.join(str(tmp_path), "results.csv"))
+
+
+def test_segmented_context_equals_the_single_graph_context(LL):
+    """pipeinfer_context_set_segments: the stage captured as per-layer segments and launched by the feeder thread computes the same bits as
+    the one-graph context (decode widths 1..17, so the VALU and the matrix-core mat-mul paths are both crossed)"""
+    stem = "tiny_llama_b_q4_k_m"
+    m = LL.Model(os.path.join(GOLD, stem + ".gguf"))
+    a, b = LL.Context(m, n_ctx=256, n_batch=64), LL.Context(m, n_ctx=256, n_batch=64)
+    b.set_segments(1)
+    rng = np.random.default_rng(5)
+    pos = 0
+    for n in (9, 1, 1, 4, 17, 2, 1, 5):
+        toks = [int(x) for x in rng.integers(3, m.n_vocab, n)]
+        la = a.decode(toks, list(range(pos, pos + n)), [[0]] * n)
+        lb = b.decode(toks, list(range(pos, pos + n)), [[0]] * n)
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), n
+        pos += n
+    assert b.stats()["n_segments"] == 8 * 3                  # three layers = three segments per call
+    a.free(); b.free(); m.free()
+
+
+@pytest.mark.parametrize("tgt,dft", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0")])
+@pytest.mark.parametrize("min_spec", [0, 1, 3])
+def test_driver_lossless_with_a_segmented_target_and_a_priority_draft(LL, tgt, dft, min_spec):
+    """the single-GPU arrangement of bench.py: the target is launched segment by segment by its feeder thread (cancelled speculative runs stop at
+    the next segment boundary), the draft context has stream priority and is served between the target's segments"""
+    prompt, want = greedy_reference(tgt, 8, 24)
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    for trial in range(4):
+        ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
+        ct.set_segments(1); cd.set_priority(1)
+        out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=3, n_parallel=3, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec)
+        assert out[:24] == want, (trial, out, want, res)
+        ct.free(); cd.free()
+    mt.free(); md.free()
+
+
+def test_cancel_of_a_run_in_flight_stops_it_at_a_segment_boundary(LL):
+    """llama_cancel_run after llama_start_async_decode (llama.cpp:9981-9993 + the abort callback :5665-5687): the run completes "empty", the
+    context stays usable and later runs compute the same bits as on a fresh context"""
+    stem = "tiny_llama_b_q4_k_m"
+    m = LL.Model(os.path.join(GOLD, stem + ".gguf"))
+    c, ref = LL.Context(m, n_ctx=256, n_batch=64), LL.Context(m, n_ctx=256, n_batch=64)
+    c.set_segments(1)
+    prompt = [5, 9, 13, 200, 77, 31, 8, 19]
+    l0 = c.decode(prompt, list(range(8)), [[0]] * 8); r0 = ref.decode(prompt, list(range(8)), [[0]] * 8)
+    assert np.array_equal(l0.view(np.uint32), r0.view(np.uint32))
+    skipped = 0
+    for trial in range(20):
+        t = c.start([42, 43, 44], [8, 9, 10], [[1], [1], [1]], batch_id=100 + trial)      # a speculative batch in partition 1
+        c.cancel([100 + trial])
+        assert c.lib.llama_finish_async_decode(c.h, t[1].c, t[0]) == 1
+        c.seq_rm(1, 8, -1)                                                                 # the driver frees the partition's cells
+    skipped = c.stats()["n_segments_skipped"]
+    l1 = c.decode([42], [8], [[0]]); r1 = ref.decode([42], [8], [[0]])
+    assert np.array_equal(l1.view(np.uint32), r1.view(np.uint32))
+    print("segments skipped by cancels:", skipped, "of", 20 * 3)
+    c.free(); ref.free(); m.free()
