@@ -231,6 +231,11 @@ def main():
     ct, cd = LL.Context(mt, n_ctx=args.n_ctx, n_batch=512), LL.Context(md, n_ctx=args.n_ctx, n_batch=512)
     cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "1")))
     ct.set_priority(int(os.environ.get("PIPEINFER_TARGET_PRIORITY", "0")))
+    # one GPU: the target's stage graphs are launched segment by segment by a feeder thread, so that a cancelled speculative run stops at the
+    # next segment boundary and the (high-priority) draft is served between segments instead of behind whole target runs
+    seg_layers = int(os.environ.get("PIPEINFER_SEG_LAYERS", "8"))
+    if seg_layers > 0:
+        ct.set_segments(seg_layers)
     ct.prepare(); cd.prepare()
     print(f"[bench] models resident in HBM after {time.time() - t0:.1f}s", file=sys.stderr)
 
@@ -303,6 +308,7 @@ def main():
                                       "GBps": round(st_t["alg_bytes_1"] / max(1e-9, st_t["gpu_ms_1"] * 1e-3) / 1e9, 1)}
     roofline["target_all_calls"] = {"calls": st_t["n_calls"], "gpu_ms_per_call": round(st_t["gpu_ms"] / max(1, st_t["n_calls"]), 4),
                                     "GBps": round(st_t["alg_bytes"] / max(1e-9, st_t["gpu_ms"] * 1e-3) / 1e9, 1)}
+    roofline["target_segments"] = {"layers_per_segment": seg_layers, "launched": st_t["n_segments"], "skipped_by_cancel": st_t["n_segments_skipped"]}
     roofline["draft_decode_call"] = {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
                                      "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}
 

@@ -1,4 +1,7 @@
 #include "vocab.h"
+#include "unicode_tables.h"
+
+#include <algorithm>
 
 #include <cstring>
 #include <queue>
@@ -162,6 +165,143 @@ private:
 
 struct fragment { bool is_token; int32_t token; size_t off, len; };
 
+// ---- byte-level BPE (gpt2 vocabularies: Falcon) ---------------------------------------------------------------------------------------
+// llm_tokenizer_bpe (llama.cpp:6117-6247) with its GPT-2 style pre-tokenizer bpe_gpt2_preprocess (:6249-6395).  The pre-tokenizer is a hand
+// written approximation of the regex  's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+  — its exact splits (including
+// the places where it differs from the regex) decide the token ids, so the state machine below follows it decision by decision.
+enum cp_class { CP_OTHER = 0, CP_DIGIT, CP_LETTER, CP_WHITESPACE };
+template <size_t N> static bool in_ranges(const uint32_t (&r)[N][2], uint32_t cp) {
+    size_t lo = 0, hi = N;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (cp > r[mid][1]) lo = mid + 1; else hi = mid; }
+    return lo < N && cp >= r[lo][0];
+}
+static cp_class classify(uint32_t cp) {
+    if (in_ranges(pi_unicode_letter, cp)) return CP_LETTER;
+    if (in_ranges(pi_unicode_digit, cp)) return CP_DIGIT;
+    if (in_ranges(pi_unicode_whitespace, cp)) return CP_WHITESPACE;
+    return CP_OTHER;
+}
+static uint32_t decode_utf8(const std::string & s, size_t & off) {               // unicode.h:259-291 on well-formed input; malformed bytes pass through one by one
+    const uint8_t c = (uint8_t) s[off];
+    const size_t left = s.size() - off;
+    if (c < 0x80 || left < 2 || (c & 0xE0) == 0x80) { off += 1; return c; }
+    if ((c & 0xE0) == 0xC0) { const uint32_t r = (c & 0x1Fu) << 6 | ((uint8_t) s[off + 1] & 0x3Fu); off += 2; return r; }
+    if ((c & 0xF0) == 0xE0 && left >= 3) { const uint32_t r = (c & 0x0Fu) << 12 | ((uint8_t) s[off + 1] & 0x3Fu) << 6 | ((uint8_t) s[off + 2] & 0x3Fu); off += 3; return r; }
+    if ((c & 0xF8) == 0xF0 && left >= 4) {
+        const uint32_t r = (c & 0x07u) << 18 | ((uint8_t) s[off + 1] & 0x3Fu) << 12 | ((uint8_t) s[off + 2] & 0x3Fu) << 6 | ((uint8_t) s[off + 3] & 0x3Fu);
+        off += 4; return r;
+    }
+    off += 1; return c;
+}
+static std::string encode_utf8(uint32_t cp) {
+    std::string r;
+    if (cp < 0x80) r.push_back((char) cp);
+    else if (cp < 0x800) { r.push_back((char) (0xC0 | cp >> 6)); r.push_back((char) (0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { r.push_back((char) (0xE0 | cp >> 12)); r.push_back((char) (0x80 | ((cp >> 6) & 0x3F))); r.push_back((char) (0x80 | (cp & 0x3F))); }
+    else { r.push_back((char) (0xF0 | cp >> 18)); r.push_back((char) (0x80 | ((cp >> 12) & 0x3F))); r.push_back((char) (0x80 | ((cp >> 6) & 0x3F))); r.push_back((char) (0x80 | (cp & 0x3F))); }
+    return r;
+}
+// GPT-2's byte -> printable unicode map (unicode.h:405-427): printable latin-1 bytes stand for themselves, the others become U+0100 + k
+static const std::string & byte_to_unicode(uint8_t b) {
+    static const std::vector<std::string> table = [] {
+        std::vector<std::string> t(256);
+        int k = 0;
+        for (int c = 0; c < 256; c++) {
+            const bool keep = (c >= 33 && c <= 126) || (c >= 161 && c <= 172) || (c >= 174 && c <= 255);
+            t[c] = encode_utf8(keep ? (uint32_t) c : (uint32_t) (256 + k++));
+        }
+        return t;
+    }();
+    return table[b];
+}
+
+static std::vector<std::string> bpe_pre_tokenize(const std::string & text) {
+    std::vector<std::string> ch; std::vector<cp_class> cls;
+    for (size_t off = 0; off < text.size();) { const uint32_t cp = decode_utf8(text, off); ch.push_back(encode_utf8(cp)); cls.push_back(classify(cp)); }
+    const int n = (int) ch.size();
+    std::vector<std::string> words;
+    std::string token;
+    enum { NONE, LETTERS, DIGITS, SPECIALS, SPACES_AHEAD } collecting = NONE;
+    static const std::string empty;
+    for (int i = 0; i < n; i++) {
+        const std::string & c = ch[i], & c1 = i + 1 < n ? ch[i + 1] : empty, & c2 = i + 2 < n ? ch[i + 2] : empty;
+        const cp_class t = cls[i], t1 = i + 1 < n ? cls[i + 1] : CP_OTHER;
+        if (c == "'" && n - i >= 2 && (c1 == "s" || c1 == "t" || c1 == "m" || c1 == "d")) {                 // 's 't 'm 'd  (the collecting state is NOT reset: :6282-6293)
+            if (!token.empty()) words.push_back(token);
+            words.push_back(c + c1); token.clear(); i += 1; continue;
+        }
+        if (c == "'" && n - i >= 3 && ((c1 == "r" && c2 == "e") || (c1 == "v" && c2 == "e") || (c1 == "l" && c2 == "l"))) {    // 're 've 'll
+            if (!token.empty()) words.push_back(token);
+            words.push_back(c + c1 + c2); token.clear(); i += 2; continue;
+        }
+        bool split = false;
+        if (collecting == NONE) {
+            const bool lead_space = token.empty() && c == " ";                                               // " ?" of the regex alternatives
+            if (t == CP_LETTER || (lead_space && t1 == CP_LETTER)) collecting = LETTERS;
+            else if (t == CP_DIGIT || (lead_space && t1 == CP_DIGIT)) collecting = DIGITS;
+            else if (t == CP_OTHER || (lead_space && t1 == CP_OTHER)) collecting = SPECIALS;                // (no next character counts as "other", like the reference's empty lookup)
+            else if (t == CP_WHITESPACE && t1 == CP_WHITESPACE && i + 1 < n) collecting = SPACES_AHEAD;
+            else if (t == CP_WHITESPACE) split = true;
+        } else if ((collecting == LETTERS && t != CP_LETTER) || (collecting == DIGITS && t != CP_DIGIT) ||
+                   (collecting == SPECIALS && t != CP_OTHER) || (collecting == SPACES_AHEAD && i + 1 < n && (t1 == CP_LETTER || t1 == CP_DIGIT))) {
+            split = true;
+        }
+        if (i + 1 == n) { split = true; token += c; }                                                       // final character: it joins the token that is pushed now
+        if (split) {
+            if (!token.empty()) words.push_back(token);
+            token = c; collecting = NONE;
+        } else token += c;
+    }
+    for (std::string & w : words) { std::string e; for (char b : w) e += byte_to_unicode((uint8_t) b); w.swap(e); }
+    return words;
+}
+
+struct bpe_bigram { int left, right; std::string text; int rank; };
+struct bpe_bigram_after { bool operator()(const bpe_bigram & l, const bpe_bigram & r) const { return l.rank > r.rank || (l.rank == r.rank && l.left > r.left); } };
+
+static void bpe_tokenize(const vocab & v, const std::string & text, std::vector<int32_t> & out) {
+    for (const std::string & word : bpe_pre_tokenize(text)) {
+        struct sym { size_t off, n; int prev, next; };
+        std::vector<sym> syms;
+        for (size_t off = 0; off < word.size();) {
+            const size_t len = std::min(word.size() - off, utf8_len(word[off]));
+            syms.push_back(sym{ off, len, (int) syms.size() - 1, -1 });
+            off += len;
+        }
+        for (size_t i = 0; i + 1 < syms.size(); i++) syms[i].next = (int) i + 1;
+        std::priority_queue<bpe_bigram, std::vector<bpe_bigram>, bpe_bigram_after> queue;
+        auto str = [&](int i) { return word.substr(syms[i].off, syms[i].n); };
+        auto try_add = [&](int l, int r) {
+            if (l < 0 || r < 0) return;
+            const std::string a = str(l), b = str(r);
+            const auto it = v.bpe_ranks.find(std::make_pair(a, b));
+            if (it != v.bpe_ranks.end()) queue.push(bpe_bigram{ l, r, a + b, it->second });
+        };
+        for (int i = 1; i < (int) syms.size(); i++) try_add(i - 1, i);
+        while (!queue.empty()) {
+            const bpe_bigram bg = queue.top(); queue.pop();
+            sym & L = syms[bg.left], & R = syms[bg.right];
+            if (L.n == 0 || R.n == 0 || str(bg.left) + str(bg.right) != bg.text) continue;                  // outdated
+            L.n += R.n; R.n = 0;                                                                             // symbols of a word are contiguous: merging extends the left one
+            L.next = R.next;
+            if (R.next >= 0) syms[R.next].prev = bg.left;
+            try_add(L.prev, bg.left);
+            try_add(bg.left, L.next);
+        }
+        for (const sym & sy : syms) {
+            if (sy.n == 0) continue;
+            const std::string piece = word.substr(sy.off, sy.n);
+            const auto it = v.token_to_id.find(piece);
+            if (it != v.token_to_id.end()) { out.push_back(it->second); continue; }
+            for (char b : piece) {                                                                           // unknown piece: its bytes, one token each (:6206-6214)
+                const auto ib = v.token_to_id.find(std::string(1, b));
+                if (ib == v.token_to_id.end()) throw std::runtime_error("ERROR: byte not found in vocab");
+                out.push_back(ib->second);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 std::vector<int32_t> vocab::tokenize(const std::string & raw, bool bos, bool special) const {
@@ -187,7 +327,12 @@ std::vector<int32_t> vocab::tokenize(const std::string & raw, bool bos, bool spe
             frags.swap(next);
         }
     }
-    if (type != 0) throw std::runtime_error("BPE (gpt2) tokenisation of raw text is not implemented on this path; pass token ids");
+    if (type != 0) {                                                        // llama_tokenize_internal, LLAMA_VOCAB_TYPE_BPE arm (llama.cpp:6575-6594)
+        for (const fragment & fr : frags) {
+            if (fr.is_token) out.push_back(fr.token); else bpe_tokenize(*this, raw.substr(fr.off, fr.len), out);
+        }
+        return out;
+    }
     for (size_t i = 0; i < frags.size(); i++) {
         const fragment & fr = frags[i];
         if (fr.is_token) { out.push_back(fr.token); continue; }

@@ -60,6 +60,20 @@ def split_layers(n_layer, n_stage, weights=None):
     return [(out[2 * i], out[2 * i + 1]) for i in range(n_stage)]
 
 
+def split_layers_balanced(n_layer, n_stage, tail_layers=1.5):
+    """[(l0, l1)] per stage with (nearly) equal WORK: the reference's equal weights give the last stage the truncation remainder on top of
+    final norm + lm_head (80 layers over 7 stages: 11 x 6 + 14), which then bounds the pipeline.  Here every stage gets floor/ceil of an even
+    share after charging the last stage `tail_layers` layers' worth for the lm_head (215 MB of Q6_K vs ~500 MB per 70B layer: ~0.45; the
+    default leaves slack for the top-k and the logits copy)."""
+    share = (n_layer + tail_layers) / n_stage
+    cuts, acc = [0], 0.0
+    for i in range(n_stage - 1):
+        acc += share
+        cuts.append(min(n_layer, max(cuts[-1] + 1, int(round(acc)))))
+    cuts.append(n_layer)
+    return [(cuts[i], cuts[i + 1]) for i in range(n_stage)]
+
+
 def run_message(run_seq, batch_id, n_tokens, words, flags, gen, meta):
     """header + (when it fits) the metadata block of a run, as one fixed-size int32 message"""
     msg = torch.zeros(HDR_WORDS + INLINE_WORDS, dtype=torch.int32)
@@ -409,10 +423,12 @@ def bench_main(args, rank, world):
     lib = L.load()
     L.check(lib.pi_device_init(local), "pi_device_init")
     # the default workload of N > 1 is BASELINE configs[2] (70B target); PIPEINFER_KEEP_WORKLOAD=1 keeps an explicit --workload 7b
-    tspec, tft, dspec, dft = B.WORKLOADS[args.workload if (args.workload != "7b" or os.environ.get("PIPEINFER_KEEP_WORKLOAD")) else "70b"]
+    tspec, tft, dspec, dft = B.WORKLOADS[args.workload]
     n_layer = synth.SPECS[tspec][1]
     n_stage = world - 1
-    ranges = split_layers(n_layer, n_stage)
+    # the bench splits by work; PIPEINFER_REFERENCE_SPLIT=1 uses the reference's ggml_mpi_split_range with equal weights instead
+    ref_split = bool(os.environ.get("PIPEINFER_REFERENCE_SPLIT"))
+    ranges = split_layers(n_layer, n_stage) if ref_split else split_layers_balanced(n_layer, n_stage)
     cache = args.cache
     os.makedirs(cache, exist_ok=True)
 
@@ -430,7 +446,7 @@ def bench_main(args, rank, world):
     n_embd, n_vocab = synth.SPECS[tspec][2], synth.SPECS[tspec][6]
     if rank == 0:
         tgt_path = stage_file("head", lambda name: False)              # header + vocabulary only: the head never reads weights
-        dft_path = B.ensure_model(cache, dspec, dft, 0xD4AF, args.signal, args.noise)
+        dft_path = B.ensure_model(cache, dspec, dft, 0xD4AF, args.signal, args.noise, flip=args.draft_miss)
         mt, md = LL.Model(tgt_path, device=local), LL.Model(dft_path, device=local)
         ct, cd = LL.Context(mt, n_ctx=args.n_ctx, n_batch=512), LL.Context(md, n_ctx=args.n_ctx, n_batch=512)
         remote = RemoteTarget(links, 1, world - 1, range(1, world), mt.n_vocab)
@@ -465,9 +481,8 @@ def bench_main(args, rank, world):
         return
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
-                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")),
-                # with the draft on a GPU of its own a pause has nothing to win; it stays on only when the ranks share one device (dry runs)
-                adaptive_window=args.adaptive_window if links.via_host else 0, adaptive_pause=args.adaptive_pause)
+                ignore_eos=1, mode=args.mode, min_spec_iters=args.min_spec_iters, max_inflight=args.max_inflight, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")),
+                adaptive_window=args.adaptive_window, adaptive_pause=args.adaptive_pause)
     rng = np.random.default_rng(0xBEEF)
     prompts = [[int(x) for x in rng.integers(3, mt.n_vocab, args.n_prompt)] for _ in range(args.warmup + args.steps + 1)]
 
@@ -498,25 +513,32 @@ def bench_main(args, rank, world):
             except OSError:
                 pass
 
-    n_tok = sum(r["n_predict"] for r in results)
-    t_dec = sum(r["t_dec_s"] for r in results)
-    drafted = sum(r["n_drafted_tokens"] for r in results)
-    acc_clean = sum(r["n_accept_clean"] for r in results)
+    main_sum = B.summarize(results)
+    main_sum["runs_skipped_by_stages"] = remote.n_skipped
     stage_stats = [{"rank": r, "layers": list(ranges[r - 1]), "calls": int(gathered[r][1]), "gpu_ms_per_call": round(float(gathered[r][0]) / max(1.0, float(gathered[r][1])), 4),
                     "GBps": round(float(gathered[r][2]) / max(1e-9, float(gathered[r][0]) * 1e-3) / 1e9, 1)} for r in range(1, world)]
     slow = max(stage_stats, key=lambda s: s["gpu_ms_per_call"])
-    out = {"metric": "accepted tokens/sec + acceptance rate, 70B Q4_K target / 1.1B draft", "value": round(n_tok / t_dec, 2), "unit": "tokens/s",
+    # dominant kernel = the single-token Q4_K mat-vec of every stage; its HBM traffic comes from the committed single-GPU PMC pass of the same
+    # kernel sources (the per-launch traffic of a mat-vec does not depend on which stage launches it)
+    traffic, traffic_src = B.committed_traffic(args.workload, "Q4_K_nt1")
+    sched = {0: "PipeInfer (asynchronous continuous speculation, examples/speculative)", 1: "synchronous tree speculation (examples/speculative_orig)", 2: "target only"}[args.mode]
+    out = {"metric": B.METRIC if args.workload == "70b" else f"accepted tokens/sec + acceptance rate, {tspec} {tft} target / {dspec} draft", "value": main_sum["tokens_per_s"], "unit": "tokens/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_total / args.steps, 2), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "int8 x int4/6 dot, fp32 accumulate (f16 KV)", "data": "synthetic",
-           "config": {"workload": f"{tspec} {tft} target layer-split over {n_stage} GPU(s) + {dspec} {dft} draft on GPU0, RCCL send/recv (BASELINE configs[2])",
+           "config": {"workload": f"{tspec} {tft} target layer-split over {n_stage} GPU(s) + {dspec} {dft} draft on GPU0, RCCL send/recv", "schedule": sched,
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel, "p_accept": args.p_accept,
-                      "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "layer_ranges": [list(r) for r in ranges]},
-           "acceptance": {"accepted_draft_tokens": acc_clean, "drafted_tokens": drafted, "rate": round(acc_clean / max(1, drafted), 4),
-                          "spec_runs": sum(r["n_runs_spec"] for r in results), "canceled_runs": sum(r["n_runs_canceled"] for r in results),
-                          "draft_paused_tokens": sum(r["n_draft_paused"] for r in results), "draft_catchups": sum(r["n_draft_catchups"] for r in results),
-                          "runs_skipped_by_stages": remote.n_skipped},
+                      "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "layer_ranges": [list(r) for r in ranges],
+                      "layer_split": "reference ggml_mpi_split_range, equal weights" if ref_split else "balanced by work (lm_head charged to the last stage)",
+                      "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}, draft wrong on {args.draft_miss:.0%} of the vocabulary"},
+           "acceptance": {k: v for k, v in main_sum.items() if k != "tokens_per_s"},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff,
-           "roofline": {"bound": "hbm", "kernel": "stage forward pass (slowest stage)", "achieved": slow["GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(slow["GBps"] / B.HBM_PEAK_GBS, 4), "traffic": None, "stages": stage_stats},
-           "cpu_baseline": None}
+           "roofline": {"bound": "hbm", "kernel": "k_mmvq_kq<Q4_K,NT=1> inside the slowest stage's forward pass", "achieved": slow["GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(slow["GBps"] / B.HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "note": "achieved = algorithmic bytes of the slowest stage's single-token calls / their GPU time (whole stage call, not one kernel)", "stages": stage_stats}}
+    if not args.no_cpu_baseline:
+        try:
+            full = B.ensure_model(cache, tspec, tft, 0x5EED, args.signal, args.noise) if n_layer <= 32 else None
+            out["cpu_baseline"] = B.cpu_baseline(tspec, tft, full, cache, args.signal, args.noise, args.cpu_tokens)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": repr(e)}
     print(json.dumps(out))

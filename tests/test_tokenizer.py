@@ -1,5 +1,6 @@
-"""CPU: SPM tokenizer known answers of the reference's own test (tests/test-tokenizer-0-llama.cpp:12-40) on the reference's
-vocab fixture (models/ggml-vocab-llama.gguf, committed under tests/golden/ as a data file), plus round trips."""
+"""CPU: tokenizer known answers of the reference's own tests on the reference's vocab fixtures (committed under tests/golden/ as data files):
+SPM - tests/test-tokenizer-0-llama.cpp:12-40 on models/ggml-vocab-llama.gguf; byte-level BPE - tests/test-tokenizer-0-falcon.cpp:12-41 on
+models/ggml-vocab-falcon.gguf; plus round trips."""
 import os
 
 import pytest
@@ -55,3 +56,53 @@ def test_special_tokens_partition(model):
     assert model.tokenize("<s>Hello</s>", add_bos=False, special=True) == [1, 10994, 2]
     assert model.tokenize("Hello</s>", add_bos=False, special=True) == [15043, 2]
     assert model.tokenize("<s>Hello", add_bos=False, special=False)[0] != 1
+
+
+# ---- byte-level BPE (Falcon): tests/test-tokenizer-0-falcon.cpp:12-41 --------------------------------------------------------------------
+VOCAB_FALCON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ggml-vocab-falcon.gguf")
+KNOWN_FALCON = {
+    "": [], " ": [204], "  ": [258], "   ": [466], "\t": [192], "\n": [193], "\t\n": [19125],
+    "Hello world": [9856, 1079], " Hello world": [23090, 1079], "Hello World": [9856, 2889], " Hello World": [23090, 2889], " Hello World!": [23090, 2889, 12],
+    "Hello, world!": [9856, 23, 1079, 12], " Hello, world!": [23090, 23, 1079, 12],
+    " this is 🦙.cpp": [414, 304, 3346, 111, 231, 25, 29247],
+    "w048 7tuijk dsdfhu": [98, 55866, 204, 34, 16682, 7149, 36190, 6869, 11481],
+    "нещо на Български": [150, 133, 6207, 151, 215, 150, 134, 5052, 133, 6279, 5052, 223, 151, 216, 49679, 123, 53110, 47043, 7795],
+    "កាន់តែពិសេសអាចខលចេញ": [38154, 206, 38154, 126, 38154, 225, 167, 237, 217, 38154, 221, 167, 237, 208, 38154, 228, 38154, 127, 38154, 237, 167, 237, 207, 38154, 237,
+                            38154, 107, 38154, 126, 38154, 211, 38154, 207, 38154, 233, 38154, 211, 167, 237, 207, 38154, 215],
+    "🚀 (normal) 😶‍🌫️ (multiple emojis concatenated) ✅ (only emoji that has its own token)":
+        [2571, 232, 206, 204, 19, 11003, 20, 8196, 126, 283, 219, 48778, 116, 13392, 204, 19, 51831, 732, 63209, 1741, 7955, 522, 20, 22438, 211, 204, 19, 7927, 53360, 325, 504,
+         701, 946, 10930, 20],
+    "Hello": [9856], " Hello": [23090], "  Hello": [204, 23090], "   Hello": [258, 23090], "    Hello": [466, 23090], "    Hello\n    Hello": [466, 23090, 742, 23090],
+    "\n =": [1212, 40], "' era": [18, 4932],
+}
+
+
+@pytest.fixture(scope="module")
+def falcon():
+    lib = LL.api()
+    p = lib.llama_model_default_params()
+    p.vocab_only = True
+    h = lib.llama_load_model_from_file(VOCAB_FALCON.encode(), p)
+    assert h
+    m = LL.Model.__new__(LL.Model)
+    m.lib, m.h, m.n_vocab = lib, h, lib.llama_n_vocab(h)
+    return m
+
+
+def test_bpe_known_answers(falcon):
+    assert falcon.n_vocab == 65024
+    for text, want in KNOWN_FALCON.items():
+        assert falcon.tokenize(text, add_bos=False) == want, text
+
+
+def test_bpe_detokenize_round_trip(falcon):
+    for text in KNOWN_FALCON:
+        toks = falcon.tokenize(text, add_bos=False)
+        assert b"".join(falcon.token_to_piece(t) for t in toks).decode("utf-8") == text
+
+
+def test_bpe_contractions_and_runs(falcon):
+    # every split of the hand-written GPT-2 pre-tokenizer must round-trip, whatever it does with apostrophes, digits and runs of spaces
+    for text in ("I'm sure they're here, we've seen it'll work; don't", "a1b22c333 4444  55555   x", "tabs\t\tand\n\nnewlines  \n ", "'" * 4 + "s't'"):
+        toks = falcon.tokenize(text, add_bos=False)
+        assert b"".join(falcon.token_to_piece(t) for t in toks).decode("utf-8") == text
