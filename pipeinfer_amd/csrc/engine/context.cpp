@@ -147,8 +147,9 @@ static pi_run * acquire_run(llama_context * ctx, int n_tokens, size_t meta_bytes
 // Kernel sequence per Llama layer (10 launches + attention):
 //   norm+quant -> wq, wk, wv -> rope+KV store -> attention -> quant -> wo(+residual) -> norm+quant -> up, gate -> silu*up+quant -> down(+residual)
 // The fused launches compute exactly what the reference's separate graph nodes compute (same fp32 rounding points).
+static bool trace_enabled() { static const bool on = getenv("PI_TRACE") != nullptr; return on; }     // debug dump of intermediates: read once
 static void trace(llama_context * ctx, const char * what, int il, const float * x, int64_t n, int n_tok, int64_t stride = 0) {
-    if (!getenv("PI_TRACE")) return;
+    if (!trace_enabled()) return;
     if (!stride) stride = n;
     std::vector<float> h((size_t) stride * n_tok);
     (void) hipStreamSynchronize(ctx->stream);
@@ -195,7 +196,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
             float * q = ctx->qkv, * k = q + (size_t) n_tok * n_embd, * v = k + (size_t) n_tok * n_gqa;
             const int vq = vdt_of(L.wq);
             if (!norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vq, ctx->q8a)) return false;
-            if (!getenv("PI_TRACE") && pi_op_mul_mat_qkv_rope_ok(L.wq, L.wk, L.wv, 0, hd)) {
+            if (!trace_enabled() && pi_op_mul_mat_qkv_rope_ok(L.wq, L.wk, L.wv, 0, hd)) {
                 // projections, RoPE, f16 rounding and the K/V cache writes in the mat-vec launch(es) themselves
                 OP_OK(pi_op_mul_mat_qkv_rope(L.wq, L.wk, L.wv, ctx->q8a, n_tok, ctx->pos_dev, ctx->rope, hd, hp.n_head, hp.n_head_kv, kv_head, ctx->dyn_dev, ctx->q16, kc, vc, s));
             } else {
@@ -281,7 +282,7 @@ static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, 
 // segment `seg` of the forward pass: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device memory that
 // launch_inputs refreshed, so replaying the captured graph IS this call's segment
 static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out) {
-    static const bool tracing = getenv("PI_TRACE") != nullptr;
+    const bool tracing = trace_enabled();
     const int nseg = n_segments(ctx);
     const int la = ctx->seg_layers > 0 ? ctx->l0 + seg * ctx->seg_layers : ctx->l0;
     const int lb = ctx->seg_layers > 0 ? std::min(ctx->l1, la + ctx->seg_layers) : ctx->l1;
@@ -328,17 +329,21 @@ static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta,
     return true;
 }
 
-// ---- device arbiter: contexts with a positive stream priority (the draft of a single-GPU run) go first ---------------------------------------
-// A feeder only hands the GPU its next segment while no such context has a run pending and none finished one in the last `grace` microseconds
-// (the driver issues draft steps back to back: a target segment slipped into the gap would delay every one of them).
-static std::atomic<int> g_urgent{0};
-static std::atomic<int64_t> g_urgent_until{0};
-static int64_t urgent_grace_us() { static const int64_t v = getenv("PI_YIELD_GRACE_US") ? atoll(getenv("PI_YIELD_GRACE_US")) : 150; return v; }
+// ---- device arbiter: contexts with a positive stream priority (the draft of a single-GPU run) go first -------------------------------------
+// While such a context has a run pending, a feeder does not hand the GPU its next segment — except for ONE segment per completed urgent
+// run (a credit).  The driver issues draft steps back to back and, with continuous speculation, never stops by itself while the target
+// is not back: without the credit the target would make no progress at all while the draft is busy; with it the two alternate, one target
+// segment per draft step, whatever the timing of the calls.
+static std::atomic<int> g_urgent{0}, g_credit{0};
 static void urgent_begin(llama_context * ctx) { if (ctx->stream_priority > 0) g_urgent.fetch_add(1); }
-static void urgent_end(llama_context * ctx) { if (ctx->stream_priority > 0) { g_urgent_until.store(time_us() + urgent_grace_us()); g_urgent.fetch_sub(1); } }
+static void urgent_end(llama_context * ctx) { if (ctx->stream_priority > 0) { g_credit.store(1); g_urgent.fetch_sub(1); } }
 static void yield_to_urgent(const llama_context * ctx) {
     if (ctx->stream_priority > 0) return;
-    while (g_urgent.load() > 0 || time_us() < g_urgent_until.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    for (int spin = 0; g_urgent.load() > 0; spin++) {
+        int c = g_credit.load();
+        if (c > 0 && g_credit.compare_exchange_strong(c, c - 1)) return;
+        if (spin < 4000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
 }
 
 // ---- feeder thread of a segmented context ---------------------------------------------------------------------------------------------------

@@ -37,6 +37,15 @@ extern "C" struct llama_context * llama_new_context_with_model(struct llama_mode
     ctx->model = model;
     ctx->cparams = params;
     ctx->n_ctx = params.n_ctx == 0 ? model->hparams.n_ctx_train : (int) params.n_ctx;       // llama.cpp:8726
+    {   // the attention kernel keeps 8 score rows of n_ctx floats (+ the visibility words) in LDS: say so HERE, not at the first decode
+        const size_t att_lds = (size_t) 8 * ((size_t) ctx->n_ctx + ((size_t) ctx->n_ctx + 31) / 32) * sizeof(float);
+        if (att_lds > 156 * 1024) {
+            fprintf(stderr, "llama_new_context_with_model: n_ctx = %d is beyond this engine's attention kernel (score rows in LDS: %zu B > 156 KiB, n_ctx <= 4840)%s\n",
+                    ctx->n_ctx, att_lds, params.n_ctx == 0 ? "; pass an explicit n_ctx (0 selected the model's training context)" : "");
+            delete ctx;
+            return nullptr;
+        }
+    }
     ctx->n_batch = (int) std::max<uint32_t>(params.n_batch, 1);
     ctx->l0 = 0; ctx->l1 = model->hparams.n_layer; ctx->is_first = ctx->is_last = true;
     ctx->cells.reset(new pi::kv_cells(ctx->n_ctx));

@@ -301,7 +301,15 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
 }
 
 static void mmq_dispatch(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    mmq_dispatch(g, groups, cfg, stream, ea, eb);
+    switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
+        case 22: mmq_go<PI_Q4_K, 2, 2, 2, 2>(g, groups, stream, ea, eb); break;
+        case 24: mmq_go<PI_Q4_K, 2, 4, 2, 2>(g, groups, stream, ea, eb); break;
+        case 25: mmq_go<PI_Q4_K, 2, 4, 2, 4>(g, groups, stream, ea, eb); break;
+        case 41: mmq_go<PI_Q4_K, 4, 1, 2, 4>(g, groups, stream, ea, eb); break;
+        case 44: mmq_go<PI_Q4_K, 4, 4, 2, 4>(g, groups, stream, ea, eb); break;
+        case 43: mmq_go<PI_Q4_K, 4, 2, 2, 2>(g, groups, stream, ea, eb); break;
+        default: mmq_go<PI_Q4_K, 4, 2, 2, 4>(g, groups, stream, ea, eb); break;
+    }
 }
 // dynamic-LDS limits of every instance, set once and outside any stream capture (a launch inside a captured graph must not change function attributes)
 extern "C" int pi_op_mul_mat_reserve(void) {

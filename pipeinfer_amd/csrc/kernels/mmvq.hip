@@ -890,7 +890,8 @@ extern "C" int pi_op_mul_mat(const pi_weight * w, const void * q8, int n_tok, fl
 
 // 1 when pi_op_mul_mat_qkv_rope applies: Llama-style RoPE (pairs 2i, 2i+1), K-quant projections, even row counts
 extern "C" int pi_op_mul_mat_qkv_rope_ok(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, int neox, int hd) {
-    if (neox || hd % 2 || getenv("PI_NO_ROPE_EPILOGUE")) return 0;
+    static const bool off = getenv("PI_NO_ROPE_EPILOGUE") != nullptr;      // tests: read once, not per call
+    if (neox || hd % 2 || off) return 0;
     const pi_weight * w[3] = { wq, wk, wv };
     for (int i = 0; i < 3; i++) if (pi_vec_dot_type(w[i]->type) != PI_Q8_K || w[i]->ne1 % 2 || w[i]->ne0 != wq->ne0) return 0;
     return 1;

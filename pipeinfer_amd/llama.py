@@ -162,6 +162,9 @@ class Model:
         raw = text.encode("utf-8")
         buf = (C.c_int32 * (len(raw) + 8))()
         n = self.lib.llama_tokenize(self.h, raw, len(raw), buf, len(buf), add_bos, special)
+        if n < 0:                                    # -n = tokens needed (byte fallback can take several tokens per character), like common.cpp:1086-1094
+            buf = (C.c_int32 * (-n))()
+            n = self.lib.llama_tokenize(self.h, raw, len(raw), buf, len(buf), add_bos, special)
         assert n >= 0
         return list(buf[:n])
 

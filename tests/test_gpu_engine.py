@@ -257,6 +257,22 @@ def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_lay
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("workload,n_predict", [("7b", 48), ("70b-l4", 48)])
+def test_every_run_equals_the_oracle_at_full_size_shapes(workload, n_predict):
+    """the same per-run comparison at the shapes of BASELINE's configurations: the whole Llama-2-7B Q4_K_M (K = 4096 / 11008, 32 layers), and
+    Llama-2-70B shapes (GQA 64/8, K = 8192 / 28672: the tile-per-wave decode instances, the matrix-core kernel on verify batches and prompt
+    chunks) cut to four layers so that the CPU oracle keeps up.  Every run the driver launches — prompt batches, single tokens, speculative
+    batches, accepted or cancelled — must give the oracle's logits bit for bit on the cells it was given."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "trace_compare_worker.py"), workload, "0.02", str(n_predict)], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
+    spec_runs = int(r.stdout.split("TRACE-PARITY OK spec_runs")[1].split()[0])
+    assert spec_runs > 0, r.stdout[-1500:]                       # speculative batches were among the runs that were compared
+
+
 def test_full_size_properties_llama_7b(LL, tmp_path_factory):
     """BASELINE's single-GPU target at full size (Llama-2-7B shapes, Q4_K_M mixture, 4.1 GB of synthetic weights): properties that
     need no oracle run — a k-token batch gives the same bits as the same tokens decoded one by one (cells contiguous in both), a
@@ -337,7 +353,7 @@ def test_reference_driver_binary_runs_on_the_engine(LL, tmp_path):
     m.free()
     r = subprocess.run([exe, "-m", os.path.join(GOLD, tgt + ".gguf"), "-md", os.path.join(GOLD, dft + ".gguf"), "-p", text, "-n", str(n_gen), "-c", "256", "-b", "64",
                         "--draft", "3", "-np", "3", "-pa", "0.05", "-ps", "0.9", "-pr", "0.0", "--temp", "0", "--repeat-last-n", "0", "--mpi-layer-split", "1.0/1.0",
-                        "-t", "1", "-tb", "1", "--log-disable"], capture_output=True, timeout=600, cwd=str(tmp_path))
+                        "-t", "1", "-tb", "1"], capture_output=True, timeout=600, cwd=str(tmp_path))     # its log file goes to cwd
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.startswith(want_text[:len(r.stdout)]) and len(r.stdout) >= len(want_text) - 8, (r.stdout, want_text)
     assert b"n_drafted" in r.stderr and b"n_accept" in r.stderr, r.stderr[-1500:]

@@ -19,10 +19,16 @@ if ":" in wl:
     tgt_path, dft_path, nl = wl.split(":")
     N_LAYER, N_CTX, N_PROMPT = int(nl), 256, 8
 else:
+    # "70b-l4": Llama-2-70B shapes (GQA 64/8, K = 8192 / 28672) cut to 4 layers with the tensor types of layers 8..11, so that the CPU oracle
+    # follows every run of a generation in about a minute; "7b" / "70b": the whole models
+    cut = None
+    if "-l" in wl:
+        wl, nl = wl.split("-l"); cut = (8, int(nl))
     tspec, tft, dspec, dft = B.WORKLOADS[wl]
-    tgt_path = B.ensure_model("/tmp/pipeinfer_models", tspec, tft, 0x5EED, 1.0, 0.8)
-    dft_path = B.ensure_model("/tmp/pipeinfer_models", dspec, dft, 0xD4AF, 1.0, 0.8)
-    N_LAYER, N_CTX, N_PROMPT = {"7b": 32, "tiny": 3, "70b": 80}[wl], 1024, 32
+    cache = os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models")
+    tgt_path = B.ensure_model(cache, tspec, tft, 0x5EED, 1.0, 0.8, layers=cut)
+    dft_path = B.ensure_model(cache, dspec, dft, 0xD4AF, 1.0, 0.8)
+    N_LAYER, N_CTX, N_PROMPT = (cut[1] if cut else {"7b": 32, "tiny": 3, "70b": 80}[wl]), 1024, 32
 o = O.oracle()
 o.o_set_threads(int(os.environ.get("ORACLE_THREADS", "64")))
 oh = o.o_model_load(tgt_path.encode(), N_CTX, 8)
