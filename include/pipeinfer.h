@@ -40,8 +40,8 @@ LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
  * the HEAD process owns the driver and the KV-cell bookkeeping of the target context; it ships one metadata block per run
  *     int32 tokens[n] | int32 pos[n] | int32 {kv_head, n_kv, n_tokens, 0} | uint32 mask[n][ceil(n_ctx/32)]
  * through `start`; STAGE processes own layer ranges and run pipeinfer_stage_run on that block, passing activations
- * [n_tokens][n_embd] fp32 from stage to stage (RCCL send/recv in pipeinfer_amd/pipeline.py).  The transport lives outside
- * this library: the callbacks below are all it needs. */
+ * [n_tokens][n_embd] fp32 from stage to stage.  Any transport can sit behind the callbacks below; the library's own (shared-memory rings +
+ * peer stores, see pipeinfer_transport_* further down) is what pipeinfer_amd/pipeline.py and bench.py --gpus N use. */
 struct pipeinfer_remote_ops {
     void * user;
     int  (*start)(void * user, int32_t run_seq, int32_t batch_id, int32_t n_tokens, const void * meta, size_t meta_bytes);
@@ -60,6 +60,50 @@ LLAMA_API void pipeinfer_split_layers(int32_t n_layer, const float * weights, in
  * stage fills the host buffers.  Returns after the stage's stream is idle. */
 LLAMA_API int  pipeinfer_stage_run(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
                                    float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum);
+
+/* pipeinfer_stage_run for a segmented stage context (pipeinfer_context_set_segments): should_abort(user) is asked before every segment after
+ * the first; when it answers 1 the rest of the run is dropped and the call returns 1 (nothing is written to x_out / the host buffers). */
+LLAMA_API int  pipeinfer_stage_run_abortable(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
+                                             float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void * user), void * user);
+
+/* ---- in-library transport of a one-node pipeline (csrc/engine/transport.cpp) ------------------------------------------------------------
+ * rank 0 = head (driver + proxy target context), ranks 1..world-1 = target stages in layer order.  One POSIX shared-memory segment per
+ * job carries the run metadata table, the header rings, the cancel table and the result ring; activations travel as peer stores into a
+ * ring in the next stage's HBM (hipIpc), or through rings in the segment when `device` < 0 or the peer mapping is not available.
+ * Replaces ggml_mpi_sync_pipelined / ggml_mpi_sync_pipelined_back / ggml_mpi_cancel_run (ggml-mpi.c:186-310) for the speculative path. */
+typedef struct pipeinfer_transport pipeinfer_transport;
+struct pipeinfer_transport_params {
+    const char * name;           /* shared-memory name, unique per job (every rank passes the same) */
+    int32_t rank, world;
+    int32_t n_embd, n_vocab;     /* of the target model */
+    int32_t n_batch, n_ctx;      /* of the target contexts (sizes of the metadata blocks, activation and result slots) */
+    int32_t device;              /* HIP device of this process, or -1: activations in host memory (processes without a GPU) */
+    int32_t timeout_ms;          /* set-up and result waits (0: 120 s) */
+};
+struct pipeinfer_transport_stats {
+    uint64_t runs, skipped, cut_short, cancel_notes;   /* stage: computed / forwarded as skipped / stopped between segments / notes seen; head: started / skipped / - / notes written */
+    double   wait_in_ms, compute_ms, send_ms;          /* stage: waiting for a header, inside the backend, in the hop to the next stage */
+};
+/* stage compute behind the transport when it is not a llama_context of this library (the CPU tests plug the oracle in here):
+ * 0 = computed, 1 = dropped, < 0 error; x_in / x_out are host pointers when the transport runs on host rings */
+struct pipeinfer_stage_backend {
+    void * user;
+    int (*run)(void * user, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
+               float * logits, int32_t * topk_ids, float * topk_vals, float * topk_sum);
+};
+/* collective over the job's ranks: returns when every rank has joined and the activation path has been agreed on; NULL on failure */
+LLAMA_API pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer_transport_params * params);
+LLAMA_API void pipeinfer_transport_close(pipeinfer_transport * tp);
+LLAMA_API const char * pipeinfer_transport_error(pipeinfer_transport * tp);
+LLAMA_API int  pipeinfer_transport_device_mode(pipeinfer_transport * tp);          /* 1: peer stores into HBM rings, 0: host rings */
+/* rank 0: makes ctx the head-side proxy of the pipeline (pipeinfer_context_set_remote with the transport's own callbacks) */
+LLAMA_API int  pipeinfer_transport_attach_head(pipeinfer_transport * tp, struct llama_context * ctx);
+/* rank 0, once every started run has been waited for: ends the stages' serve loops */
+LLAMA_API int  pipeinfer_transport_shutdown(pipeinfer_transport * tp);
+LLAMA_API void pipeinfer_transport_get_stats(pipeinfer_transport * tp, struct pipeinfer_transport_stats * out);      /* head-side counters */
+/* ranks >= 1: serves runs until the head shuts the pipeline down.  Compute = pipeinfer_stage_run_abortable on stage_ctx (backend NULL),
+ * or the backend's run().  A sender thread overlaps each hop with the next run's compute. */
+LLAMA_API int  pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_context * stage_ctx, const struct pipeinfer_stage_backend * backend, struct pipeinfer_transport_stats * out);
 
 LLAMA_API int  pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp);
 

@@ -275,7 +275,7 @@ static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, 
               hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok && x_in) ok = hipMemcpyAsync(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (ok && x_in) ok = hipMemcpyAsync(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;      // device (peer ring) or host (staged transport)
     if (!ok) ctx->last_error = "H2D of batch metadata failed";
     return ok;
 }
@@ -504,20 +504,39 @@ bool context_wait(llama_context * ctx, pi_run * run) {
 // One run on a pipeline stage (a process that owns layers [l0, l1)).  Mirrors the worker side of llama_decode_internal
 // (llama.cpp:5588-5760): receive activations, compute the local graph, hand the result on; here the transport is the caller's.
 int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
-              float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum) {
+              float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void *), void * abort_user) {
     std::string err;
     if (!context_prepare(ctx, err)) { ctx->last_error = err; return -1; }
     const int words = (ctx->n_ctx + 31) / 32;
     if (n_tokens <= 0 || n_tokens > ctx->n_batch || meta_bytes < (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4) { ctx->last_error = "stage_run: bad metadata block"; return -1; }
     if (!ctx->is_first && !x_in) { ctx->last_error = "stage_run: activations missing"; return -1; }
+    hipStream_t s = ctx->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
-    (void) hipEventRecord(e0, ctx->stream);
-    bool ok = launch_forward(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in, nullptr);
-    hipStream_t s = ctx->stream;
+    (void) hipEventRecord(e0, s);
+    // With an abort callback and a segmented context (pipeinfer_context_set_segments) the calling thread plays the feeder: segments go
+    // out at most two ahead of the GPU and the callback is asked before each — a run cancelled by the head while this stage computes it
+    // stops at the next segment boundary (the reference's workers poll for the cancel message between graph nodes, llama.cpp:5665-5687).
+    bool ok = true, cut = false;
+    const int nseg = n_segments(ctx);
+    if (should_abort && nseg > 1) {
+        if (!ctx->seg_events[0]) ok = hipEventCreateWithFlags(&ctx->seg_events[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->seg_events[1], hipEventDisableTiming) == hipSuccess;
+        const int kv_head = ((const int32_t *) meta)[2 * n_tokens];
+        if (ok) ok = launch_inputs(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in);
+        int seg = 0;
+        for (; ok && seg < nseg; seg++) {
+            if (seg >= 2) (void) hipEventSynchronize(ctx->seg_events[seg & 1]);
+            if (seg > 0 && should_abort(abort_user)) { cut = true; break; }
+            ok = launch_segment(ctx, n_tokens, kv_head, seg, nullptr);
+            if (ok) ok = hipEventRecord(ctx->seg_events[seg & 1], s) == hipSuccess;
+        }
+        ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
+    } else {
+        ok = launch_forward(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in, nullptr);
+    }
     const size_t nv = ctx->model->hparams.n_vocab;
-    if (ok && !ctx->is_last) ok = hipMemcpyAsync(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDeviceToDevice, s) == hipSuccess;
-    if (ok && ctx->is_last)
+    if (ok && !cut && !ctx->is_last) ok = hipMemcpyAsync(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;
+    if (ok && !cut && ctx->is_last)
         ok = hipMemcpyAsync(logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipMemcpyAsync(topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipMemcpyAsync(topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -525,9 +544,10 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     (void) hipEventRecord(e1, s);
     if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
     float ms = 0.0f;
-    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n_tokens == 1) ctx->stat_gpu_ms_1 += ms; }
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n_tokens == 1 && !cut) ctx->stat_gpu_ms_1 += ms; }
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "stage_run failed"; return -1; }
+    if (cut) return 1;
     const int32_t * h_dyn = (const int32_t *) meta + 2 * n_tokens;
     ctx->stat_calls++;
     ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, h_dyn[1]);

@@ -148,6 +148,7 @@ int  context_finish(llama_context * ctx, pi_run * run);
 bool context_poll_oldest(llama_context * ctx);
 bool context_wait(llama_context * ctx, pi_run * run);                    // blocks until the run's results are in host memory
 int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
-               float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum);
+               float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
+               int (*should_abort)(void *) = nullptr, void * abort_user = nullptr);        // 0 done, 1 cut short by should_abort, < 0 error
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

@@ -287,6 +287,10 @@ extern "C" void pipeinfer_split_layers(int32_t n_layer, const float * weights, i
     }
 }
 
+extern "C" int pipeinfer_stage_run_abortable(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
+                                             float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void *), void * user) {
+    return pi::stage_run(ctx, n_tokens, meta, meta_bytes, x_in_dev, x_out_dev, logits_host, topk_ids, topk_vals, topk_sum, should_abort, user);
+}
 extern "C" int pipeinfer_stage_run(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
                                    float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum) {
     return pi::stage_run(ctx, n_tokens, meta, meta_bytes, x_in_dev, x_out_dev, logits_host, topk_ids, topk_vals, topk_sum);

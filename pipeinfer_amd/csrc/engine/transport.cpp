@@ -1,0 +1,451 @@
+// Stage-to-stage transport of a one-node pipeline, inside the library (include/pipeinfer.h, "in-library transport").
+//
+// Replaces, for the speculative hot path, the reference's MPI message plumbing (ggml-mpi.c:186-310 ggml_mpi_sync_pipelined[_back]:
+// per run one message of tokens / positions / sequence ids per hop, then the activations, then the logits back to rank 0;
+// llama.cpp:9981-9993 llama_cancel_run -> ggml_mpi_cancel_run: one small message to every worker) with what one node of MI355X offers:
+//
+//   * run METADATA is not forwarded hop by hop: the head writes each run's block once into a table in a POSIX shared-memory segment
+//     that every stage maps; what travels from stage to stage is a 32-byte header in a single-producer/single-consumer ring;
+//   * ACTIVATIONS [n_tokens][n_embd] fp32 are stored by the producing stage straight into a ring in the consuming stage's HBM
+//     (hipIpc memory handle opened once; one device-to-device copy over xGMI per hop on the producer's copy stream).  The consumer
+//     never posts a receive: slot k of its ring is free as soon as it has consumed header k, so the next run's activations arrive
+//     while it still computes the current one, and a sender thread per stage overlaps the hop with the next run's compute;
+//   * LOGITS + the device top-8 of the last stage go into a result ring in the shared segment (D2H straight into the slot);
+//   * CANCEL notes are entries of one shared append-only table — no message per stage; a stage looks at it before a run and,
+//     through pipeinfer_stage_run_abortable, between the segments of the run it is computing.
+//
+// If the peer mapping cannot be set up (or the probe block does not arrive intact) every rank falls back, together, to activation
+// rings in the shared segment (D2H + H2D per hop); processes without a GPU (the CPU tests, with the oracle as the stage backend) use
+// the same host rings.  Nothing here is a collective: the exchange is point-to-point, one hop per stage boundary per run.
+#include "engine.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <unordered_set>
+
+namespace {
+
+constexpr uint32_t TP_MAGIC = 0x54504950u;       // "PIPT"
+constexpr int TP_MAX_WORLD = 64;
+constexpr int TP_RUN_TABLE = 256;                // metadata blocks of runs in flight (started, result not yet consumed)
+constexpr int TP_IN1_SLOTS = 256;                // headers the head may queue at the first stage (no activations attached)
+constexpr int TP_X_SLOTS = 4;                    // activation slots per stage boundary
+constexpr int TP_RES_SLOTS = 4;                  // result slots (last stage -> head)
+constexpr int TP_CANCEL_CAP = 8192;
+enum { KIND_RUN = 1, KIND_SHUTDOWN = 2 };
+enum { F_SKIPPED = 1 };
+
+struct alignas(64) ring_ctl {
+    std::atomic<uint64_t> head;                  // messages produced
+    char pad0[56];
+    std::atomic<uint64_t> tail;                  // messages consumed
+    char pad1[56];
+};
+struct msg_hdr { int32_t kind, run_seq, batch_id, n_tokens, flags, gen, pad0, pad1; };
+
+struct stage_block {                             // index = rank
+    ring_ctl in;                                 // producer: rank - 1 (the head for rank 1); consumer: rank
+    msg_hdr slots[TP_IN1_SLOTS];                 // ranks >= 2 use the first TP_X_SLOTS
+    std::atomic<uint32_t> ipc_ready, probe_written, joined, setup_done;
+    char ipc_handle[64];                         // hipIpcMemHandle_t
+};
+struct shm_layout {
+    std::atomic<uint32_t> magic;
+    int32_t world, n_embd, n_vocab, n_batch, n_ctx;
+    uint64_t meta_stride, x_slot_bytes, res_slot_bytes, off_meta, off_x, off_res, total;
+    std::atomic<int32_t> fatal;                  // any rank sets it: every wait gives up
+    std::atomic<int32_t> device_fail;            // the peer-store path is unusable on this node: host rings for everybody
+    std::atomic<uint64_t> n_cancel;
+    std::atomic<uint64_t> cancel[TP_CANCEL_CAP]; // (generation << 32) | batch id
+    ring_ctl res;
+    stage_block st[TP_MAX_WORLD];
+};
+static_assert(sizeof(hipIpcMemHandle_t) <= 64, "hipIpcMemHandle_t does not fit its slot");
+
+int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+struct pipeinfer_transport {
+    std::string name, error;
+    int rank = 0, world = 0, n_embd = 0, n_vocab = 0, n_batch = 0, n_ctx = 0, device = -1, timeout_ms = 120000;
+    bool creator = false, device_mode = false;
+    uint8_t * base = nullptr; size_t total = 0;
+    shm_layout * L = nullptr;
+    // stage side
+    float * my_ring = nullptr;                   // device mode: this stage's activation ring in its HBM (ranks >= 2)
+    float * peer_ring = nullptr;                 // device mode: the next stage's ring, mapped through hipIpc
+    hipStream_t copy_stream = nullptr;
+    bool res_registered = false;
+    // head side
+    int32_t gen = 0;
+    uint64_t started = 0, consumed = 0;
+    pipeinfer_transport_stats head_stats{};
+    // cancel view of a stage (compute thread only)
+    uint64_t cancel_cursor = 0; std::unordered_set<uint64_t> cancelled; uint64_t cur_key = ~0ull;
+
+    bool fail(const std::string & what) {
+        error = what;
+        fprintf(stderr, "[pipeinfer transport, rank %d] %s\n", rank, what.c_str());
+        if (L) L->fatal.store(1);
+        return false;
+    }
+    // spins, then sleeps in 50 us steps; false on timeout (timeout_ms < 0: none) or when any rank has declared the pipeline dead
+    template <class F> bool wait_for(F pred, int tmo_ms) {
+        for (int i = 0; i < 4000; i++) { if (pred()) return true; __builtin_ia32_pause(); }
+        const int64_t t0 = now_us();
+        while (true) {
+            if (pred()) return true;
+            if (L->fatal.load(std::memory_order_relaxed)) return false;
+            if (tmo_ms >= 0 && now_us() - t0 > (int64_t) tmo_ms * 1000) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    int in_cap(int r) const { return r == 1 ? TP_IN1_SLOTS : TP_X_SLOTS; }
+    uint8_t * meta_of(int32_t run_seq) const { return base + L->off_meta + (size_t) ((uint32_t) run_seq % TP_RUN_TABLE) * L->meta_stride; }
+    float * host_x_slot(int r, uint64_t k) const { return (float *) (base + L->off_x + ((size_t) (r - 2) * TP_X_SLOTS + k % TP_X_SLOTS) * L->x_slot_bytes); }
+    uint8_t * res_slot(uint64_t k) const { return base + L->off_res + (size_t) (k % TP_RES_SLOTS) * L->res_slot_bytes; }
+    // fixed offsets inside a result slot, sized for n_batch tokens
+    int32_t * res_ids(uint8_t * s) const { return (int32_t *) (s + 64); }
+    float * res_vals(uint8_t * s) const { return (float *) (s + 64 + (size_t) n_batch * 32); }
+    float * res_sums(uint8_t * s) const { return (float *) (s + 64 + (size_t) n_batch * 64); }
+    float * res_logits(uint8_t * s) const { return (float *) (s + 64 + (size_t) n_batch * 68); }
+
+    void scan_cancels() {
+        const uint64_t n = L->n_cancel.load(std::memory_order_acquire);
+        for (; cancel_cursor < n; cancel_cursor++) cancelled.insert(L->cancel[cancel_cursor % TP_CANCEL_CAP].load(std::memory_order_relaxed));
+    }
+    bool is_cancelled(int32_t g, int32_t batch_id) { scan_cancels(); return cancelled.count(((uint64_t) (uint32_t) g << 32) | (uint32_t) batch_id) > 0; }
+};
+
+namespace {
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool map_segment(pipeinfer_transport * tp, const pipeinfer_transport_params & P) {
+    const size_t words = (size_t) (P.n_ctx + 31) / 32;
+    const size_t meta_stride = round_up((size_t) P.n_batch * 8 + 16 + (size_t) P.n_batch * words * 4, 64);
+    const size_t x_slot = round_up((size_t) P.n_batch * P.n_embd * 4, 4096);
+    const size_t res_slot = round_up(64 + (size_t) P.n_batch * (68 + (size_t) P.n_vocab * 4), 4096);
+    const size_t off_meta = round_up(sizeof(shm_layout), 4096);
+    const size_t off_x = off_meta + round_up(meta_stride * TP_RUN_TABLE, 4096);
+    const size_t off_res = off_x + x_slot * TP_X_SLOTS * (size_t) std::max(0, P.world - 2);
+    const size_t total = off_res + res_slot * TP_RES_SLOTS;
+    int fd = -1;
+    if (tp->rank == 0) {
+        (void) shm_unlink(tp->name.c_str());
+        fd = shm_open(tp->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return tp->fail("shm_open(create " + tp->name + ") failed: " + strerror(errno));
+        if (ftruncate(fd, (off_t) total) != 0) { close(fd); return tp->fail(std::string("ftruncate of the shared segment failed: ") + strerror(errno)); }
+        tp->creator = true;
+    } else {
+        const int64_t t0 = now_us();
+        while (true) {
+            fd = shm_open(tp->name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t) sb.st_size >= total) break;      // pages are sparse: the size appears with the creator's ftruncate
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (now_us() - t0 > (int64_t) tp->timeout_ms * 1000) return tp->fail("the head's shared segment " + tp->name + " did not appear");
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    void * m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return tp->fail(std::string("mmap of the shared segment failed: ") + strerror(errno));
+    tp->base = (uint8_t *) m; tp->total = total; tp->L = (shm_layout *) m;
+    shm_layout * L = tp->L;
+    if (tp->rank == 0) {
+        L->world = P.world; L->n_embd = P.n_embd; L->n_vocab = P.n_vocab; L->n_batch = P.n_batch; L->n_ctx = P.n_ctx;
+        L->meta_stride = meta_stride; L->x_slot_bytes = x_slot; L->res_slot_bytes = res_slot; L->off_meta = off_meta; L->off_x = off_x; L->off_res = off_res; L->total = total;
+        L->magic.store(TP_MAGIC, std::memory_order_release);
+    } else {
+        const int64_t t0 = now_us();
+        while (L->magic.load(std::memory_order_acquire) != TP_MAGIC) {
+            if (now_us() - t0 > (int64_t) tp->timeout_ms * 1000) return tp->fail("the shared segment was never initialised by the head");
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (L->world != P.world || L->n_embd != P.n_embd || L->n_vocab != P.n_vocab || L->n_batch != P.n_batch || L->n_ctx != P.n_ctx || L->total != total)
+            return tp->fail("this rank's transport parameters differ from the head's");
+    }
+    return true;
+}
+
+// peer-store path: ranks >= 2 export a ring in their HBM, their upstream neighbour maps it and sends a probe block through it
+void setup_device_rings(pipeinfer_transport * tp) {
+    shm_layout * L = tp->L;
+    const int r = tp->rank, W = tp->world;
+    auto bad = [&](const char * what, hipError_t e) { fprintf(stderr, "[pipeinfer transport, rank %d] %s: %s — activations will be staged through host memory\n", r, what, hipGetErrorString(e)); L->device_fail.store(1); };
+    hipError_t e = hipSetDevice(tp->device);
+    if (e != hipSuccess) { bad("hipSetDevice", e); return; }
+    if (r >= 1 && (e = hipStreamCreateWithFlags(&tp->copy_stream, hipStreamNonBlocking)) != hipSuccess) { bad("hipStreamCreate", e); return; }
+    if (r >= 2) {
+        hipIpcMemHandle_t h;
+        if ((e = hipMalloc((void **) &tp->my_ring, L->x_slot_bytes * TP_X_SLOTS)) != hipSuccess) { bad("hipMalloc of the activation ring", e); tp->my_ring = nullptr; }
+        else if ((e = hipMemset(tp->my_ring, 0, L->x_slot_bytes * TP_X_SLOTS)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) bad("hipMemset of the activation ring", e);
+        else if ((e = hipIpcGetMemHandle(&h, tp->my_ring)) != hipSuccess) bad("hipIpcGetMemHandle", e);
+        else memcpy(L->st[r].ipc_handle, &h, sizeof h);
+        L->st[r].ipc_ready.store(1, std::memory_order_release);                 // (also on failure: the neighbour must not wait for it)
+    }
+    if (r >= 1 && r + 1 < W) {                                                  // map the next stage's ring and write the probe block
+        if (!tp->wait_for([&] { return L->st[r + 1].ipc_ready.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) L->device_fail.store(1);
+        if (!L->device_fail.load()) {
+            hipIpcMemHandle_t h; memcpy(&h, L->st[r + 1].ipc_handle, sizeof h);
+            if ((e = hipIpcOpenMemHandle((void **) &tp->peer_ring, h, hipIpcMemLazyEnablePeerAccess)) != hipSuccess) { bad("hipIpcOpenMemHandle", e); tp->peer_ring = nullptr; }
+            else {
+                float probe[256];
+                for (int i = 0; i < 256; i++) probe[i] = (float) (r * 1000 + i);
+                if ((e = hipMemcpyAsync(tp->peer_ring, probe, sizeof probe, hipMemcpyHostToDevice, tp->copy_stream)) != hipSuccess || (e = hipStreamSynchronize(tp->copy_stream)) != hipSuccess) bad("probe store into the next stage's ring", e);
+            }
+        }
+        L->st[r + 1].probe_written.store(1, std::memory_order_release);
+    }
+    if (r >= 2) {
+        if (!tp->wait_for([&] { return L->st[r].probe_written.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) L->device_fail.store(1);
+        if (!L->device_fail.load() && tp->my_ring) {
+            float got[256];
+            if ((e = hipMemcpy(got, tp->my_ring, sizeof got, hipMemcpyDeviceToHost)) != hipSuccess) bad("read-back of the probe block", e);
+            else for (int i = 0; i < 256; i++) if (got[i] != (float) ((r - 1) * 1000 + i)) { fprintf(stderr, "[pipeinfer transport, rank %d] the probe block did not arrive intact in the peer-mapped ring\n", r); L->device_fail.store(1); break; }
+        }
+    }
+}
+
+// ---- head side: struct pipeinfer_remote_ops over the shared rings -------------------------------------------------------------------------
+int head_start(void * user, int32_t run_seq, int32_t batch_id, int32_t n_tokens, const void * meta, size_t meta_bytes) {
+    pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    shm_layout * L = tp->L;
+    if (meta_bytes > L->meta_stride || n_tokens > tp->n_batch) { tp->fail("run metadata larger than the transport was opened for (n_batch / n_ctx)"); return -1; }
+    ring_ctl & in = L->st[1].in;
+    const uint64_t h = in.head.load(std::memory_order_relaxed);
+    if (tp->started - tp->consumed >= (uint64_t) TP_RUN_TABLE || h - in.tail.load(std::memory_order_acquire) >= (uint64_t) TP_IN1_SLOTS) {
+        tp->fail("more than " + std::to_string(TP_RUN_TABLE) + " runs in flight: the driver never waits for its oldest run"); return -1;
+    }
+    memcpy(tp->meta_of(run_seq), meta, meta_bytes);
+    msg_hdr & m = L->st[1].slots[h % TP_IN1_SLOTS];
+    m.kind = KIND_RUN; m.run_seq = run_seq; m.batch_id = batch_id; m.n_tokens = n_tokens; m.flags = 0; m.gen = tp->gen;
+    in.head.store(h + 1, std::memory_order_release);
+    tp->started++;
+    tp->head_stats.runs++;
+    return 0;
+}
+int head_poll(void * user) {
+    pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    return tp->L->res.head.load(std::memory_order_acquire) > tp->L->res.tail.load(std::memory_order_relaxed) ? 1 : 0;
+}
+int head_wait(void * user, int32_t run_seq, float * logits, int32_t * ids, float * vals, float * sums) {
+    pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    shm_layout * L = tp->L;
+    const uint64_t t = L->res.tail.load(std::memory_order_relaxed);
+    const int64_t t0 = now_us();
+    if (!tp->wait_for([&] { return L->res.head.load(std::memory_order_acquire) > t; }, tp->timeout_ms)) { tp->fail("no result for run " + std::to_string(run_seq) + " (a stage died or timed out)"); return -1; }
+    tp->head_stats.wait_in_ms += (now_us() - t0) / 1e3;
+    uint8_t * s = tp->res_slot(t);
+    const msg_hdr m = *(const msg_hdr *) s;
+    if (m.run_seq != run_seq) { tp->fail("result of run " + std::to_string(m.run_seq) + " while waiting for " + std::to_string(run_seq)); return -1; }
+    const bool computed = !(m.flags & F_SKIPPED);
+    if (computed) {
+        const size_t n = (size_t) m.n_tokens;
+        memcpy(ids, tp->res_ids(s), n * 32); memcpy(vals, tp->res_vals(s), n * 32); memcpy(sums, tp->res_sums(s), n * 4);
+        memcpy(logits, tp->res_logits(s), n * (size_t) tp->n_vocab * 4);
+    } else tp->head_stats.skipped++;
+    L->res.tail.store(t + 1, std::memory_order_release);
+    tp->consumed++;
+    return computed ? 1 : 0;
+}
+void head_cancel(void * user, int32_t batch_id) {
+    pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    if (batch_id == -2) { tp->gen++; return; }                                  // a new generation: batch ids restart
+    shm_layout * L = tp->L;
+    const uint64_t n = L->n_cancel.load(std::memory_order_relaxed);
+    L->cancel[n % TP_CANCEL_CAP].store(((uint64_t) (uint32_t) tp->gen << 32) | (uint32_t) batch_id, std::memory_order_relaxed);
+    L->n_cancel.store(n + 1, std::memory_order_release);
+    tp->head_stats.cancel_notes++;
+}
+
+int abort_probe(void * user) {                                                  // between the segments of the run a stage is computing
+    pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    tp->scan_cancels();
+    return tp->cancelled.count(tp->cur_key) > 0 ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer_transport_params * P) {
+    if (!P || !P->name || P->world < 2 || P->world > TP_MAX_WORLD || P->rank < 0 || P->rank >= P->world || P->n_batch <= 0 || P->n_embd <= 0 || P->n_vocab <= 0 || P->n_ctx <= 0) {
+        fprintf(stderr, "pipeinfer_transport_open: bad parameters\n"); return nullptr;
+    }
+    pipeinfer_transport * tp = new pipeinfer_transport();
+    tp->name = P->name[0] == '/' ? P->name : std::string("/") + P->name;
+    tp->rank = P->rank; tp->world = P->world; tp->n_embd = P->n_embd; tp->n_vocab = P->n_vocab; tp->n_batch = P->n_batch; tp->n_ctx = P->n_ctx;
+    tp->device = P->device; if (P->timeout_ms > 0) tp->timeout_ms = P->timeout_ms;
+    if (!map_segment(tp, *P)) { pipeinfer_transport_close(tp); return nullptr; }
+    shm_layout * L = tp->L;
+    if (P->device < 0) L->device_fail.store(1);                                 // a rank without a GPU: host rings for everybody
+    L->st[tp->rank].joined.store(1, std::memory_order_release);
+    for (int r = 0; r < tp->world; r++)
+        if (!tp->wait_for([&] { return L->st[r].joined.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never joined the transport"); pipeinfer_transport_close(tp); return nullptr; }
+    if (tp->creator) (void) shm_unlink(tp->name.c_str());                       // everybody has it mapped: the name can go (nothing is left behind after a crash)
+    if (!L->device_fail.load() && P->device >= 0) setup_device_rings(tp);
+    L->st[tp->rank].setup_done.store(1, std::memory_order_release);
+    for (int r = 0; r < tp->world; r++)
+        if (!tp->wait_for([&] { return L->st[r].setup_done.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never finished the transport set-up"); pipeinfer_transport_close(tp); return nullptr; }
+    tp->device_mode = P->device >= 0 && !L->device_fail.load();
+    if (P->device >= 0 && tp->rank == tp->world - 1) {                          // the last stage copies D2H straight into the result slots: pin them
+        if (hipSetDevice(P->device) == hipSuccess && hipHostRegister(tp->base + L->off_res, L->res_slot_bytes * TP_RES_SLOTS, hipHostRegisterDefault) == hipSuccess) tp->res_registered = true;
+        else (void) hipGetLastError();
+    }
+    return tp;
+}
+
+extern "C" void pipeinfer_transport_close(pipeinfer_transport * tp) {
+    if (!tp) return;
+    if (tp->res_registered) (void) hipHostUnregister(tp->base + tp->L->off_res);
+    if (tp->peer_ring) (void) hipIpcCloseMemHandle(tp->peer_ring);
+    if (tp->my_ring) (void) hipFree(tp->my_ring);
+    if (tp->copy_stream) (void) hipStreamDestroy(tp->copy_stream);
+    if (tp->creator && tp->L && !tp->L->st[tp->world - 1].joined.load()) (void) shm_unlink(tp->name.c_str());
+    if (tp->base) munmap(tp->base, tp->total);
+    delete tp;
+}
+
+extern "C" const char * pipeinfer_transport_error(pipeinfer_transport * tp) { return tp ? tp->error.c_str() : "no transport"; }
+extern "C" int pipeinfer_transport_device_mode(pipeinfer_transport * tp) { return tp && tp->device_mode ? 1 : 0; }
+
+extern "C" int pipeinfer_transport_attach_head(pipeinfer_transport * tp, struct llama_context * ctx) {
+    if (!tp || !ctx || tp->rank != 0) return -1;
+    pipeinfer_remote_ops ops{};
+    ops.user = tp; ops.start = head_start; ops.poll = head_poll; ops.wait = head_wait; ops.cancel = head_cancel;
+    pipeinfer_context_set_remote(ctx, &ops);
+    return 0;
+}
+
+extern "C" int pipeinfer_transport_shutdown(pipeinfer_transport * tp) {
+    if (!tp || tp->rank != 0) return -1;
+    if (tp->started != tp->consumed) { tp->fail("shutdown with runs still in flight"); return -1; }
+    shm_layout * L = tp->L;
+    ring_ctl & in = L->st[1].in;
+    const uint64_t h = in.head.load(std::memory_order_relaxed);
+    if (!tp->wait_for([&] { return h - in.tail.load(std::memory_order_acquire) < (uint64_t) TP_IN1_SLOTS; }, tp->timeout_ms)) return -1;
+    msg_hdr & m = L->st[1].slots[h % TP_IN1_SLOTS];
+    memset(&m, 0, sizeof m); m.kind = KIND_SHUTDOWN;
+    in.head.store(h + 1, std::memory_order_release);
+    return 0;
+}
+
+extern "C" void pipeinfer_transport_get_stats(pipeinfer_transport * tp, struct pipeinfer_transport_stats * out) { if (tp && out) *out = tp->head_stats; }
+
+// ---- stage side -----------------------------------------------------------------------------------------------------------------------------
+extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_context * ctx, const struct pipeinfer_stage_backend * backend, struct pipeinfer_transport_stats * out) {
+    if (!tp || tp->rank < 1 || (!ctx && !backend)) return -1;
+    shm_layout * L = tp->L;
+    const int r = tp->rank;
+    const bool is_first = r == 1, is_last = r == tp->world - 1, dev = tp->device_mode;
+    pipeinfer_transport_stats st{};
+    if (dev && hipSetDevice(tp->device) != hipSuccess) { tp->fail("hipSetDevice failed"); return -1; }
+
+    // outgoing activations: two local buffers, so that the hop of run k overlaps the compute of run k + 1
+    float * x_out[2] = { nullptr, nullptr };
+    const size_t xb = L->x_slot_bytes;
+    if (!is_last) for (int i = 0; i < 2; i++) {
+        if (dev) { if (hipMalloc((void **) &x_out[i], xb) != hipSuccess) { tp->fail("hipMalloc of the outgoing activation buffer failed"); return -1; } }
+        else x_out[i] = (float *) malloc(xb);
+    }
+    struct out_msg { msg_hdr h; int buf; };
+    std::mutex mu; std::condition_variable cv;
+    std::deque<out_msg> outq; int buf_busy[2] = { 0, 0 }; bool sender_failed = false;
+    std::thread sender;
+    if (!is_last) sender = std::thread([&] {
+        if (dev) (void) hipSetDevice(tp->device);
+        ring_ctl & nx = L->st[r + 1].in;
+        while (true) {
+            out_msg m;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !outq.empty(); }); m = outq.front(); outq.pop_front(); }
+            const uint64_t h = nx.head.load(std::memory_order_relaxed);
+            const int64_t t0 = now_us();
+            if (!tp->wait_for([&] { return h - nx.tail.load(std::memory_order_acquire) < (uint64_t) TP_X_SLOTS; }, -1)) { std::lock_guard<std::mutex> lk(mu); sender_failed = true; cv.notify_all(); return; }
+            if (m.h.kind == KIND_RUN && !(m.h.flags & F_SKIPPED)) {
+                const size_t bytes = (size_t) m.h.n_tokens * tp->n_embd * 4;
+                bool ok = true;
+                if (dev) ok = hipMemcpyAsync((uint8_t *) tp->peer_ring + (h % TP_X_SLOTS) * xb, x_out[m.buf], bytes, hipMemcpyDeviceToDevice, tp->copy_stream) == hipSuccess && hipStreamSynchronize(tp->copy_stream) == hipSuccess;
+                else memcpy(tp->host_x_slot(r + 1, h), x_out[m.buf], bytes);
+                if (!ok) { tp->fail("peer store of the activations failed"); std::lock_guard<std::mutex> lk(mu); sender_failed = true; cv.notify_all(); return; }
+            }
+            if (m.buf >= 0) { std::lock_guard<std::mutex> lk(mu); buf_busy[m.buf] = 0; cv.notify_all(); }
+            L->st[r + 1].slots[h % TP_X_SLOTS] = m.h;
+            nx.head.store(h + 1, std::memory_order_release);                    // the header is published after its activations have landed
+            { std::lock_guard<std::mutex> lk(mu); st.send_ms += (now_us() - t0) / 1e3; }
+            if (m.h.kind == KIND_SHUTDOWN) return;
+        }
+    });
+
+    ring_ctl & in = L->st[r].in;
+    const int cap = tp->in_cap(r);
+    int rc_all = 0, jbuf = 0;
+    while (true) {
+        const uint64_t t = in.tail.load(std::memory_order_relaxed);
+        int64_t t0 = now_us();
+        if (!tp->wait_for([&] { return in.head.load(std::memory_order_acquire) > t; }, -1)) { rc_all = -1; break; }
+        st.wait_in_ms += (now_us() - t0) / 1e3;
+        msg_hdr m = L->st[r].slots[t % cap];
+        if (m.kind == KIND_SHUTDOWN) {
+            in.tail.store(t + 1, std::memory_order_release);
+            if (!is_last) { std::lock_guard<std::mutex> lk(mu); outq.push_back({ m, -1 }); cv.notify_all(); }
+            break;
+        }
+        const int n = m.n_tokens;
+        const size_t words = (size_t) (tp->n_ctx + 31) / 32, meta_bytes = (size_t) n * 8 + 16 + (size_t) n * words * 4;
+        bool skipped = (m.flags & F_SKIPPED) != 0;
+        if (!skipped && tp->is_cancelled(m.gen, m.batch_id)) skipped = true;    // the head cancelled it before this stage started on it
+        uint8_t * rs = nullptr; uint64_t rh = 0;
+        if (is_last) {
+            rh = L->res.head.load(std::memory_order_relaxed);
+            if (!tp->wait_for([&] { return rh - L->res.tail.load(std::memory_order_acquire) < (uint64_t) TP_RES_SLOTS; }, -1)) { rc_all = -1; break; }
+            rs = tp->res_slot(rh);
+        }
+        int buf = -1;
+        if (!skipped) {
+            if (!is_last) {
+                buf = jbuf & 1;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !buf_busy[buf] || sender_failed; });
+                if (sender_failed) { rc_all = -1; break; }
+                buf_busy[buf] = 1;
+            }
+            const float * x_in = is_first ? nullptr : (dev ? (const float *) ((uint8_t *) tp->my_ring + (t % TP_X_SLOTS) * xb) : tp->host_x_slot(r, t));
+            float * xo = is_last ? nullptr : x_out[buf];
+            tp->cur_key = ((uint64_t) (uint32_t) m.gen << 32) | (uint32_t) m.batch_id;
+            t0 = now_us();
+            int rc;
+            if (backend) rc = backend->run(backend->user, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr);
+            else rc = pi::stage_run(ctx, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr, abort_probe, tp);
+            st.compute_ms += (now_us() - t0) / 1e3;
+            tp->cur_key = ~0ull;
+            if (rc < 0) { tp->fail(std::string("stage run failed: ") + (ctx ? pipeinfer_context_error(ctx) : "backend error")); rc_all = -1; break; }
+            if (rc == 1) { skipped = true; st.cut_short++; if (buf >= 0) { std::lock_guard<std::mutex> lk(mu); buf_busy[buf] = 0; } buf = -1; }
+            else { st.runs++; if (!is_last) jbuf++; }
+        }
+        if (skipped) st.skipped++;
+        in.tail.store(t + 1, std::memory_order_release);                        // the incoming activation slot is free again
+        m.flags = skipped ? F_SKIPPED : 0;
+        if (is_last) {
+            *(msg_hdr *) rs = m;
+            L->res.head.store(rh + 1, std::memory_order_release);
+        } else {
+            std::lock_guard<std::mutex> lk(mu);
+            outq.push_back({ m, buf }); cv.notify_all();
+        }
+    }
+    if (sender.joinable()) {
+        if (rc_all != 0) { std::lock_guard<std::mutex> lk(mu); msg_hdr bye{}; bye.kind = KIND_SHUTDOWN; outq.push_back({ bye, -1 }); cv.notify_all(); }
+        sender.join();
+    }
+    for (int i = 0; i < 2; i++) if (x_out[i]) { if (dev) (void) hipFree(x_out[i]); else free(x_out[i]); }
+    st.cancel_notes = tp->cancel_cursor;
+    if (out) *out = st;
+    return rc_all;
+}

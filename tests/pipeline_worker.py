@@ -1,8 +1,8 @@
 """world_size-2 worker for tests/test_pipeline_gloo.py (launched by torch.distributed.run, gloo, no GPU).
 
 rank 0  the C++ PipeInfer driver (pipeinfer_speculative) with the TARGET context as the proxy of a remote pipeline
-        (pipeinfer_amd.pipeline.RemoteTarget over gloo) and the DRAFT context served in-process
-rank 1  pipeinfer_amd.pipeline.stage_loop — the whole target model as one stage
+        (pipeinfer_transport_attach_head: the library's shared-memory transport) and the DRAFT context served in-process
+rank 1  pipeinfer_transport_serve — the whole target model as one stage (world 3: a relay stage + the model)
 
 The layers themselves are computed by the ORACLE (oracle/model.c o_model_forward) on both sides: this is test infrastructure
 standing in for pipeinfer_stage_run, so that the transport, the metadata block, early cancellation and the driver are
@@ -68,7 +68,7 @@ class Relay:
         self.n_embd = n_embd
 
     def run(self, n, meta, x_in=None, x_out=None):
-        x_out.copy_(torch.from_numpy(self.pattern(n, meta, self.n_embd)))
+        x_out[:] = self.pattern(n, meta, self.n_embd)
         return None
 
 
@@ -77,7 +77,7 @@ class CheckedOracle(OracleCompute):
 
     def run(self, n, meta, x_in=None, x_out=None):
         want = Relay.pattern(n, np.ascontiguousarray(meta, np.int32), x_in.shape[1])
-        assert np.array_equal(x_in.numpy(), want), "activation block changed on its way between the stages"
+        assert np.array_equal(np.asarray(x_in), want), "activation block changed on its way between the stages"
         return super().run(n, meta)
 
 
@@ -115,43 +115,41 @@ def main():
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("PI_TEST_WATCHDOG", "100")), exit=True)
     out_path, tgt, dft = sys.argv[1], sys.argv[2], sys.argv[3]
-    links = P.init_links()
+    dist.init_process_group("gloo")
     rank = dist.get_rank()
     world = dist.get_world_size()
-    assert world in (2, 3) and links.device == "cpu"
+    assert world in (2, 3)
+    probe = OracleCompute(tgt)
+    n_embd, n_vocab = probe.o.o_model_info(probe.h, 1), probe.n_vocab
+    tp = P.Transport(P.job_name(), rank, world, n_embd, n_vocab, 64, N_CTX, device=-1, timeout_ms=60000)
+    assert not tp.device_mode
     if rank >= 1:
         if world == 2:
-            comp = OracleCompute(tgt)
+            comp = probe
         else:
-            comp = CheckedOracle(tgt) if rank == 2 else None
-        probe = comp if comp is not None else OracleCompute(tgt)
-        n_embd, n_vocab = probe.o.o_model_info(probe.h, 1), probe.n_vocab
-        if comp is None:
-            comp = Relay(n_embd)
-        st = P.stage_loop(links, comp, head=0, prev=rank - 1, nxt=None if rank == world - 1 else rank + 1, n_embd=n_embd, n_vocab=n_vocab, n_batch=64)
+            comp = CheckedOracle(tgt) if rank == 2 else Relay(n_embd)
+        st = tp.serve(backend=comp.run)
         dist.barrier()
+        tp.close()
         print("stage", rank, "served", st, file=sys.stderr)
         return
-    world = dist.get_world_size() if 'world' not in dir() else world
     g = np.load(os.path.join(GOLD, tgt + ".npz"))
     prompt, _ = S.scenario_greedy(512, seed=int(sys.argv[4]), n_prompt=8)
     want = [int(x) for x in g["greedy_tokens"][:24]]
     mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
     verdict = {"trials": []}
-    remote = None
     for trial, (n_draft, n_parallel, min_spec) in enumerate(((3, 3, 1), (4, 2, 2), (2, 1, 0))):
         ct, cd = LL.Context(mt, n_ctx=N_CTX, n_batch=64), LL.Context(md, n_ctx=N_CTX, n_batch=64)
-        remote = remote if trial else P.RemoteTarget(links, 1, world - 1, list(range(1, world)), mt.n_vocab)     # one transport, several generations
-        remote.attach(ct)
+        tp.attach_head(ct)                                  # one transport, several generations
         local = LocalOps(OracleCompute(dft))
         local.attach(cd)
         out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec, verbose=int(os.environ.get("V", "0")))
         verdict["trials"].append({"out": [int(x) for x in out[:24]], "want": want, "n_runs_spec": res["n_runs_spec"], "n_runs_canceled": res["n_runs_canceled"],
-                                  "n_accept_clean": res["n_accept_clean"], "started": remote.n_started, "results": remote.n_results, "skipped": remote.n_skipped,
-                                  "cancel_msgs": remote.n_cancel_msgs})
+                                  "n_accept_clean": res["n_accept_clean"], **{k: tp.stats()[k] for k in ("runs", "skipped", "cancel_notes")}})
         ct.free(); cd.free()
-    remote.shutdown()
+    tp.shutdown()
     dist.barrier()
+    tp.close()
     with open(out_path, "w") as f:
         json.dump(verdict, f)
 
