@@ -53,6 +53,9 @@ PI_API int     pi_kernel_timing_report(int weight_type, int n_tok, double * avg_
 PI_API pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host_blocks, void * stream);
 PI_API void    pi_weight_free(pi_weight * w);
 PI_API size_t  pi_weight_nbytes(const pi_weight * w);  /* HBM bytes == ggml_nbytes of the tensor */
+PI_API const void * pi_weight_data(const pi_weight * w); /* device address of the (repacked) tensor bytes */
+/* reads [p, p + bytes) once with up to `workgroups` workgroups (0: as many as the bytes need): warms the memory-side Infinity Cache */
+PI_API int     pi_op_prefetch(const void * p, size_t bytes, int workgroups, void * stream);
 PI_API int     pi_weight_type(const pi_weight * w);
 
 /* type the activations must be quantised to for this weight type (type_traits[].vec_dot_type, ggml.c:415-600) */

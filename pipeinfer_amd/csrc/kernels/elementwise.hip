@@ -148,13 +148,12 @@ static __device__ __forceinline__ void wave_emit_frags(const q8k_frags & F, cons
     const int64_t cb = (int64_t) (t >> 4) * nb + blk;                                       // (chunk, block)
     const uint32_t h02 = (uint32_t) __half_as_ushort(__float2half_rn((float) q[0])) | (uint32_t) __half_as_ushort(__float2half_rn((float) q[2])) << 16;
     const uint32_t h13 = (uint32_t) __half_as_ushort(__float2half_rn((float) q[1])) | (uint32_t) __half_as_ushort(__float2half_rn((float) q[3])) << 16;
-    const int ga = 2 * (j >> 2) + (j & 1), ea = (j >> 1) & 1, gb = 2 * (j >> 2) + ((j >> 1) & 1), eb = j & 1;
-    *(uint2 *) (F.fa + (((cb * 8 + k) * 64 + tl + 16 * ga) * 16 + ea * 8)) = make_uint2(h02, h13);
-    *(uint2 *) (F.fb + (((cb * 8 + k) * 64 + tl + 16 * gb) * 16 + eb * 8)) = make_uint2(h02, h13);
-    // s4: sum of the 16-group lane/4 (valid in every lane of the quad); pair sums like _mm_hadd_epi16 of the bsums
-    int s2 = s4 + pi_xor4(s4);                                                            // lanes 16c and 16c+8: groups (4c, 4c+1) and (4c+2, 4c+3)
-    const int sB = pi_partner<8>(s2);
-    if ((lane & 15) == 0) *(float2 *) (F.aux + cb * 1024 + 64 + (lane >> 4) * 128 + tl * 8) = make_float2((float) (short) s2, (float) (short) sB);
+    // fragment of accumulator lane k: MFMA lane (token, c) holds sub-blocks 2c and 2c+1 (8 bytes each) — the lane that unpacks qs group c of a weight row
+    *(uint2 *) (F.fa + (((cb * 8 + k) * 64 + tl + 16 * (j >> 1)) * 16 + (j & 1) * 8)) = make_uint2(h02, h13);
+    // aux: [16 tokens] d as float, then the sixteen 16-value sums of the block as f16 (|sum| <= 16 * 127: exact), lane (token, c) = sums 4c..4c+3:
+    // the operand of the mins product  m[2c]*(bs[4c]+bs[4c+1]) + m[2c+1]*(bs[4c+2]+bs[4c+3])  (ggml-quants.c:5339-5345)
+    // s4: sum of the 16-group lane/4 (valid in every lane of the quad)
+    if ((lane & 3) == 0) *(uint16_t *) (F.aux + cb * 1024 + 64 + (tl + 16 * (lane >> 4)) * 8 + ((lane >> 2) & 3) * 2) = __half_as_ushort(__float2half_rn((float) s4));
     if (lane == 0) *(float *) (F.aux + cb * 1024 + tl * 4) = d;
 }
 

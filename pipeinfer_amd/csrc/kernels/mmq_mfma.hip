@@ -17,16 +17,21 @@
 // VALU kernel and as the reference.
 //
 // Mapping.  The MFMA is issued "transposed" (tokens are the rows of A, weight rows the columns of B) so that the C tile puts weight row
-// r on lane (r, g) with tokens 4g..4g+3 in its four registers: the block scalars of the row (d, dmin, 6-bit scales, mins) are then in the
-// lane that loaded the row's block header, and the chains run straight from the MFMA result registers.
+// r on lane (r, c) with tokens 4c..4c+3 in its four registers, and lane (r, c) builds the K-slice of sub-blocks 2c, 2c+1 — the low and high
+// nibbles of ONE dword per accumulator lane k (qs group c, bytes 4k..4k+3).  The tile-major weight copy (runtime.hip: k_repack_mq_q4_K,
+// PI_MQ_TILE bytes per 16 rows x one block) hands each lane exactly what it needs: (d, dmin), a 4-byte record with its two scales and its two
+// mins already unpacked from the 6-bit packing, and its 8 dwords of quants.  VALU per (block, k): one shift, four v_and_or_b32, four
+// v_pk_fma_f16; per block: 8 for the scales / mins (v_perm_b32 builds the f16 pairs 1024 + s), 8 for d_x*d_y and -dmin*d_y, and the chains.
+// The mins go through the matrix cores too: acc_m[c] needs m[2c]*(bs[4c]+bs[4c+1]) + m[2c+1]*(bs[4c+2]+bs[4c+3]) — an MFMA whose B operand
+// is (m[2c], m[2c], m[2c+1], m[2c+1]) on the lanes of K-slice c and zero elsewhere, A = the tokens' sixteen 16-value sums as f16 (<= 2032).
 // A workgroup is R row groups of 16 rows x S waves; wave s of a row group owns accumulator lanes k in [s*8/S, (s+1)*8/S) and mins lanes
-// c in [s*4/S, (s+1)*4/S) for ALL blocks of the row, so waves never exchange anything until the final fold — no per-block barrier —
-// and a row group streams S waves deep.  Weights come from a TILE-MAJOR copy (16 rows x one block = 2304 contiguous bytes, runtime.hip:
-// k_repack_mq_q4_K): reading 16 rows x one block per step from the row-major planes of the decode kernel streams at 1.3-1.6 TB/s with no
-// arithmetic at all, the same bytes tile-major at ~5 TB/s (tools_dev/pattern.hip).  What IS shared is the
+// c in [s*4/S, (s+1)*4/S) for ALL blocks of the row, so waves never exchange anything until the final fold — no per-block barrier.  S = 1
+// (tall matrices: enough row groups to fill the chip) needs the fewest instructions per byte; S = 2 / 4 buy waves for short matrices at
+// the price of repeating the per-block scalar work.  Reading 16 rows x one block per step from the row-major planes of the decode kernel
+// streams at 1.3-1.6 TB/s with no arithmetic at all, the same bytes tile-major at ~5 TB/s (tools_dev/pattern.hip).  What IS shared is the
 // activation side: the f16 fragments, the tokens' d and block sums (written by the quantisers in exactly this image, elementwise.hip:
 // wave_emit_frags) are copied global -> LDS by DMA one tile of TB blocks ahead, once per workgroup.
-// Weights: each wave keeps a ring of 2*TB blocks in registers (its share: 8/S + 16 bytes per lane and block), refilled right after use.
+// Weights: each wave keeps a ring of 2*TB blocks in registers (its share: 8 + 32/S bytes per lane and block), refilled right after use.
 #include "mmvq_args.h"
 
 #include <cstdlib>
@@ -58,18 +63,20 @@ static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { retu
 #define MQ_STR(x) MQ_STR_(x)
 #define MQ_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 
-template <int TYPE, int S> struct mq_w { uint4 hdr; uint4 q[4 / S]; };                  // one lane's share of one block (Q4_K)
+template <int S> struct mq_q { uint4 v[2 / S]; };
+template <> struct mq_q<4> { uint2 v[1]; };
+template <int TYPE, int S> struct mq_w { uint32_t dd, rec; mq_q<S> q; };                  // one lane's share of one block (Q4_K): (d, dmin), its scales / mins record, 8 / S quant dwords
 
 template <int TYPE, int S, int R, int TB, bool NT8>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
     static_assert(TYPE == PI_Q4_K, "types are added one by one");
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = 1 + 4 / S;       // LW: vector loads per block of weights
+    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = S == 1 ? 4 : 3;  // LW: vector loads per block of weights
     constexpr int FRAG = NT8 ? 512 : 1024, MQ_BLK_LDS = 8 * FRAG + 1024, NP = NT8 ? 5 : 9;   // NP: DMA pieces of 1 KB per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
-    const int r = lane & 15, gq = lane >> 4, p = gq >> 1, h = gq & 1;                     // weight row r, K-slice gq = (p, h): sub-blocks {4p+h, 4p+2+h}; C tile: tokens 4 gq ..
+    const int r = lane & 15, gq = lane >> 4;                                              // weight row r, K-slice gq: sub-blocks 2gq, 2gq+1; C tile: tokens 4 gq ..
     const int rg_raw = (int) blockIdx.x * R + rgl;
     const bool active = rg_raw < n_groups;
     const int rg = active ? rg_raw : n_groups - 1;
@@ -78,13 +85,19 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     const int64_t row0 = (int64_t) (rg - sg.wave0) * 16;
     const int rows = sg.M - row0 < 16 ? (int) (sg.M - row0) : 16;
     const int nb = g.nb, nt = g.nt, ntile = (nb + TB - 1) / TB;
+    // tuning toggles (1 no compute, 2 no staging, 4 no barrier, 8 no chains; wrong results): only in a -DPI_MMQ_DBG_BUILD build — as run-time branches
+    // they sit between every MFMA and its chain and keep the scheduler from overlapping one accumulator lane's MFMA with the next one's operand build
+#ifdef PI_MMQ_DBG_BUILD
+    const int dbg = g.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
 
-    // lane constants of the nibble-half: h = 0 takes (q & 0x000F000F) | 0x6400 = 1024 + n, scaled by s; h = 1 takes (q & 0x00F000F0) | 0x6400
-    // = 1024 + 16 n, scaled by s / 16 (exact: a power of two) — no shift, and (1024 + x n) * s' - 1024 * s' == n * s in one v_pk_fma_f16
-    const uint32_t nib_mask = h ? 0x00F000F0u : 0x000F000Fu;
-    const uint32_t h_scale = h ? 0x2C002C00u : 0x3C003C00u;                               // f16 pair (1/16, 1/16) : (1, 1)
+    // (q & 0x000F000F) | 0x6400 = 1024 + n is scaled by s; (q & 0x00F000F0) | 0x6400 = 1024 + 16 n by s / 16 (exact: a power of two) — no shift of
+    // the high nibbles, and (1024 + x n) * s' - 1024 * s' == n * s in one v_pk_fma_f16
     uint32_t magic = 0x64006400u;                                                         // f16 pair (1024, 1024); kept in a VGPR so that (q & mask) | magic is one v_and_or_b32
     asm volatile("" : "+v"(magic));
+    const uint32_t own[4] = { gq == 0 ? 0xffffffffu : 0u, gq == 1 ? 0xffffffffu : 0u, gq == 2 ? 0xffffffffu : 0u, gq == 3 ? 0xffffffffu : 0u };
 
     float acc[KS][4], accm[CS][4];
 #pragma unroll
@@ -96,21 +109,28 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 #pragma unroll
         for (int i = 0; i < 4; i++) accm[cc][i] = 0.0f;
 
-    // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = 2304 contiguous bytes = [16 headers][4 parts of 512 B]; this
-    // wave's parts are s*4/S .., lane (r, p, h) reads 16 bytes of each (both nibble-halves h read the same bytes)
-    const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * 2304;
-    const uint32_t hdr_off = 16 * r, share_off = 256 + (4 / S) * s * 512 + (r * 2 + p) * 16;
+    // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = PI_MQ_TILE contiguous bytes
+    const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * PI_MQ_TILE;
+    const uint32_t dd_off = 4 * r, rec_off = 64 + 4 * lane, q_off = 320 + 16 * lane + (S == 1 ? 0 : S == 2 ? 1024 * s : 1024 * (s >> 1) + 8 * (s & 1));
     auto load_w = [&](int b, mq_w<TYPE, S> & W) __attribute__((always_inline)) {
-        const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * 2304u;                     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
-        W.hdr = *(const uint4 *) (wbase + (bo + hdr_off));
+        const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * (uint32_t) PI_MQ_TILE;     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
+        W.dd = *(const uint32_t *) (wbase + (bo + dd_off));
+        W.rec = *(const uint32_t *) (wbase + (bo + rec_off));
+        if constexpr (S == 4) W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off));
+        else {
 #pragma unroll
-        for (int i = 0; i < 4 / S; i++) W.q[i] = *(const uint4 *) (wbase + (bo + share_off + 512 * i));
+            for (int i = 0; i < 2 / S; i++) W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + 1024 * i));
+        }
+    };
+    auto qdword = [&](const mq_w<TYPE, S> & W, int kk) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (S == 4) return kk ? W.q.v[0].y : W.q.v[0].x;
+        else { const uint4 v = W.q.v[kk >> 2]; return (kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w; }
     };
     // activation tile T -> LDS buffer: 9 pieces of 1 KB per block, dealt round-robin to the workgroup's waves, one DMA instruction each
     // (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l).  Issued from inline asm: the compiler's wait-count pass drains
     // vmcnt before every LDS read once it sees an LDS-DMA, which would serialise the weight ring; the wave counts its DMAs itself (MQ_WAIT_VM)
     auto dma_tile = [&](int T, uint32_t buf) __attribute__((always_inline)) {
-        if (T < ntile && !(g.dbg & 2)) {
+        if (T < ntile && !(dbg & 2)) {
 #pragma unroll
             for (int i = 0; i < (NP * TB + NW - 1) / NW; i++) {
                 const int piece = i * NW + wave;
@@ -130,55 +150,52 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     };
     // workgroup barrier without the fence of __syncthreads (which waits for every outstanding load): LDS reads of this wave have returned
     // (lgkmcnt), the DMA writes it issued have landed (the caller's MQ_WAIT_VM)
-    auto wg_barrier = [&]() __attribute__((always_inline)) { if (!(g.dbg & 6)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto wg_barrier = [&]() __attribute__((always_inline)) { if (!(dbg & 6)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
-        // ---- block scalars from the row's header: d, dmin, this lane's two 6-bit scales (sub-blocks 4p+h, 4p+2+h), this wave's mins ----
-        const uint4 hdr = W.hdr;
-        const float dx = pi_h2f((uint16_t) (hdr.x & 0xffff)), dminx = pi_h2f((uint16_t) (hdr.x >> 16));
-        const uint32_t scA = hdr.y & 0x3f3f3f3fu, mA = hdr.z & 0x3f3f3f3fu;                               // get_scale_min_k4 (ggml-quants.c:1446-1453), four at a time
-        const uint32_t scB = (hdr.w & 0x0f0f0f0fu) | (((hdr.y >> 6) & 0x03030303u) << 4);
-        const uint32_t mB  = ((hdr.w >> 4) & 0x0f0f0f0fu) | (((hdr.z >> 6) & 0x03030303u) << 4);
-        const uint32_t scw = (p ? scB : scA) >> (8 * h);
-        // integer scale -> f16 pair without a conversion: 0x6400 | s == 1024 + s
-        const uint32_t S1 = pk_mul(pk_add(__umul24(scw & 0xff, 0x00010001u) | 0x64006400u, 0xE400E400u), h_scale);            // (s1, s1) or (s1/16, s1/16)
-        const uint32_t S2 = pk_mul(pk_add(__umul24((scw >> 16) & 0xff, 0x00010001u) | 0x64006400u, 0xE400E400u), h_scale);
-        const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);                         // -1024 * s'
-        const float4 dy4 = *(const float4 *) (blk + 8 * FRAG + 16 * gq);                                       // d of tokens 4 gq .. 4 gq + 3
+    auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk, bool live) __attribute__((always_inline)) {
+        // ---- block scalars: d, dmin of the row; this lane's two scales and two mins, bytes of one record ----
+        const uint32_t ddl = live ? W.dd : 0u;
+        const float dx = pi_h2f((uint16_t) (ddl & 0xffff)), dminx = pi_h2f((uint16_t) (ddl >> 16));
+        // integer -> f16 pair without a conversion: bytes (v, 0x64, v, 0x64) = (1024 + v, 1024 + v)
+        const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);                       // (s, s) of sub-block 2gq   (low nibbles)
+        const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);          // (1024 + s) / 16 - 64 = s / 16 of sub-block 2gq+1 (high nibbles)
+        const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);                                             // -1024 * s'
+        const float4 dy4 = *(const float4 *) (blk + 8 * FRAG + 16 * gq);                                                       // d of tokens 4 gq .. 4 gq + 3
         const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
         float d[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) d[i] = dy[i] * dx;                                                     // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+        const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
-            const uint4 qv = W.q[kk / 2];
-            const uint32_t q0 = (kk & 1) ? qv.z : qv.x, q1 = (kk & 1) ? qv.w : qv.y;                       // dwords (k, m = 2p) and (k, m = 2p + 1)
+            const uint32_t q = qdword(W, kk), qh = q >> 8;
             uint4 bw;
-            bw.x = pk_fma((q0 & nib_mask) | magic, S1, C1);                                                // sub-block 4p+h: bytes (i0, i2)
-            bw.y = pk_fma(((q0 >> 8) & nib_mask) | magic, S1, C1);                                         //                  bytes (i1, i3)
-            bw.z = pk_fma((q1 & nib_mask) | magic, S2, C2);                                                // sub-block 4p+2+h
-            bw.w = pk_fma(((q1 >> 8) & nib_mask) | magic, S2, C2);
+            bw.x = pk_fma((q & 0x000F000Fu) | magic, S1, C1);                                              // sub-block 2gq:   bytes (i0, i2)
+            bw.y = pk_fma((qh & 0x000F000Fu) | magic, S1, C1);                                             //                  bytes (i1, i3)
+            bw.z = pk_fma((q & 0x00F000F0u) | magic, S2, C2);                                              // sub-block 2gq+1
+            bw.w = pk_fma((qh & 0x00F000F0u) | magic, S2, C2);
             const uint4 af = *(const uint4 *) (blk + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));   // tokens' fragment of accumulator lane k
-            const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
             const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
-            if (g.dbg & 8) { acc[kk][0] += c[0] + c[1] + c[2] + c[3]; continue; }
+            if (dbg & 8) { acc[kk][0] += c[0] + c[1] + c[2] + c[3]; continue; }
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[kk][i] = fmaf(d[i], c[i], acc[kk][i]);                         // (float) sumi[k] of row r, token 4 gq + i
         }
-        if (g.dbg & 8) return;
+        if (dbg & 8) return;
         // mins: acc_m[c] = fma(-y.d * dmin, (float) (m[2c]*(bs[4c]+bs[4c+1]) + m[2c+1]*(bs[4c+2]+bs[4c+3])), acc_m[c])   (ggml-quants.c:5339-5345)
+        const uint32_t M0 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04020402u), 0xE400E400u);   // (m[2gq], m[2gq])
+        const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);   // (m[2gq+1], m[2gq+1])
+        const uint2 bs = *(const uint2 *) (blk + 8 * FRAG + 64 + (NT8 ? (gq * 16 + (r & 7)) : lane) * 8);  // f16 (bs[4gq] .. bs[4gq+3]) of token r
+        const uint4 am = make_uint4(bs.x, bs.y, 0u, 0u);
         float nd[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) nd[i] = -dy[i] * dminx;
 #pragma unroll
         for (int cc = 0; cc < CS; cc++) {
             const int c = s * CS + cc;
-            const uint32_t mw = ((c & 2) ? mB : mA) >> (16 * (c & 1));
-            const float m0 = (float) (mw & 0xff), m1 = (float) ((mw >> 8) & 0xff);
-            const float4 f01 = *(const float4 *) (blk + 8 * FRAG + 64 + c * 128 + gq * 32), f23 = *(const float4 *) (blk + 8 * FRAG + 64 + c * 128 + gq * 32 + 16);
-            const float fa[4] = { f01.x, f01.z, f23.x, f23.z }, fb[4] = { f01.y, f01.w, f23.y, f23.w };
+            const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);                                 // only K-slice c contributes to chain c
+            const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) accm[cc][i] = fmaf(nd[i], fmaf(m0, fa[i], m1 * fb[i]), accm[cc][i]);   // the products are integers below 2^24: exact in any form
+            for (int i = 0; i < 4; i++) accm[cc][i] = fmaf(nd[i], cm[i], accm[cc][i]);                     // the products are integers below 2^24: exact in any form
         }
     };
 
@@ -198,7 +215,10 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     // after the DMAs of tile T + NB - 1 a wave issues TB * LW refills in tile T; when tile T ends, the DMAs of tile T + 1 are older than
     // (NB - 2) tiles of refills + this tile's refills + at least floor(9 TB / NW) DMAs of each younger tile
     constexpr int DMA_MIN = (NP * TB) / NW, WAIT_N = (NB - 1) * TB * LW + (NB - 2) * DMA_MIN;
-    for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {                            // 2 NB tiles per trip: buffer (T % NB) and ring half (T % 2) are compile-time
+    // 2 NB tiles per trip: buffer (T % NB) and ring half (T % 2) are compile-time.  The uniform branches around a tile and around a block's
+    // compute are deliberate: they are basic-block boundaries for the scheduler, which otherwise interleaves several blocks, doubles the
+    // registers in use and spills (measured: 90 -> 124 VGPRs at S = 4, 170 -> 256 + 340 bytes of scratch at S = 1 without them)
+    for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
 #pragma unroll
         for (int j = 0; j < 2 * NB; j++) {
             const int T = T0 + j;
@@ -209,10 +229,11 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
                 for (int u = 0; u < TB; u++) {
                     const int b = T * TB + u;
                     mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
-                    if (b < nb && !(g.dbg & 1)) compute(W, buf + u * MQ_BLK_LDS); else if (g.dbg & 1) acc[0][0] += __builtin_bit_cast(float, W.hdr.x ^ W.q[0].y);
+                    if (dbg & 1) acc[0][0] += __builtin_bit_cast(float, W.dd ^ W.rec ^ qdword(W, 0) ^ qdword(W, KS - 1));
+                    else if (b < nb) compute(W, buf + u * MQ_BLK_LDS, true);
                     load_w(b + D, W);
                 }
-                if (!(g.dbg & 2)) {
+                if (!(dbg & 2)) {
                     if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);      // (the last tiles request nothing new)
                 }
                 wg_barrier();
@@ -302,21 +323,22 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
 
 static void mmq_dispatch(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
-        case 22: mmq_go<PI_Q4_K, 2, 2, 2, 2>(g, groups, stream, ea, eb); break;
-        case 24: mmq_go<PI_Q4_K, 2, 4, 2, 2>(g, groups, stream, ea, eb); break;
-        case 25: mmq_go<PI_Q4_K, 2, 4, 2, 4>(g, groups, stream, ea, eb); break;
+        case 17: mmq_go<PI_Q4_K, 1, 7, 2, 4>(g, groups, stream, ea, eb); break;
+        case 18: mmq_go<PI_Q4_K, 1, 8, 2, 4>(g, groups, stream, ea, eb); break;
+        case 14: mmq_go<PI_Q4_K, 1, 4, 2, 4>(g, groups, stream, ea, eb); break;
+        case 22: mmq_go<PI_Q4_K, 2, 2, 2, 4>(g, groups, stream, ea, eb); break;
+        case 24: mmq_go<PI_Q4_K, 2, 4, 2, 4>(g, groups, stream, ea, eb); break;
         case 41: mmq_go<PI_Q4_K, 4, 1, 2, 4>(g, groups, stream, ea, eb); break;
-        case 44: mmq_go<PI_Q4_K, 4, 4, 2, 4>(g, groups, stream, ea, eb); break;
-        case 43: mmq_go<PI_Q4_K, 4, 2, 2, 2>(g, groups, stream, ea, eb); break;
         default: mmq_go<PI_Q4_K, 4, 2, 2, 4>(g, groups, stream, ea, eb); break;
     }
 }
+static const int mmq_cfgs[] = { 17, 18, 14, 22, 24, 41, 42 };
 // dynamic-LDS limits of every instance, set once and outside any stream capture (a launch inside a captured graph must not change function attributes)
 extern "C" int pi_op_mul_mat_reserve(void) {
     static bool done = false;
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
-    for (int cfg : { 22, 24, 25, 41, 44, 43, 42 }) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int cfg : mmq_cfgs) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(g, 0, cfg, nullptr, nullptr, nullptr); }
     done = true;
     PI_CHECK_LAUNCH();
     return 0;
@@ -333,10 +355,15 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
     if (type != PI_Q4_K) { pi_set_error("pi_mmq_launch: weight type %d has no MFMA kernel", type); return -1; }
     static const int dbg_env = getenv("PI_MMQ_DBG") ? atoi(getenv("PI_MMQ_DBG")) : 0;
     g.dbg = dbg_env;
-    // (waves per row group, row groups per workgroup): more waves per group for short matrices (enough waves to fill 256 CUs), more groups
-    // per workgroup for tall ones (the staged activations are shared by the workgroup).  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
+    // (waves per row group, row groups per workgroup).  One wave per row group needs the fewest instructions per weight byte (the block scalars
+    // are decoded once), but a launch wants >= ~6 waves per CU: S = 1 for tall matrices, 2 / 4 for shorter ones; R fills workgroups of up to
+    // 8 waves that share the staged activations, while keeping >= 256 workgroups.  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
     static const int cfg_env = getenv("PI_MMQ_CFG") ? atoi(getenv("PI_MMQ_CFG")) : 0;
-    int cfg = groups >= 1024 ? 24 : 42;
+    int cfg;
+    if (groups >= 1536) cfg = groups % 7 == 0 || groups >= 2048 ? 17 : 14;
+    else if (groups >= 768) cfg = 24;
+    else if (groups >= 384) cfg = 42;
+    else cfg = 41;
     if (cfg_env) cfg = cfg_env;
     mmq_dispatch(g, groups, cfg, stream, ea, eb);
     PI_CHECK_LAUNCH();

@@ -17,6 +17,8 @@
 //   Q4_0 (18 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][4 dwords c][4 blocks b]   p1: d [groups][4] f16
 //   Q8_0 (34 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][8 lanes k][4 blocks b]    p1: d [groups][4] f16
 //   F32 / F16     native rows
+#define PI_MQ_TILE 2368      /* bytes of one (16 rows x 256 values) tile of the tile-major Q4_K copy */
+
 struct pi_weight {
     int      type;
     int64_t  ne0, ne1;     // K (contiguous), rows
@@ -27,7 +29,7 @@ struct pi_weight {
     const uint8_t * p0, * p1, * p2, * p3;
     // second, TILE-MAJOR copy for the multi-token MFMA kernel (mmq_mfma.hip), null when the type has none or copies are off (PI_MMQ_COPIES=0):
     // that kernel reads 16 rows x one block per step, which streams at 1.3-1.6 TB/s from the row-major planes above and at ~5 TB/s when the
-    // 16 blocks are contiguous (tools_dev/pattern.hip).  [row group of 16][block][2304 B]; same bytes, re-ordered (layout in runtime.hip)
+    // 16 blocks are contiguous (tools_dev/pattern.hip).  [row group of 16][block][PI_MQ_TILE bytes]; scales / mins unpacked per lane, quants re-ordered (layout in runtime.hip)
     const uint8_t * mq;
     void *   mq_base;
 };

@@ -117,26 +117,40 @@ __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restr
     // (row, p, h) reads the 64 contiguous bytes of half p and takes nibble-half h of every dword (mmq_mfma.hip)
     for (int k = 0; k < 8; k++) for (int m = 0; m < 4; m++) dq[(m >> 1) * 16 + k * 2 + (m & 1)] = sq[m * 8 + k];
 }
-// Q4_K, tile-major copy for the MFMA kernel: tile (row group g, block b) = 16 row headers of 16 B, then four parts of 512 B; part t holds,
-// for row r and half p, the dwords (k = 2t, m = 2p), (2t, 2p+1), (2t+1, 2p), (2t+1, 2p+1) of the block (dword (k, m) = bytes 4k..4k+3 of the
-// m-th 32-byte qs group) — the 16 bytes lane (r, p, h) of wave-part t loads.  Rows past the end of the matrix are zero (d = 0: they add nothing).
+// Q4_K, tile-major copy for the MFMA kernel (mmq_mfma.hip): tile (row group g, block b) = PI_MQ_TILE = 2368 contiguous bytes
+//   [  0,   64)  16 rows x (d, dmin) as the block's two f16
+//   [ 64,  320)  64 records of 4 bytes, record (r + 16 c) = s(2c), s(2c+1), m(2c), m(2c+1) of row r: the 6-bit scales / mins of sub-blocks
+//                2c, 2c+1 already unpacked (get_scale_min_k4, ggml-quants.c:1446-1453) — lane (r, c) of the kernel needs exactly these four
+//   [320, 1344)  part 0: lane (r + 16 c) x 16 bytes = dwords k = 0..3 of qs group c (dword k = bytes 4k..4k+3 of the c-th 32-byte group:
+//                low nibbles = sub-block 2c, high nibbles = sub-block 2c+1, accumulator lane k)
+//   [1344, 2368) part 1: k = 4..7
+// Rows past the end of the matrix are zero (d = 0: they add nothing).
 __global__ void k_repack_mq_q4_K(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t rows, int64_t nb) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;                  // (row group, block, row in group)
     const int64_t n_rg = (rows + 15) / 16;
     if (i >= n_rg * nb * 16) return;
     const int r = (int) (i & 15); const int64_t gb = i >> 4, g = gb / nb, b = gb % nb, row = g * 16 + r;
-    uint8_t * tile = dst + gb * 2304;
-    uint32_t * hd = (uint32_t *) (tile + 16 * r);
+    uint8_t * tile = dst + gb * PI_MQ_TILE;
+    uint32_t * dd = (uint32_t *) tile, * rec = (uint32_t *) (tile + 64), * q0 = (uint32_t *) (tile + 320), * q1 = (uint32_t *) (tile + 1344);
     if (row >= rows) {
-        for (int j = 0; j < 4; j++) hd[j] = 0;
-        for (int t = 0; t < 4; t++) for (int p = 0; p < 2; p++) for (int j = 0; j < 4; j++) ((uint32_t *) (tile + 256 + t * 512 + (r * 2 + p) * 16))[j] = 0;
+        dd[r] = 0;
+        for (int c = 0; c < 4; c++) { rec[r + 16 * c] = 0; for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = 0; q1[(r + 16 * c) * 4 + k] = 0; } }
         return;
     }
-    const uint32_t * s = (const uint32_t *) (src + (row * nb + b) * 144);
-    for (int j = 0; j < 4; j++) hd[j] = s[j];
+    const uint8_t * blk = src + (row * nb + b) * 144;
+    const uint32_t * s = (const uint32_t *) blk;
+    const uint8_t * sc = blk + 4;
+    dd[r] = s[0];
+    uint32_t scl[8], mn[8];
+    for (int j = 0; j < 8; j++) {
+        if (j < 4) { scl[j] = sc[j] & 63; mn[j] = sc[j + 4] & 63; }
+        else { scl[j] = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4); mn[j] = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
+    }
     const uint32_t * sq = s + 4;
-    for (int k = 0; k < 8; k++) for (int m = 0; m < 4; m++)
-        ((uint32_t *) (tile + 256 + (k >> 1) * 512 + (r * 2 + (m >> 1)) * 16))[(k & 1) * 2 + (m & 1)] = sq[m * 8 + k];
+    for (int c = 0; c < 4; c++) {
+        rec[r + 16 * c] = scl[2 * c] | scl[2 * c + 1] << 8 | mn[2 * c] << 16 | mn[2 * c + 1] << 24;
+        for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = sq[c * 8 + k]; q1[(r + 16 * c) * 4 + k] = sq[c * 8 + 4 + k]; }
+    }
 }
 __global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint16_t * d, int64_t nblocks) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,7 +263,7 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
     if (mq_on && type == PI_Q4_K) {
         const int64_t n_rg = (ne1 + 15) / 16;
-        if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * 2304 + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
+        if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * PI_MQ_TILE + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
         w->mq = (const uint8_t *) w->mq_base;
         hipLaunchKernelGGL(k_repack_mq_q4_K, dim3((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads)), dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
     }
@@ -261,6 +275,35 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
 
 extern "C" void pi_weight_free(pi_weight * w) { if (w) { (void) hipFree(w->base); if (w->mq_base) (void) hipFree(w->mq_base); delete w; } }
 extern "C" size_t pi_weight_nbytes(const pi_weight * w) { return w->nbytes; }
+
+// ---- Infinity-Cache warm-up: read [p, p + bytes) once so that the bytes sit in the 256 MB memory-side cache when the mat-vec that owns them starts.
+// Runs on a side stream next to the latency-bound launches of a decode layer (norm / quantise / attention keep one to 64 CUs busy and leave HBM idle).
+__global__ void __launch_bounds__(256) k_prefetch(const uint4 * __restrict__ p, size_t n16, uint32_t * __restrict__ sink) {
+    const size_t stride = (size_t) gridDim.x * 256;
+    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= v[u].x ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const uint4 v = p[i]; acc ^= v.x ^ v.w; }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;                                    // (keeps the loads alive; practically never taken)
+}
+extern "C" int pi_op_prefetch(const void * p, size_t bytes, int workgroups, void * stream) {
+    if (!p || bytes < 16) return 0;
+    static uint32_t * sink = nullptr;
+    if (!sink) PI_CHECK_HIP(hipMalloc((void **) &sink, 64));
+    const size_t n16 = bytes / 16;
+    size_t wg = (n16 + 256 * 8 - 1) / (256 * 8);
+    if (workgroups > 0 && wg > (size_t) workgroups) wg = (size_t) workgroups;
+    hipLaunchKernelGGL(k_prefetch, dim3((unsigned) wg), dim3(256), 0, (hipStream_t) stream, (const uint4 *) p, n16, sink);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" const void * pi_weight_data(const pi_weight * w) { return w->base; }
 extern "C" int pi_weight_type(const pi_weight * w) { return w->type; }
 
 extern "C" int pi_vec_dot_type(int t) {
@@ -301,8 +344,8 @@ extern "C" void pi_q8_frag_layout(int64_t k, int n_tok, size_t * off_fa, size_t 
     const size_t chunks = (size_t) (n_tok + 15) / 16, nb = (size_t) (k / 256);
     const size_t fa = ob + align256((size_t) n_tok * (k / 16) * 2), frag = chunks * nb * 8 * 1024;
     if (off_fa) *off_fa = fa;
-    if (off_fb) *off_fb = fa + frag;
-    if (off_aux) *off_aux = fa + 2 * frag;
+    if (off_fb) *off_fb = fa;                                   // (one pairing only: every MFMA kernel so far pairs sub-blocks 2c, 2c+1)
+    if (off_aux) *off_aux = fa + frag;
 }
 
 extern "C" size_t pi_q8_nbytes(int vdt, int64_t k, int n_tok) {
