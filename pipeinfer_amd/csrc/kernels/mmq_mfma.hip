@@ -43,9 +43,10 @@ using pi_half2 = __attribute__((ext_vector_type(2))) _Float16;
 using pi_f32x4 = __attribute__((ext_vector_type(4))) float;
 
 int pi_mmq_min_nt() {
-    // measured on 70B shapes (tools_dev/perf_mmvq.py): the VALU mat-vec costs 1.35x / 1.6x / 1.8x / 3.4x a single-token launch at 2 / 3 / 4 / 8
-    // tokens, the matrix-core kernel 1.6-1.9x at any width up to 16: it takes over from 4 tokens
-    static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 4; return n < 2 ? 2 : n; }();
+    // measured on 70B shapes (tools_dev/perf_mmvq.py, us per launch, 8192x8192 / 28672x8192 / 8192x28672; one token: 11.2 / 30.4 / 34.0): the VALU
+    // mat-vec takes 14.9 / 42.2 / 46.5 at 2 tokens and 19.3 / 49.2 / 53.8 at 3, the matrix-core kernel 16.9 / 40.4 / 48.9 and 17.2 / 37.7 / 44.9,
+    // and the same at every width up to 8 (16: 19.5 / 39.6 / 57.6): it takes over from 3 tokens
+    static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 3; return n < 2 ? 2 : n; }();
     return v;
 }
 bool pi_mmq_supported(int type) { return type == PI_Q4_K; }
