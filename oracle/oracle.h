@@ -24,7 +24,7 @@ extern "C" {
 #define ORACLE_API __attribute__((visibility("default")))
 
 // ggml type ids (ggml.h enum ggml_type)
-enum { OT_F32 = 0, OT_F16 = 1, OT_Q4_0 = 2, OT_Q8_0 = 8, OT_Q2_K = 10, OT_Q3_K = 11, OT_Q4_K = 12, OT_Q5_K = 13, OT_Q6_K = 14, OT_Q8_K = 15 };
+enum { OT_F32 = 0, OT_F16 = 1, OT_Q4_0 = 2, OT_Q4_1 = 3, OT_Q5_0 = 6, OT_Q5_1 = 7, OT_Q8_0 = 8, OT_Q8_1 = 9, OT_Q2_K = 10, OT_Q3_K = 11, OT_Q4_K = 12, OT_Q5_K = 13, OT_Q6_K = 14, OT_Q8_K = 15 };
 
 #define OQK   32
 #define OQK_K 256
@@ -32,6 +32,10 @@ enum { OT_F32 = 0, OT_F16 = 1, OT_Q4_0 = 2, OT_Q8_0 = 8, OT_Q2_K = 10, OT_Q3_K =
 #pragma pack(push, 1)
 typedef struct { uint16_t d; uint8_t qs[16]; }                                     oblk_q4_0;  // ggml-quants.h:10-15
 typedef struct { uint16_t d; int8_t qs[32]; }                                      oblk_q8_0;  // :42-47
+typedef struct { uint16_t d, m; uint8_t qs[16]; }                                  oblk_q4_1;  // ggml-quants.h:18-22 (20 bytes)
+typedef struct { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; }                      oblk_q5_0;  // :26-30 (22 bytes)
+typedef struct { uint16_t d, m; uint8_t qh[4]; uint8_t qs[16]; }                   oblk_q5_1;  // :34-39 (24 bytes)
+typedef struct { float d; float s; int8_t qs[32]; }                                oblk_q8_1;  // :50-54 (40 bytes): s = d * sum(qs)
 typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qs[128]; }          oblk_q4_K;  // :116-122
 typedef struct { uint16_t d, dmin; uint8_t scales[12]; uint8_t qh[32]; uint8_t qs[128]; } oblk_q5_K; // :138-145
 typedef struct { uint8_t ql[128]; uint8_t qh[64]; int8_t scales[16]; uint16_t d; } oblk_q6_K;  // :152-158

@@ -53,7 +53,7 @@ uint16_t o_fp32_to_fp16(float f) {
 int o_blck_size(int type) {
     switch (type) {
         case OT_F32: case OT_F16: return 1;
-        case OT_Q4_0: case OT_Q8_0: return OQK;
+        case OT_Q4_0: case OT_Q4_1: case OT_Q5_0: case OT_Q5_1: case OT_Q8_0: case OT_Q8_1: return OQK;
         case OT_Q2_K: case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: case OT_Q8_K: return OQK_K;
     }
     return 0;
@@ -63,6 +63,7 @@ int o_type_size(int type) {
     switch (type) {
         case OT_F32: return 4; case OT_F16: return 2;
         case OT_Q4_0: return sizeof(oblk_q4_0); case OT_Q8_0: return sizeof(oblk_q8_0);
+        case OT_Q4_1: return sizeof(oblk_q4_1); case OT_Q5_0: return sizeof(oblk_q5_0); case OT_Q5_1: return sizeof(oblk_q5_1); case OT_Q8_1: return sizeof(oblk_q8_1);
         case OT_Q4_K: return sizeof(oblk_q4_K); case OT_Q5_K: return sizeof(oblk_q5_K);
         case OT_Q6_K: return sizeof(oblk_q6_K); case OT_Q8_K: return sizeof(oblk_q8_K); case OT_Q3_K: return sizeof(oblk_q3_K); case OT_Q2_K: return sizeof(oblk_q2_K);
     }
@@ -75,7 +76,8 @@ size_t o_row_size(int type, int64_t n) { return (size_t) (n / o_blck_size(type))
 int o_vec_dot_type(int type) {
     switch (type) {
         case OT_F32: return OT_F32; case OT_F16: return OT_F16;
-        case OT_Q4_0: case OT_Q8_0: return OT_Q8_0;
+        case OT_Q4_0: case OT_Q5_0: case OT_Q8_0: return OT_Q8_0;
+        case OT_Q4_1: case OT_Q5_1: return OT_Q8_1;                       // type_traits[].vec_dot_type, ggml.c:436-470
         case OT_Q2_K: case OT_Q3_K: case OT_Q4_K: case OT_Q5_K: case OT_Q6_K: return OT_Q8_K;
     }
     return -1;
@@ -136,9 +138,35 @@ void o_quantize_row_q8_0(const float * x, void * vy, int k) {
     }
 }
 
-void o_quantize_act(int vec_dot_type, const float * x, void * y, int k) {
-    if (vec_dot_type == OT_Q8_K) o_quantize_row_q8_K(x, y, k); else o_quantize_row_q8_0(x, y, k);
+// ggml-quants.c:940-1000 — the AVX2 arm of quantize_row_q8_1: as Q8_0 but d stays a float and s = d * (sum of the 32 quants)
+void o_quantize_row_q8_1(const float * x, void * vy, int k) {
+    oblk_q8_1 * y = vy;
+    const int nb = k / OQK;
+    for (int i = 0; i < nb; i++, x += OQK) {
+        float amax = 0.0f;
+        for (int j = 0; j < OQK; j++) { const float a = fabsf(x[j]); if (a > amax) amax = a; }
+        const float d  = amax / 127.f;
+        y[i].d = d;
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        int sum = 0;
+        for (int j = 0; j < OQK; ++j) {
+            int v = (int) nearbyintf(x[j] * id);
+            sum += v;                                                 // the sum is taken over the int32 lanes, before packs saturate (|v| <= 127 anyway)
+            if (v > 127) v = 127; else if (v < -128) v = -128;
+            y[i].qs[j] = (int8_t) v;
+        }
+        y[i].s = d * (float) sum;
+    }
 }
+
+void o_quantize_act(int vec_dot_type, const float * x, void * y, int k) {
+    if (vec_dot_type == OT_Q8_K) o_quantize_row_q8_K(x, y, k); else if (vec_dot_type == OT_Q8_1) o_quantize_row_q8_1(x, y, k); else o_quantize_row_q8_0(x, y, k);
+}
+
+// element b (0..31) of a legacy 32-block as the integer the dot product multiplies: low nibbles are elements 0..15, high nibbles 16..31
+// (bytes_from_nibbles_32, ggml-quants.c:92-99); Q5: bit b of qh is the fifth bit (bytes_from_bits_32 :76-90)
+static inline int q41_at(const oblk_q4_1 * x, int b) { return b < 16 ? x->qs[b] & 0xF : x->qs[b - 16] >> 4; }
+static inline int q5_nib(const uint8_t * qs, const uint8_t * qh, int b) { uint32_t h; memcpy(&h, qh, 4); return (b < 16 ? qs[b] & 0xF : qs[b - 16] >> 4) | (int) (((h >> b) & 1) << 4); }
 
 // ggml-quants.c:1446-1453
 static inline void scale_min_k4(int j, const uint8_t * q, uint8_t * d, uint8_t * m) {
@@ -191,6 +219,27 @@ void o_dequantize_row(int type, const void * vx, float * y, int k) {
                     y[i * OQK + j]      = ((x[i].qs[j] & 0x0F) - 8) * d;
                     y[i * OQK + j + 16] = ((x[i].qs[j] >> 4) - 8) * d;
                 }
+            }
+        } break;
+        case OT_Q4_1: {                                                          // ggml-quants.c:1094-1113
+            const oblk_q4_1 * x = vx;
+            for (int i = 0; i < k / OQK; i++) {
+                const float d = o_fp16_to_fp32(x[i].d), m = o_fp16_to_fp32(x[i].m);
+                for (int b = 0; b < OQK; b++) y[i * OQK + b] = q41_at(&x[i], b) * d + m;
+            }
+        } break;
+        case OT_Q5_0: {                                                          // :1115-1139
+            const oblk_q5_0 * x = vx;
+            for (int i = 0; i < k / OQK; i++) {
+                const float d = o_fp16_to_fp32(x[i].d);
+                for (int b = 0; b < OQK; b++) y[i * OQK + b] = (q5_nib(x[i].qs, x[i].qh, b) - 16) * d;
+            }
+        } break;
+        case OT_Q5_1: {                                                          // :1141-1166
+            const oblk_q5_1 * x = vx;
+            for (int i = 0; i < k / OQK; i++) {
+                const float d = o_fp16_to_fp32(x[i].d), m = o_fp16_to_fp32(x[i].m);
+                for (int b = 0; b < OQK; b++) y[i * OQK + b] = q5_nib(x[i].qs, x[i].qh, b) * d + m;
             }
         } break;
         case OT_Q8_0: {
@@ -266,6 +315,19 @@ static inline float hsum8(const float a[8]) {
 void o_block_isums(int type, const void * xb, const void * yb, int32_t * isum, int32_t * msum) {
     for (int k = 0; k < 8; k++) isum[k] = 0;
     *msum = 0;
+    if (type == OT_Q4_1 || type == OT_Q5_1) {                                    // x Q8_1: unsigned weights
+        const oblk_q8_1 * y = yb;
+        for (int b = 0; b < 32; b++) {
+            const int xv = type == OT_Q4_1 ? q41_at((const oblk_q4_1 *) xb, b) : q5_nib(((const oblk_q5_1 *) xb)->qs, ((const oblk_q5_1 *) xb)->qh, b);
+            isum[b >> 2] += xv * y->qs[b];
+        }
+        return;
+    }
+    if (type == OT_Q5_0) {
+        const oblk_q8_0 * y = yb; const oblk_q5_0 * x = xb;
+        for (int b = 0; b < 32; b++) isum[b >> 2] += (q5_nib(x->qs, x->qh, b) - 16) * y->qs[b];
+        return;
+    }
     if (type == OT_Q4_0 || type == OT_Q8_0) {
         const oblk_q8_0 * y = yb;
         for (int b = 0; b < 32; b++) {
@@ -323,6 +385,34 @@ float o_vec_dot(int type, int n, const void * vx, const void * vy) {
         float sumf = (t[0] + t[1]) + (t[2] + t[3]);
         for (int i = np; i < n; ++i) sumf += x[i] * y[i];
         return sumf;
+    }
+    if (type == OT_Q4_1 || type == OT_Q5_1) {        // ggml-quants.c:2808-2842, 3372-3398 (AVX2): acc = fmadd(d0*d1, xy, acc); summs += m * y.s; *s = hsum_float_8(acc) + summs
+        const int nb = n / OQK;
+        const oblk_q8_1 * y = vy;
+        float summs = 0.0f;
+        for (int i = 0; i < nb; i++) {
+            int32_t is[8], ms;
+            const void * xb = type == OT_Q4_1 ? (const void *) ((const oblk_q4_1 *) vx + i) : (const void *) ((const oblk_q5_1 *) vx + i);
+            const uint16_t xd = type == OT_Q4_1 ? ((const oblk_q4_1 *) vx)[i].d : ((const oblk_q5_1 *) vx)[i].d;
+            const uint16_t xm = type == OT_Q4_1 ? ((const oblk_q4_1 *) vx)[i].m : ((const oblk_q5_1 *) vx)[i].m;
+            o_block_isums(type, xb, &y[i], is, &ms);
+            const float prod = o_fp16_to_fp32(xm) * y[i].s;
+            summs += prod;
+            const float d = o_fp16_to_fp32(xd) * y[i].d;
+            for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+        }
+        return hsum8(acc) + summs;
+    }
+    if (type == OT_Q5_0) {                            // ggml-quants.c:3056-3078: like Q4_0 with the fifth bit
+        const int nb = n / OQK;
+        const oblk_q8_0 * y = vy; const oblk_q5_0 * x = vx;
+        for (int i = 0; i < nb; i++) {
+            int32_t is[8], ms;
+            o_block_isums(type, &x[i], &y[i], is, &ms);
+            const float d = o_fp16_to_fp32(x[i].d) * o_fp16_to_fp32(y[i].d);
+            for (int k = 0; k < 8; k++) acc[k] = fmaf(d, (float) is[k], acc[k]);
+        }
+        return hsum8(acc);
     }
     if (type == OT_Q4_0 || type == OT_Q8_0) {
         const int nb = n / OQK;

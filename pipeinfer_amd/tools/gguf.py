@@ -13,10 +13,10 @@ ALIGN = 32
 # gguf value types
 U8, I8, U16, I16, U32, I32, F32, BOOL, STR, ARR, U64, I64, F64 = range(13)
 # ggml tensor types
-T_F32, T_F16, T_Q4_0, T_Q8_0, T_Q2_K, T_Q3_K, T_Q4_K, T_Q5_K, T_Q6_K = 0, 1, 2, 8, 10, 11, 12, 13, 14
-BLCK = {T_F32: 1, T_F16: 1, T_Q4_0: 32, T_Q8_0: 32, T_Q2_K: 256, T_Q3_K: 256, T_Q4_K: 256, T_Q5_K: 256, T_Q6_K: 256}
-TSIZE = {T_F32: 4, T_F16: 2, T_Q4_0: 18, T_Q8_0: 34, T_Q2_K: 84, T_Q3_K: 110, T_Q4_K: 144, T_Q5_K: 176, T_Q6_K: 210}
-TYPE_BY_NAME = {"f32": T_F32, "f16": T_F16, "q4_0": T_Q4_0, "q8_0": T_Q8_0, "q2_k": T_Q2_K, "q3_k": T_Q3_K, "q4_k": T_Q4_K, "q5_k": T_Q5_K, "q6_k": T_Q6_K}
+T_F32, T_F16, T_Q4_0, T_Q4_1, T_Q5_0, T_Q5_1, T_Q8_0, T_Q2_K, T_Q3_K, T_Q4_K, T_Q5_K, T_Q6_K = 0, 1, 2, 3, 6, 7, 8, 10, 11, 12, 13, 14
+BLCK = {T_F32: 1, T_F16: 1, T_Q4_0: 32, T_Q4_1: 32, T_Q5_0: 32, T_Q5_1: 32, T_Q8_0: 32, T_Q2_K: 256, T_Q3_K: 256, T_Q4_K: 256, T_Q5_K: 256, T_Q6_K: 256}
+TSIZE = {T_F32: 4, T_F16: 2, T_Q4_0: 18, T_Q4_1: 20, T_Q5_0: 22, T_Q5_1: 24, T_Q8_0: 34, T_Q2_K: 84, T_Q3_K: 110, T_Q4_K: 144, T_Q5_K: 176, T_Q6_K: 210}
+TYPE_BY_NAME = {"f32": T_F32, "f16": T_F16, "q4_0": T_Q4_0, "q4_1": T_Q4_1, "q5_0": T_Q5_0, "q5_1": T_Q5_1, "q8_0": T_Q8_0, "q2_k": T_Q2_K, "q3_k": T_Q3_K, "q4_k": T_Q4_K, "q5_k": T_Q5_K, "q6_k": T_Q6_K}
 
 _SCALAR_FMT = {U8: "<B", I8: "<b", U16: "<H", I16: "<h", U32: "<I", I32: "<i", F32: "<f", BOOL: "<?", U64: "<Q", I64: "<q", F64: "<d"}
 

@@ -159,6 +159,13 @@ def random_blocks(ttype, n_elem, rng, std):
     jitter = (0.75 + 0.5 * rng.random(nb)).astype(np.float32)
     if ttype == G.T_Q4_0:
         out[:, 0:2] = _f16(std / 4.61 * jitter).view(np.uint8).reshape(nb, 2)
+    elif ttype == G.T_Q5_0:                                                  # d | qh 4 | qs 16: (5-bit - 16) * d, uniform 0..31 has std 9.23
+        out[:, 0:2] = _f16(std / 9.23 * jitter).view(np.uint8).reshape(nb, 2)
+    elif ttype in (G.T_Q4_1, G.T_Q5_1):                                      # d | m | (qh) | qs: q * d + m with m = -mid * d
+        mid, spread = (7.5, 4.61) if ttype == G.T_Q4_1 else (15.5, 9.23)
+        d = std / spread * jitter
+        out[:, 0:2] = _f16(d).view(np.uint8).reshape(nb, 2)
+        out[:, 2:4] = _f16(-mid * d).view(np.uint8).reshape(nb, 2)
     elif ttype == G.T_Q8_0:
         out[:, 0:2] = _f16(std / 73.3 * jitter).view(np.uint8).reshape(nb, 2)
         q = out[:, 2:].view(np.int8)

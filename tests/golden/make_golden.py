@@ -122,6 +122,27 @@ def kernel_vectors_q3k(t=None, fname="kernels_q3k.npz"):
     np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
+def kernel_vectors_legacy():
+    """the same vectors for the legacy 32-blocks Q4_1 / Q5_0 / Q5_1 (x Q8_1 / Q8_0 activations), in a file of their own"""
+    r = O.Impl("ref")
+    q = ref_quantizer()
+    out = {}
+    k = 1024
+    for t in (O.Q4_1, O.Q5_0, O.Q5_1):
+        rng = np.random.default_rng(100 + t)
+        w = (rng.standard_normal((6, k)) * 0.05 + 0.01).astype(np.float32)
+        blocks = q(t, w).reshape(6, -1)
+        act = np.stack([synth_signal(k, s + t) for s in range(3)])
+        qa = np.stack([r.quantize_act(O.VEC_DOT_TYPE[t], a) for a in act])
+        name = O.TYPE_NAMES[t]
+        out[f"{name}_blocks"] = blocks
+        out[f"{name}_act"] = act
+        out[f"{name}_qact"] = qa
+        out[f"{name}_dots"] = np.array([[r.vec_dot(t, k, blocks[i], qa[j]) for i in range(6)] for j in range(3)], np.float32)
+        out[f"{name}_deq"] = np.stack([r.dequantize(t, b, k) for b in blocks])
+    np.savez_compressed(os.path.join(HERE, "kernels_legacy.npz"), **out)
+
+
 def model_vectors(only=None):
     q = ref_quantizer()
     for stem, spec, ftype, seed in MODELS:
@@ -156,7 +177,9 @@ def model_vectors(only=None):
 
 if __name__ == "__main__":
     assert O.ref() is not None, "needs oracle/_ref (make -C oracle ref)"
-    if sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
+    if sys.argv[1:] == ["legacy"]:
+        kernel_vectors_legacy()
+    elif sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
         model_vectors(only=["tiny_llama_q3_k_m"])
     elif sys.argv[1:] == ["q2k"]:
@@ -166,4 +189,5 @@ if __name__ == "__main__":
         kernel_vectors()
         kernel_vectors_q3k()
         kernel_vectors_q3k(O.Q2_K, "kernels_q2k.npz")
+        kernel_vectors_legacy()
         model_vectors()

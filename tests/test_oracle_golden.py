@@ -19,13 +19,14 @@ def bits(a):
 
 K3 = np.load(os.path.join(GOLD, "kernels_q3k.npz"))
 K2 = np.load(os.path.join(GOLD, "kernels_q2k.npz"))
+KL = np.load(os.path.join(GOLD, "kernels_legacy.npz"))
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q5_0, O.Q5_1, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K])
 def test_quant_golden(t):
     o = O.Impl("oracle")
     name = O.TYPE_NAMES[t]
-    blocks, act, qact, dots, deq = ({O.Q3_K: K3, O.Q2_K: K2}.get(t, K)[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
+    blocks, act, qact, dots, deq = ({O.Q3_K: K3, O.Q2_K: K2, O.Q4_1: KL, O.Q5_0: KL, O.Q5_1: KL}.get(t, K)[f"{name}_{s}"] for s in ("blocks", "act", "qact", "dots", "deq"))
     k = act.shape[1]
     for j in range(act.shape[0]):
         assert np.array_equal(o.quantize_act(O.VEC_DOT_TYPE[t], act[j]), qact[j])          # bytes identical

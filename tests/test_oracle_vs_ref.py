@@ -9,7 +9,7 @@ from tests import oracle_lib as O
 
 pytestmark = pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
 
-QTYPES = [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
+QTYPES = [O.Q4_0, O.Q4_1, O.Q5_0, O.Q5_1, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
 
 
 def synth(n, seed):
@@ -51,7 +51,7 @@ def test_fp16_conversion_exhaustive():
     assert np.array_equal(h_ref, x.astype(np.float16).view(np.uint16))           # numpy agrees too (RNE)
 
 
-@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0])
+@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0, O.Q8_1])
 def test_activation_quantisers_bit_exact(vdt):
     o, r = O.Impl("oracle"), O.Impl("ref")
     for seed in range(6):
