@@ -29,7 +29,7 @@ extern "C" {
 #define PI_API __attribute__((visibility("default")))
 
 /* ggml tensor type ids (ggml.h enum ggml_type) */
-enum pi_type { PI_F32 = 0, PI_F16 = 1, PI_Q4_0 = 2, PI_Q8_0 = 8, PI_Q2_K = 10, PI_Q3_K = 11, PI_Q4_K = 12, PI_Q5_K = 13, PI_Q6_K = 14, PI_Q8_K = 15 };
+enum pi_type { PI_F32 = 0, PI_F16 = 1, PI_Q4_0 = 2, PI_Q4_1 = 3, PI_Q5_0 = 6, PI_Q5_1 = 7, PI_Q8_0 = 8, PI_Q8_1 = 9, PI_Q2_K = 10, PI_Q3_K = 11, PI_Q4_K = 12, PI_Q5_K = 13, PI_Q6_K = 14, PI_Q8_K = 15 };
 
 typedef struct pi_weight pi_weight;    /* a weight matrix resident in HBM in the kernel-friendly layout */
 
@@ -60,9 +60,9 @@ PI_API int     pi_weight_type(const pi_weight * w);
 
 /* type the activations must be quantised to for this weight type (type_traits[].vec_dot_type, ggml.c:415-600) */
 PI_API int     pi_vec_dot_type(int weight_type);
-/* bytes of the device activation buffer for n_tok rows of k values quantised to vdt (PI_Q8_K or PI_Q8_0) */
+/* bytes of the device activation buffer for n_tok rows of k values quantised to vdt (PI_Q8_K, PI_Q8_0 or PI_Q8_1) */
 PI_API size_t  pi_q8_nbytes(int vdt, int64_t k, int n_tok);
-/* byte offsets of the planes inside that buffer: qs (int8 [n_tok][k]), d (f32 [n_tok][k/256] | f16 [n_tok][k/32]), bsums (int16 [n_tok][k/16], Q8_K only) */
+/* byte offsets of the planes inside that buffer: qs (int8 [n_tok][k]), d (f32 [n_tok][k/256] | f16 [n_tok][k/32] | Q8_1: f32 [n_tok][k/32]), third plane: bsums (int16 [n_tok][k/16], Q8_K) or s = d * sum(qs) (f32 [n_tok][k/32], Q8_1) */
 PI_API void    pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size_t * off_d, size_t * off_bsums);
 /* Q8_K, n_tok >= 2: byte offsets of the MFMA operand planes the quantisers also write (f16 copies of qs in the lane order of
  * v_mfma_f32_16x16x32_f16, two sub-block pairings, and per-token block sums / scales as floats); layout in runtime.hip */

@@ -94,7 +94,7 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     if (!(ctx->rope = pi_rope_table_create(std::max(ctx->n_ctx, 32), hp.head_dim(), freq_base, freq_scale, neox))) { err = pi_last_error(); return false; }
     const size_t qkv_w = (size_t) n_embd + 2 * n_gqa;
     const size_t kmax = (size_t) std::max(n_embd, n_ff);
-    const size_t q8_bytes = std::max(pi_q8_nbytes(PI_Q8_K, (int64_t) ((kmax + 255) / 256 * 256), nb), pi_q8_nbytes(PI_Q8_0, (int64_t) kmax, nb));
+    const size_t q8_bytes = std::max(pi_q8_nbytes(PI_Q8_K, (int64_t) ((kmax + 255) / 256 * 256), nb), std::max(pi_q8_nbytes(PI_Q8_0, (int64_t) kmax, nb), pi_q8_nbytes(PI_Q8_1, (int64_t) kmax, nb)));
     if (!(ctx->x = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->x2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->nx = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->nx2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->qkv = (float *) dev((size_t) 4 * nb * qkv_w)) || !(ctx->att = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->up = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->gate = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->q16 = (uint16_t *) dev((size_t) 2 * nb * n_embd)) ||

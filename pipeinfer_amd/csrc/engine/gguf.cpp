@@ -15,6 +15,9 @@ size_t type_row_size(int type, int64_t ne0) {
         case 0:  return (size_t) ne0 * 4;
         case 1:  return (size_t) ne0 * 2;
         case 2:  return (size_t) ne0 / 32 * 18;
+        case 3:  return (size_t) ne0 / 32 * 20;      // Q4_1
+        case 6:  return (size_t) ne0 / 32 * 22;      // Q5_0
+        case 7:  return (size_t) ne0 / 32 * 24;      // Q5_1
         case 8:  return (size_t) ne0 / 32 * 34;
         case 10: return (size_t) ne0 / 256 * 84;
         case 11: return (size_t) ne0 / 256 * 110;

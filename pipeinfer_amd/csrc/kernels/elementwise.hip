@@ -29,6 +29,14 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
             const int x = (l < 16 ? (q & 0xF) : (q >> 4)) - 8;
             y = x * pi_h2f(((const uint16_t *) w.p1)[grp * 4 + bi]);
         } break;
+        case PI_Q4_1: case PI_Q5_0: case PI_Q5_1: {                                              // dequantize_row_q4_1 / q5_0 / q5_1, ggml-quants.c:1094-1166
+            const int64_t blk = e >> 5, grp = row * w.ng + (blk >> 2); const int bi = (int) (blk & 3), l = (int) (e & 31);
+            const uint8_t q = w.p0[grp * 64 + ((l & 15) >> 2) * 16 + bi * 4 + (l & 3)];
+            const int hb = (int) ((((const uint32_t *) w.p2)[grp * 4 + bi] >> l) & 1) << 4;       // (0 for Q4_1)
+            const int x = (l < 16 ? (q & 0xF) : (q >> 4)) | hb;
+            const float d = pi_h2f(((const uint16_t *) w.p1)[grp * 8 + bi]), m = pi_h2f(((const uint16_t *) w.p1)[grp * 8 + 4 + bi]);
+            y = w.type == PI_Q5_0 ? (x - 16) * d : x * d + m;
+        } break;
         case PI_Q8_0: {
             const int64_t blk = e >> 5, grp = row * w.ng + (blk >> 2); const int bi = (int) (blk & 3), l = (int) (e & 31);
             y = (int) ((const int8_t *) w.p0)[grp * 128 + (l >> 2) * 16 + bi * 4 + (l & 3)] * pi_h2f(((const uint16_t *) w.p1)[grp * 4 + bi]);
@@ -188,8 +196,16 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__
     wave_emit_frags(F, q, s, d, lane, t, blk, nb);
 }
 
+// block scale of Q8_0 (f16 d) or Q8_1 (ss != null: float d and s = d * sum of the 32 quants, quantize_row_q8_1 ggml-quants.c:940-985)
+static __device__ __forceinline__ void q8_0_store_scale(const int q[4], float d, int kk, int64_t grp, int bi, uint16_t * dd, float * ss) {
+    if (!ss) { if (kk == 0) dd[grp * 4 + bi] = pi_f2h(d); return; }
+    int sum = q[0] + q[1] + q[2] + q[3];
+    sum += pi_partner<1>(sum); sum += pi_partner<2>(sum); sum += pi_xor4(sum);            // the 8 lanes of the block (integers: any order)
+    if (kk == 0) { ((float *) dd)[grp * 4 + bi] = d; ss[grp * 4 + bi] = d * (float) sum; }
+}
+
 // one wave = 8 blocks of 32 = two groups of 4 blocks; values past k belong to the zero padding of the last group
-__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int64_t ng, uint32_t * __restrict__ qs, uint16_t * __restrict__ dd) {
+__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int64_t ng, uint32_t * __restrict__ qs, uint16_t * __restrict__ dd, float * __restrict__ ss) {
     const int t = blockIdx.y, lane = threadIdx.x;
     const int64_t e0 = (int64_t) blockIdx.x * 256 + lane * 4;
     if (e0 >= ng * 128) return;
@@ -204,7 +220,7 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__
     for (int i = 0; i < 4; i++) { int r = __float2int_rn(xs[i] * id); q[i] = r > 127 ? 127 : (r < -128 ? -128 : r); }
     const int64_t blk = e0 >> 5, grp = (int64_t) t * ng + (blk >> 2); const int bi = (int) (blk & 3), kk = lane & 7;
     qs[(grp * 8 + kk) * 4 + bi] = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
-    if (kk == 0) dd[grp * 4 + bi] = pi_f2h(d);
+    q8_0_store_scale(q, d, kk, grp, bi, dd, ss);
 }
 
 // ---- per-256 (Q8_K) / per-8x32 (Q8_0) quantisation of four consecutive values held by each lane of a wave ----------------
@@ -235,7 +251,7 @@ static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int
     if (lane == 0) dd[row_blk] = d;
     wave_emit_frags(F, q, s, d, lane, t, blk, nb);
 }
-static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int lane, int64_t tok_ng, int64_t e0, uint32_t * qs, uint16_t * dd) {
+static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int lane, int64_t tok_ng, int64_t e0, uint32_t * qs, uint16_t * dd, float * ss) {
     float amax = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3])));
     amax = fmaxf(amax, pi_partner<1>(amax)); amax = fmaxf(amax, pi_partner<2>(amax)); amax = fmaxf(amax, pi_xor4(amax));
     const float d = amax / 127.f;
@@ -245,7 +261,7 @@ static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int
     for (int i = 0; i < 4; i++) { int r = __float2int_rn(xs[i] * id); q[i] = r > 127 ? 127 : (r < -128 ? -128 : r); }
     const int64_t blk = e0 >> 5, grp = tok_ng + (blk >> 2); const int bi = (int) (blk & 3), kk = lane & 7;
     qs[(grp * 8 + kk) * 4 + bi] = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
-    if (kk == 0) dd[grp * 4 + bi] = pi_f2h(d);
+    q8_0_store_scale(q, d, kk, grp, bi, dd, ss);
 }
 
 // norm (rms / layer) * weight (+ bias) straight into the quantised activation planes; optionally also the fp32 result.
@@ -344,7 +360,7 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
             if (yf) *(float4 *) (yf + (int64_t) t * n + e0) = make_float4(ys[0], ys[1], ys[2], ys[3]);
         }
         if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, t, c0 >> 8, n >> 8, (int8_t *) qs, (float *) dd, bsums, F);
-        else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd);
+        else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd, vdt == PI_Q8_1 ? (float *) bsums : nullptr);
     }
 }
 
@@ -360,7 +376,7 @@ static q8k_frags frags_of(int vdt, int64_t k, int n_tok, uint8_t * base) {
 
 extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float * b, float * y_f32, int n, int n_tok, float eps, int rms, int vdt, void * q8, void * stream) {
     if (n_tok <= 0) return 0;
-    if ((vdt == PI_Q8_K && n % 256) || (vdt == PI_Q8_0 && n % 32) || (vdt != PI_Q8_K && vdt != PI_Q8_0)) { pi_set_error("pi_op_norm_quantize: n=%d not valid for activation type %d", n, vdt); return -1; }
+    if ((vdt == PI_Q8_K && n % 256) || (vdt != PI_Q8_K && n % 32) || (vdt != PI_Q8_K && vdt != PI_Q8_0 && vdt != PI_Q8_1)) { pi_set_error("pi_op_norm_quantize: n=%d not valid for activation type %d", n, vdt); return -1; }
     size_t oq, od, ob;
     pi_q8_layout(vdt, n, n_tok, &oq, &od, &ob);
     uint8_t * base = (uint8_t *) q8;
@@ -389,12 +405,12 @@ __global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g,
         for (int i = 0; i < 4; i++) { const float a = pi_h2f(tab[pi_f2h(gs[i])]); ys[i] = which == 0 ? a * us[i] : a; }
     }
     if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, t, c0 >> 8, n >> 8, (int8_t *) qs, (float *) dd, bsums, F);
-    else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd);
+    else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd, vdt == PI_Q8_1 ? (float *) bsums : nullptr);
 }
 
 extern "C" int pi_op_act_quantize(const float * gate, const float * up, int which, int64_t n, int n_tok, int vdt, void * q8, void * stream) {
     if (n_tok <= 0) return 0;
-    if ((vdt == PI_Q8_K && n % 256) || (vdt == PI_Q8_0 && n % 32) || (vdt != PI_Q8_K && vdt != PI_Q8_0)) { pi_set_error("pi_op_act_quantize: n=%lld not valid for activation type %d", (long long) n, vdt); return -1; }
+    if ((vdt == PI_Q8_K && n % 256) || (vdt != PI_Q8_K && n % 32) || (vdt != PI_Q8_K && vdt != PI_Q8_0 && vdt != PI_Q8_1)) { pi_set_error("pi_op_act_quantize: n=%lld not valid for activation type %d", (long long) n, vdt); return -1; }
     size_t oq, od, ob;
     pi_q8_layout(vdt, n, n_tok, &oq, &od, &ob);
     uint8_t * base = (uint8_t *) q8;
@@ -415,10 +431,11 @@ extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, vo
     if (vdt == PI_Q8_K) {
         if (k % 256) { pi_set_error("pi_op_quantize: Q8_K needs k %% 256 == 0 (k=%lld)", (long long) k); return -1; }
         hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob), frags_of(vdt, k, n_tok, base));
-    } else if (vdt == PI_Q8_0) {
-        if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 needs k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
+    } else if (vdt == PI_Q8_0 || vdt == PI_Q8_1) {
+        if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 / Q8_1 need k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
         const int64_t ng = (k / 32 + 3) / 4;
-        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((ng * 128 + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, ng, (uint32_t *) (base + oq), (uint16_t *) (base + od));
+        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((ng * 128 + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, ng, (uint32_t *) (base + oq), (uint16_t *) (base + od),
+                           vdt == PI_Q8_1 ? (float *) (base + ob) : nullptr);
     } else { pi_set_error("pi_op_quantize: unsupported activation type %d", vdt); return -1; }
     PI_CHECK_LAUNCH();
     return 0;

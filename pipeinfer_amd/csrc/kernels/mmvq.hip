@@ -620,6 +620,104 @@ __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     }
 }
 
+// ================================================================================================================
+// Legacy 32-blocks Q4_1 / Q5_0 / Q5_1 (x Q8_1 / Q8_0 / Q8_1): the Q4_0 walk above with the formats' extras —
+//   ggml_vec_dot_q4_1_q8_1 (ggml-quants.c:2808-2842), q5_0_q8_0 (:3056-3078), q5_1_q8_1 (:3372-3398), AVX2 arms:
+//   acc[k] = fma(d_x * d_y, (float) sum_{i<4} x[4k+i] * y[4k+i], acc[k]) per block in block order (x unsigned for the _1 formats, 5-bit - 16 for
+//   Q5_0), and for the _1 formats a NINTH, scalar chain  summs += m_x * s_y  (a multiply, then an add) over the same blocks;
+//   result = hsum_float_8(acc) + summs.  Weights: nibbles as Q4_0, (d, m) and qh in planes of their own (runtime.hip: k_repack_legacy).
+// Coverage kernel: one instance for every width (no decode-width specialisation like k_mmvq_q0r).
+// ================================================================================================================
+template <int TYPE, int NT>
+__global__ void __launch_bounds__(256) k_mmvq_leg(const mmvq_args g) {
+    constexpr bool Y81 = TYPE == PI_Q4_1 || TYPE == PI_Q5_1, HB = TYPE != PI_Q4_1;
+    constexpr int DSTR = Y81 ? 16 : 8;                                       // bytes of activation scales per group: 4 floats or 4 f16
+    const mmvq_seg & sg = g.seg[0];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t * l_qs = lds;                                                    // qs [NT][TILE groups][128] | d [NT][TILE][DSTR] | s [NT][TILE][16]
+    uint8_t * l_d = lds + (size_t) NT * MMVQ_TILE * 128;
+    float * l_s = (float *) (l_d + (size_t) NT * MMVQ_TILE * DSTR);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, k = lane & 7;
+    const int64_t row = (int64_t) blockIdx.x * (blockDim.x >> 3) + wave * 8 + r;
+    const bool live = row < sg.M;
+    const int64_t rowc = live ? row : sg.M - 1;
+    const int ng = g.nb, nbr = g.K / 32;                                     // groups per row, real (unpadded) blocks per row
+    float acc[NT], summs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) { acc[t] = 0.0f; summs[t] = 0.0f; }
+
+    for (int g0 = 0; g0 < ng; g0 += MMVQ_TILE) {
+        const int ngt = min(MMVQ_TILE, ng - g0);
+        uint4 w_x[MMVQ_TILE], w_dm[MMVQ_TILE], w_h[MMVQ_TILE];
+#pragma unroll
+        for (int gi = 0; gi < MMVQ_TILE; gi++) {
+            const int64_t grp = rowc * ng + g0 + (gi < ngt ? gi : ngt - 1);
+            w_x[gi] = *(const uint4 *) (sg.p0 + grp * 64 + 16 * (k & 3));
+            w_dm[gi] = *(const uint4 *) (sg.p1 + grp * 16);
+            if constexpr (HB) w_h[gi] = *(const uint4 *) (sg.p2 + grp * 16);
+        }
+        __syncthreads();
+        for (int u = tid; u < NT * ngt * 8; u += blockDim.x) {
+            const int t = u / (ngt * 8), rem = u % (ngt * 8);
+            *(uint4 *) (l_qs + ((size_t) t * MMVQ_TILE * 128) + rem * 16) = *(const uint4 *) (g.aq + ((size_t) t * ng + g0) * 128 + (size_t) rem * 16);
+        }
+        for (int u = tid; u < NT * ngt; u += blockDim.x) {
+            const int t = u / ngt, gi = u % ngt;
+            if constexpr (Y81) {
+                *(uint4 *) (l_d + ((size_t) t * MMVQ_TILE + gi) * 16) = *(const uint4 *) (g.ad + ((size_t) t * ng + g0 + gi) * 16);
+                *(uint4 *) (l_s + ((size_t) t * MMVQ_TILE + gi) * 4) = *(const uint4 *) (g.abs_ + ((size_t) t * ng + g0 + gi) * 16);
+            } else *(uint2 *) (l_d + ((size_t) t * MMVQ_TILE + gi) * 8) = *(const uint2 *) (g.ad + ((size_t) t * ng + g0 + gi) * 8);
+        }
+        __syncthreads();
+        if (!live) continue;
+#pragma unroll
+        for (int gi = 0; gi < MMVQ_TILE; gi++) {
+          if (gi < ngt) {
+            const uint32_t x4[4] = { w_x[gi].x, w_x[gi].y, w_x[gi].z, w_x[gi].w };
+            const uint32_t h4[4] = { w_h[gi].x, w_h[gi].y, w_h[gi].z, w_h[gi].w };
+            int xs[4]; float dx[4], mx[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint32_t v = ((k & 4) ? (x4[b] >> 4) : x4[b]) & 0x0F0F0F0Fu;
+                if constexpr (HB) v |= ((((h4[b] >> (4 * k)) & 0xFu) * 0x00204081u) & 0x01010101u) << 4;     // bits 4k..4k+3 of qh -> bit 4 of bytes 0..3
+                xs[b] = TYPE == PI_Q5_0 ? bytes_sub((int) v, 0x10101010) : (int) v;
+                dx[b] = pi_h2f((uint16_t) (((b < 2 ? w_dm[gi].x : w_dm[gi].y) >> (16 * (b & 1))) & 0xffff));
+                mx[b] = pi_h2f((uint16_t) (((b < 2 ? w_dm[gi].z : w_dm[gi].w) >> (16 * (b & 1))) & 0xffff));
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint4 yv = *(const uint4 *) (l_qs + ((size_t) t * MMVQ_TILE + gi) * 128 + 16 * k);
+                const int y4[4] = { (int) yv.x, (int) yv.y, (int) yv.z, (int) yv.w };
+                float dy[4], sy[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if constexpr (Y81) {
+                    const float4 dv = *(const float4 *) (l_d + ((size_t) t * MMVQ_TILE + gi) * 16), sv = *(const float4 *) (l_s + ((size_t) t * MMVQ_TILE + gi) * 4);
+                    dy[0] = dv.x; dy[1] = dv.y; dy[2] = dv.z; dy[3] = dv.w; sy[0] = sv.x; sy[1] = sv.y; sy[2] = sv.z; sy[3] = sv.w;
+                } else {
+                    const uint2 dyv = *(const uint2 *) (l_d + ((size_t) t * MMVQ_TILE + gi) * 8);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) dy[b] = pi_h2f((uint16_t) (((b < 2 ? dyv.x : dyv.y) >> (16 * (b & 1))) & 0xffff));
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if constexpr (Y81) { if ((g0 + gi) * 4 + b < nbr) { const float prod = mx[b] * sy[b]; summs[t] = summs[t] + prod; } }   // the padding blocks of the last group are not part of the row
+                    acc[t] = fmaf(dx[b] * dy[b], (float) pi_dot4(xs[b], y4[b], 0), acc[t]);
+                }
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        float v = hsum8_lanes(acc[t]);
+        if constexpr (Y81) v = v + summs[t];
+        if (live && k == 0) {
+            const int64_t o = (int64_t) t * sg.M + row;
+            sg.out[o] = sg.res ? sg.res[o] + v : v;
+        }
+    }
+}
+
 // ---- sampled per-launch timing for the roofline report (bench.py): HIP events on the launch stream around every Nth
 //      launch of each kernel instantiation.  Eager launches: samples resolved by pi_kernel_timing_report after a sync.
 //      Captured launches (HIP graphs): the event pair becomes part of the graph and is re-recorded by every replay; the
@@ -694,7 +792,7 @@ static bool kt_begin(int type, int nt, hipEvent_t & ea, hipEvent_t & eb) {
 }
 // algorithmic bytes of a sampled launch: the weight matrices once + quantised activations + fp32 output (+ residual)
 static void kt_end(int type, int nt, const mmvq_launch & L, hipEvent_t ea, hipEvent_t eb) {
-    const double abytes = (double) nt * ((type == PI_Q4_0 || type == PI_Q8_0) ? (double) L.g.K / 32 * 34 : (double) L.g.K / 256 * 292);
+    const double abytes = (double) nt * ((type == PI_Q4_1 || type == PI_Q5_1) ? (double) L.g.K / 32 * 40 : (type == PI_Q4_0 || type == PI_Q8_0 || type == PI_Q5_0) ? (double) L.g.K / 32 * 34 : (double) L.g.K / 256 * 292);
     const double obytes = (double) nt * L.m_total * 4 * (L.any_res ? 2 : 1);
     std::lock_guard<std::mutex> lk(g_kt_mu);
     g_kt.push_back(pi_kt_sample{ ea, eb, type, nt <= 8 ? nt : 8, L.wbytes + abytes + obytes });
@@ -707,7 +805,15 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
     // rocprofv3 reports as the duration); events recorded around a launch would add the dispatch gap (~3 us) to every sample
     hipEvent_t ea = nullptr, eb = nullptr;
     const bool sample = kt_begin(TYPE, NT, ea, eb);
-    if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
+    if constexpr (TYPE == PI_Q4_1 || TYPE == PI_Q5_0 || TYPE == PI_Q5_1) {
+        const int64_t M = g.seg[0].M;
+        int wpb = 1;
+        while (wpb < 4 && M / (8 * wpb * 2) >= 512) wpb *= 2;
+        const unsigned grid = (unsigned) ((M + 8 * wpb - 1) / (8 * wpb));
+        const size_t lds = (size_t) NT * MMVQ_TILE * (128 + 16 + 16);
+        if (sample) hipExtLaunchKernelGGL((k_mmvq_leg<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, ea, eb, 0, g);
+        else        hipLaunchKernelGGL((k_mmvq_leg<TYPE, NT>), dim3(grid), dim3(64 * wpb), lds, stream, g);
+    } else if constexpr (TYPE == PI_Q4_0 || TYPE == PI_Q8_0) {
         const int64_t M = g.seg[0].M;
         bool launched = false;
         if constexpr (NT <= 2) {                                   // decode widths: one wave per range of groups (k_mmvq_q0r)
@@ -811,10 +917,10 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     if (n_w > MMVQ_MAX_SEG) { pi_set_error("pi_op_mul_mat_multi: n_w=%d > %d", n_w, MMVQ_MAX_SEG); return -1; }
     const pi_weight * w0 = ws[0];
     const int vdt = pi_vec_dot_type(w0->type);
-    if (vdt != PI_Q8_K && vdt != PI_Q8_0) { pi_set_error("pi_op_mul_mat: weight type %d has no quantised mat-vec", w0->type); return -1; }
+    if (vdt != PI_Q8_K && vdt != PI_Q8_0 && vdt != PI_Q8_1) { pi_set_error("pi_op_mul_mat: weight type %d has no quantised mat-vec", w0->type); return -1; }
     for (int i = 1; i < n_w; i++)
         if (ws[i]->type != w0->type || ws[i]->ne0 != w0->ne0) { pi_set_error("pi_op_mul_mat_multi: weights differ in type or width"); return -1; }
-    if (vdt == PI_Q8_0 && n_w > 1) {
+    if (vdt != PI_Q8_K && n_w > 1) {
         for (int i = 0; i < n_w; i++) { const int rc = mul_mat_multi_impl(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, nullptr, stream_); if (rc) return rc; }
         return 0;
     }
@@ -852,7 +958,9 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         if (vdt == PI_Q8_K) {
             L.g.aq = base + oq + (size_t) t0 * nbq * 256; L.g.ad = base + od + (size_t) t0 * nbq * 4; L.g.abs_ = base + ob + (size_t) t0 * nbq * 32;
         } else {
-            L.g.aq = base + oq + (size_t) t0 * nbq * 128; L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr;
+            L.g.aq = base + oq + (size_t) t0 * nbq * 128;
+            if (vdt == PI_Q8_1) { L.g.ad = base + od + (size_t) t0 * nbq * 16; L.g.abs_ = base + ob + (size_t) t0 * nbq * 16; }
+            else { L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr; }
         }
         int rc = -1;
         if (mfma) {
@@ -873,6 +981,9 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             case PI_Q5_K: rc = dispatch_nt<PI_Q5_K>(L, nt, stream); break;
             case PI_Q6_K: rc = dispatch_nt<PI_Q6_K>(L, nt, stream); break;
             case PI_Q4_0: rc = dispatch_nt<PI_Q4_0>(L, nt, stream); break;
+            case PI_Q4_1: rc = dispatch_nt<PI_Q4_1>(L, nt, stream); break;
+            case PI_Q5_0: rc = dispatch_nt<PI_Q5_0>(L, nt, stream); break;
+            case PI_Q5_1: rc = dispatch_nt<PI_Q5_1>(L, nt, stream); break;
             case PI_Q8_0: rc = dispatch_nt<PI_Q8_0>(L, nt, stream); break;
         }
         if (rc) return rc;

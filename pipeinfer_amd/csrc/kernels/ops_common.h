@@ -16,6 +16,7 @@
 //   Q6_K (210 B)  p0: [blocks][192 B] = [2 halves n][8 lanes k][8 B: ql[64n+4k], ql[64n+32+4k]] + [8 lanes][8 B: qh[4k], qh[32+4k]]   p1: scales [blocks][16]   p2: d [blocks] f16
 //   Q4_0 (18 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][4 dwords c][4 blocks b]   p1: d [groups][4] f16
 //   Q8_0 (34 B)   groups of 4 blocks, rows padded with zero blocks:  p0: [groups][8 lanes k][4 blocks b]    p1: d [groups][4] f16
+//   Q4_1 / Q5_0 / Q5_1 (20 / 22 / 24 B)  as Q4_0:  p0: [groups][4 dwords c][4 blocks b] nibbles   p1: [groups][d x 4, m x 4] f16 (m = 0 for Q5_0)   p2: qh [groups][4] u32 (0 for Q4_1)
 //   F32 / F16     native rows
 #define PI_MQ_TILE 2368      /* bytes of one (16 rows x 256 values) tile of the tile-major Q4_K copy */
 
@@ -59,12 +60,14 @@ const pi_tables & pi_get_tables();
 // planes from the same width on.  PI_MMQ_MIN_NT overrides (tuning / A-B tests; read once).
 int pi_mmq_min_nt();
 
+static inline bool pi_type_is_legacy(int t) { return t == PI_Q4_1 || t == PI_Q5_0 || t == PI_Q5_1; }
 static inline int pi_type_blck(int t) {
-    switch (t) { case PI_F32: case PI_F16: return 1; case PI_Q4_0: case PI_Q8_0: return 32; default: return 256; }
+    switch (t) { case PI_F32: case PI_F16: return 1; case PI_Q4_0: case PI_Q4_1: case PI_Q5_0: case PI_Q5_1: case PI_Q8_0: case PI_Q8_1: return 32; default: return 256; }
 }
 static inline int pi_type_size(int t) {
     switch (t) {
         case PI_F32: return 4; case PI_F16: return 2; case PI_Q4_0: return 18; case PI_Q8_0: return 34;
+        case PI_Q4_1: return 20; case PI_Q5_0: return 22; case PI_Q5_1: return 24; case PI_Q8_1: return 40;
         case PI_Q2_K: return 84; case PI_Q3_K: return 110; case PI_Q4_K: return 144; case PI_Q5_K: return 176; case PI_Q6_K: return 210; case PI_Q8_K: return 292;
     }
     return 0;

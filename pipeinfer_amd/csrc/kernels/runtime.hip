@@ -216,17 +216,35 @@ __global__ void k_repack_q8_0(const uint8_t * __restrict__ src, uint32_t * qs, u
         qs[((row * ng + g) * 8 + k) * 4 + bi] = (uint32_t) b[2 + 4 * k] | (uint32_t) b[3 + 4 * k] << 8 | (uint32_t) b[4 + 4 * k] << 16 | (uint32_t) b[5 + 4 * k] << 24;
 }
 
+// Q4_1 / Q5_0 / Q5_1: nibbles exactly like Q4_0; the per-block scalars in planes of their own (hdr = bytes before qh / qs: 4 / 2 / 4, qh present for Q5)
+__global__ void k_repack_legacy(const uint8_t * __restrict__ src, int type, uint32_t * qs, uint16_t * dm, uint32_t * qh, int64_t rows, int64_t nb, int64_t ng) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nb) return;
+    const int64_t row = i / nb, blk = i % nb, g = blk >> 2, bi = blk & 3;
+    const int tsz = type == PI_Q4_1 ? 20 : type == PI_Q5_0 ? 22 : 24;
+    const uint8_t * b = src + i * tsz;
+    const bool has_m = type != PI_Q5_0, has_h = type != PI_Q4_1;
+    dm[(row * ng + g) * 8 + bi] = (uint16_t) (b[0] | (b[1] << 8));
+    dm[(row * ng + g) * 8 + 4 + bi] = has_m ? (uint16_t) (b[2] | (b[3] << 8)) : (uint16_t) 0;
+    const uint8_t * h = b + (has_m ? 4 : 2);
+    qh[(row * ng + g) * 4 + bi] = has_h ? ((uint32_t) h[0] | (uint32_t) h[1] << 8 | (uint32_t) h[2] << 16 | (uint32_t) h[3] << 24) : 0u;
+    const uint8_t * q = h + (has_h ? 4 : 0);
+    for (int c = 0; c < 4; c++)
+        qs[((row * ng + g) * 4 + c) * 4 + bi] = (uint32_t) q[4 * c] | (uint32_t) q[4 * c + 1] << 8 | (uint32_t) q[4 * c + 2] << 16 | (uint32_t) q[4 * c + 3] << 24;
+}
+
 extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host, void * stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     const int blck = pi_type_blck(type), tsz = pi_type_size(type);
-    if (!tsz || type == PI_Q8_K) { pi_set_error("pi_weight_upload: unsupported tensor type %d", type); return nullptr; }
+    if (!tsz || type == PI_Q8_K || type == PI_Q8_1) { pi_set_error("pi_weight_upload: unsupported tensor type %d", type); return nullptr; }
     if (ne0 % blck) { pi_set_error("pi_weight_upload: ne0=%lld not a multiple of the block size %d", (long long) ne0, blck); return nullptr; }
     pi_weight * w = new pi_weight();
     w->type = type; w->ne0 = ne0; w->ne1 = ne1; w->nb = ne0 / blck; w->ng = (w->nb + 3) / 4;
     const int64_t nblocks = w->nb * ne1;
     w->nbytes = (size_t) nblocks * tsz;
-    const bool small = type == PI_Q4_0 || type == PI_Q8_0;
-    const size_t alloc = small ? (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32) + (size_t) ne1 * w->ng * 8 + 512
+    const bool legacy = pi_type_is_legacy(type);
+    const bool small = type == PI_Q4_0 || type == PI_Q8_0 || legacy;
+    const size_t alloc = small ? (size_t) ne1 * w->ng * 4 * (type == PI_Q8_0 ? 32 : 16) + (size_t) ne1 * w->ng * (legacy ? 32 : 8) + 1024
                        : type == PI_Q3_K ? (size_t) nblocks * (96 + 16 + 2) + 512 : w->nbytes + 512;        // (Q2_K: 64 + 16 + 4 = its 84 bytes)
     if (hipMalloc(&w->base, alloc) != hipSuccess) { pi_set_error("pi_weight_upload: hipMalloc(%zu) failed", alloc); delete w; return nullptr; }
     uint8_t * base = (uint8_t *) w->base;
@@ -253,10 +271,13 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
         w->p1 = base + nblocks * 192; w->p2 = w->p1 + nblocks * 16;
         hipLaunchKernelGGL(k_repack_q6_K, dim3(grid), dim3(threads), 0, stream, staging, base, (uint8_t *) w->p1, (uint16_t *) w->p2, nblocks);
     } else {
-        const size_t qbytes = (size_t) ne1 * w->ng * 4 * (type == PI_Q4_0 ? 16 : 32);
+        const size_t qbytes = (size_t) ne1 * w->ng * 4 * (type == PI_Q8_0 ? 32 : 16);
         w->p1 = base + ((qbytes + 255) & ~(size_t) 255);
         (void) hipMemsetAsync(base, 0, alloc, stream);                    // zero blocks pad the last group of every row
-        if (type == PI_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
+        if (legacy) {
+            w->p2 = w->p1 + (((size_t) ne1 * w->ng * 16 + 255) & ~(size_t) 255);
+            hipLaunchKernelGGL(k_repack_legacy, dim3(grid), dim3(threads), 0, stream, staging, type, (uint32_t *) base, (uint16_t *) w->p1, (uint32_t *) w->p2, ne1, w->nb, w->ng);
+        } else if (type == PI_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
         else                 hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
     }
     w->mq = nullptr; w->mq_base = nullptr;
@@ -308,7 +329,8 @@ extern "C" int pi_weight_type(const pi_weight * w) { return w->type; }
 
 extern "C" int pi_vec_dot_type(int t) {
     switch (t) {
-        case PI_Q4_0: case PI_Q8_0: return PI_Q8_0;
+        case PI_Q4_0: case PI_Q5_0: case PI_Q8_0: return PI_Q8_0;
+        case PI_Q4_1: case PI_Q5_1: return PI_Q8_1;                   // type_traits[].vec_dot_type (ggml.c:436-470)
         case PI_Q2_K: case PI_Q3_K: case PI_Q4_K: case PI_Q5_K: case PI_Q6_K: return PI_Q8_K;
         case PI_F16: return PI_F16; case PI_F32: return PI_F32;
     }
@@ -321,10 +343,11 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t) 255; }
 //   Q8_K: qs [n_tok][K/256][8 lanes k][8 dwords = (j, lo/hi)]   byte of value e: k*32 + ((e>>6)*2 + ((e>>5)&1))*4 + (e&3), k = (e&31)>>2
 //         d  [n_tok][K/256] f32       bsums [n_tok][K/256][16] int16
 //   Q8_0: qs [n_tok][groups of 4 blocks][8 lanes k][4 blocks b] dwords (zero padded)     d [n_tok][groups][4] f16
+//   Q8_1: qs as Q8_0     d [n_tok][groups][4] f32     s [n_tok][groups][4] f32 (= d * sum of the block's quants, the third plane)
 extern "C" void pi_q8_layout(int vdt, int64_t k, int n_tok, size_t * off_qs, size_t * off_d, size_t * off_bsums) {
     size_t qs, d;
     if (vdt == PI_Q8_K) { qs = align256((size_t) n_tok * k); d = align256((size_t) n_tok * (k / 256) * 4); }
-    else { const size_t ng = (size_t) (k / 32 + 3) / 4; qs = align256((size_t) n_tok * ng * 128); d = align256((size_t) n_tok * ng * 8); }
+    else { const size_t ng = (size_t) (k / 32 + 3) / 4; qs = align256((size_t) n_tok * ng * 128); d = align256((size_t) n_tok * ng * (vdt == PI_Q8_1 ? 16 : 8)); }
     if (off_qs) *off_qs = 0;
     if (off_d) *off_d = qs;
     if (off_bsums) *off_bsums = qs + d;
@@ -351,6 +374,7 @@ extern "C" void pi_q8_frag_layout(int64_t k, int n_tok, size_t * off_fa, size_t 
 extern "C" size_t pi_q8_nbytes(int vdt, int64_t k, int n_tok) {
     size_t oq, od, ob;
     pi_q8_layout(vdt, k, n_tok, &oq, &od, &ob);
+    if (vdt == PI_Q8_1) return ob + (ob - od);                   // the s plane has the size of the d plane
     if (vdt != PI_Q8_K) return ob;
     size_t oa;
     pi_q8_frag_layout(k, n_tok, nullptr, nullptr, &oa);

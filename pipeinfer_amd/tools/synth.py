@@ -44,7 +44,7 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None, layers=None):
     hd = n_embd // n_head
     n_gqa = hd * n_head_kv
     ftype = ftype.lower()
-    base = {"q4_0": G.T_Q4_0, "q8_0": G.T_Q8_0, "q2_k": G.T_Q2_K, "q3_k_m": G.T_Q3_K, "q4_k_m": G.T_Q4_K, "q4_k_s": G.T_Q4_K, "q5_k_m": G.T_Q5_K, "q5_k_s": G.T_Q5_K,
+    base = {"q4_0": G.T_Q4_0, "q4_1": G.T_Q4_1, "q5_0": G.T_Q5_0, "q5_1": G.T_Q5_1, "q8_0": G.T_Q8_0, "q2_k": G.T_Q2_K, "q3_k_m": G.T_Q3_K, "q4_k_m": G.T_Q4_K, "q4_k_s": G.T_Q4_K, "q5_k_m": G.T_Q5_K, "q5_k_s": G.T_Q5_K,
             "q6_k": G.T_Q6_K, "f16": G.T_F16, "f32": G.T_F32}[ftype]
     kq = ftype.startswith(("q2_k", "q3_k", "q4_k", "q5_k", "q6_k"))
     is_70b = arch == "llama" and n_layer == 80 and n_head != n_head_kv    # llama.cpp MODEL_70B detection (n_layer 80)

@@ -25,6 +25,9 @@ MODELS = [  # (file stem, spec, ftype, seed)
     ("tiny_falcon40_q4_k_m", "tiny-falcon40", "q4_k_m", 15),   # 40B-style: GQA, two norms, Q5_K qkv
     ("tiny_llama_q3_k_m", "tiny-llama", "q3_k_m", 16),         # Q3_K / Q4_K / Q5_K / Q6_K mixture of llama.cpp:7919-7961
     ("tiny_llama_q2_k", "tiny-llama", "q2_k", 17),             # Q2_K / Q3_K / Q6_K mixture (llama.cpp:7918, 7936, 7958, 7976)
+    ("tiny_llama_q5_1", "tiny-llama", "q5_1", 18),             # legacy 32-blocks with min and fifth bit (x Q8_1 activations), Q6_K head
+    ("tiny_llama_q5_0", "tiny-llama", "q5_0", 19),             # signed 5-bit (x Q8_0)
+    ("tiny_llama_q4_1", "tiny-llama", "q4_1", 20),
 ]
 
 
@@ -179,6 +182,7 @@ if __name__ == "__main__":
     assert O.ref() is not None, "needs oracle/_ref (make -C oracle ref)"
     if sys.argv[1:] == ["legacy"]:
         kernel_vectors_legacy()
+        model_vectors(only=["tiny_llama_q5_1", "tiny_llama_q5_0", "tiny_llama_q4_1"])
     elif sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
         model_vectors(only=["tiny_llama_q3_k_m"])

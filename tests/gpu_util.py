@@ -64,6 +64,10 @@ def q8_planes(lib, vdt, k, n_tok, dev):
     ng = (nb + 3) // 4
     raw = dev.get(np.int8, (n_tok, ng, 8, 4, 4), oq.value, n_tok * ng * 128)            # [group][k][block][byte]
     qs = raw.transpose(0, 1, 3, 2, 4).reshape(n_tok, ng * 128)[:, :k]
+    if vdt == 9:                                                                         # Q8_1: d and s as floats
+        d = dev.get(np.float32, (n_tok, ng * 4), od.value, n_tok * ng * 4)[:, :nb]
+        sm = dev.get(np.float32, (n_tok, ng * 4), ob.value, n_tok * ng * 4)[:, :nb]
+        return qs, d, sm
     d = dev.get(np.uint16, (n_tok, ng * 4), od.value, n_tok * ng * 4)[:, :nb]
     return qs, d, None
 
@@ -80,6 +84,12 @@ def q8_as_ref_blocks(vdt, qs, d, bs):
         out[:, :, 260:292] = bs.reshape(n_tok, nb, 16).view(np.uint8).reshape(n_tok, nb, 32)
         return out.reshape(n_tok, -1)
     nb = k // 32
+    if vdt == 9:                                                                         # block_q8_1: float d, float s, 32 quants
+        out = np.zeros((n_tok, nb, 40), np.uint8)
+        out[:, :, 0:4] = d.reshape(n_tok, nb, 1).view(np.uint8).reshape(n_tok, nb, 4)
+        out[:, :, 4:8] = np.ascontiguousarray(bs).reshape(n_tok, nb, 1).view(np.uint8).reshape(n_tok, nb, 4)
+        out[:, :, 8:40] = qs.reshape(n_tok, nb, 32).view(np.uint8)
+        return out.reshape(n_tok, -1)
     out = np.zeros((n_tok, nb, 34), np.uint8)
     out[:, :, 0:2] = d.reshape(n_tok, nb, 1).view(np.uint8).reshape(n_tok, nb, 2)
     out[:, :, 2:34] = qs.reshape(n_tok, nb, 32).view(np.uint8)

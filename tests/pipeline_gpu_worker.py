@@ -14,7 +14,7 @@ from pipeinfer_amd import llama as LL, pipeline as P          # noqa: E402
 from tests import scenarios as S                              # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17}
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20}
 
 
 class InProcessPipeline:

@@ -18,7 +18,8 @@ from tests import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-QTYPES = [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K]
+LEGACY = [O.Q4_1, O.Q5_0, O.Q5_1]
+QTYPES = [O.Q4_0, O.Q8_0, O.Q2_K, O.Q3_K, O.Q4_K, O.Q5_K, O.Q6_K] + LEGACY
 
 
 @pytest.fixture(scope="module")
@@ -62,11 +63,11 @@ def gpu_mul_mat(lib, U, t, w, k, rows, act, residual=None):
     return out.get(np.float32, (n_tok, rows))
 
 
-@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0])
+@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0, O.Q8_1])
 def test_activation_quantiser_bytes_identical(gpu, vdt):
     lib, U = gpu
     o = O.Impl("oracle")
-    for k in (256, 1024, 4096, 11008 // 256 * 256) + ((4544, 18176) if vdt == O.Q8_0 else ()):
+    for k in (256, 1024, 4096, 11008 // 256 * 256) + ((4544, 18176) if vdt != O.Q8_K else ()):
         x = np.stack([signal(k, s) * (0.01 if s % 2 else 3.0) for s in range(5)])
         x[4, :256] = 0.0                              # all-zero block
         x[3, 10] = 2.5; x[3, 11] = -2.5               # equal |x| with opposite signs: first one fixes the sign of the scale
@@ -76,11 +77,11 @@ def test_activation_quantiser_bytes_identical(gpu, vdt):
             assert np.array_equal(got[t], o.quantize_act(vdt, x[t])), (k, t)
 
 
-@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0])
+@pytest.mark.parametrize("vdt", [O.Q8_K, O.Q8_0, O.Q8_1])
 def test_activation_quantiser_golden(gpu, vdt):
     lib, U = gpu
-    K = np.load(os.path.join(GOLD, "kernels.npz"))
-    for t in ([O.Q4_K, O.Q5_K, O.Q6_K] if vdt == O.Q8_K else [O.Q4_0, O.Q8_0]):
+    K = np.load(os.path.join(GOLD, "kernels_legacy.npz" if vdt == O.Q8_1 else "kernels.npz"))
+    for t in ([O.Q4_K, O.Q5_K, O.Q6_K] if vdt == O.Q8_K else [O.Q4_1, O.Q5_1] if vdt == O.Q8_1 else [O.Q4_0, O.Q8_0]):
         name = O.TYPE_NAMES[t]
         act, qact = K[f"{name}_act"], K[f"{name}_qact"]
         q8 = gpu_quantize(lib, U, vdt, act)
@@ -92,7 +93,7 @@ def test_activation_quantiser_golden(gpu, vdt):
 def test_mul_mat_golden_blocks(gpu, t):
     """weights quantised by the reference's own quantiser + reference vec_dot results (tests/golden/kernels.npz)"""
     lib, U = gpu
-    K = np.load(os.path.join(GOLD, {O.Q3_K: "kernels_q3k.npz", O.Q2_K: "kernels_q2k.npz"}.get(t, "kernels.npz")))
+    K = np.load(os.path.join(GOLD, {O.Q3_K: "kernels_q3k.npz", O.Q2_K: "kernels_q2k.npz", O.Q4_1: "kernels_legacy.npz", O.Q5_0: "kernels_legacy.npz", O.Q5_1: "kernels_legacy.npz"}.get(t, "kernels.npz")))
     name = O.TYPE_NAMES[t]
     blocks, act, dots = K[f"{name}_blocks"], K[f"{name}_act"], K[f"{name}_dots"]
     rows, k = blocks.shape[0], act.shape[1]
@@ -140,8 +141,10 @@ def test_mul_mat_integer_sums_exact(gpu, t):
     rng = np.random.default_rng(99 + t)
     blocks = synth.random_blocks(t, rows * k, rng, 0.05).reshape(rows * (k // O.BLCK[t]), O.TSIZE[t]).copy()
     one = np.array([0x3C00], np.uint16).view(np.uint8)          # f16 1.0
-    if t in (O.Q4_0, O.Q8_0):
+    if t in (O.Q4_0, O.Q8_0, O.Q5_0):
         blocks[:, 0:2] = one
+    elif t in (O.Q4_1, O.Q5_1):
+        blocks[:, 0:2] = one; blocks[:, 2:4] = one                                       # d = m = 1: summs = sum of the block sums, an integer
     elif t in (O.Q4_K, O.Q5_K):
         blocks[:, 0:2] = one; blocks[:, 2:4] = one
     elif t == O.Q2_K:

@@ -10,7 +10,7 @@ from tests import scenarios as S
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 K = np.load(os.path.join(GOLD, "kernels.npz"))
-MODELS = ["tiny_llama_q4_k_m", "tiny_llama_q4_0", "tiny_llama_b_q4_k_m", "tiny_falcon_q4_0", "tiny_falcon40_q4_k_m", "tiny_llama_q3_k_m", "tiny_llama_q2_k"]
+MODELS = ["tiny_llama_q4_k_m", "tiny_llama_q4_0", "tiny_llama_b_q4_k_m", "tiny_falcon_q4_0", "tiny_falcon40_q4_k_m", "tiny_llama_q3_k_m", "tiny_llama_q2_k", "tiny_llama_q5_1", "tiny_llama_q5_0", "tiny_llama_q4_1"]
 
 
 def bits(a):
@@ -69,7 +69,7 @@ def test_model_scenarios_golden(stem):
     g = np.load(os.path.join(GOLD, stem + ".npz"))
     path = os.path.join(GOLD, stem + ".gguf")
     m = O.OracleModel(path, n_ctx=128, max_seq=8)
-    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17}[stem]
+    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20}[stem]
     outs = S.run_scenario(S.scenario_spec_like(m.n_vocab, seed=seed), m)
     for i, lg in enumerate(outs):
         assert np.allclose(lg, g[f"spec_like_{i}"], rtol=0, atol=1e-5), (stem, i, np.abs(lg - g[f"spec_like_{i}"]).max())
