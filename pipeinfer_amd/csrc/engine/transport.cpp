@@ -26,6 +26,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_set>
 
@@ -285,7 +286,7 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
     tp->device = P->device; if (P->timeout_ms > 0) tp->timeout_ms = P->timeout_ms;
     if (!map_segment(tp, *P)) { pipeinfer_transport_close(tp); return nullptr; }
     shm_layout * L = tp->L;
-    if (P->device < 0) L->device_fail.store(1);                                 // a rank without a GPU: host rings for everybody
+    if (P->device < 0 || getenv("PIPEINFER_TRANSPORT_HOST")) L->device_fail.store(1);   // a rank without a GPU (or the test switch): host rings for everybody
     L->st[tp->rank].joined.store(1, std::memory_order_release);
     for (int r = 0; r < tp->world; r++)
         if (!tp->wait_for([&] { return L->st[r].joined.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never joined the transport"); pipeinfer_transport_close(tp); return nullptr; }

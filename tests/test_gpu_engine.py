@@ -242,11 +242,14 @@ def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
     assert "PIPELINE-OK" in r.stdout
 
 
-@pytest.mark.parametrize("tgt,dft,seed,ranges", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3"), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 11, "0-1,1-2")])
-def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt, dft, seed, ranges):
+@pytest.mark.parametrize("tgt,dft,seed,ranges,host_rings", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", False), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 11, "0-1,1-2", False),
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", True)])
+def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt, dft, seed, ranges, host_rings):
     """head + two HIP stages as three processes on this one GPU (tests/transport_gpu_worker.py): run headers, metadata, results and cancel
     notes through the shared segment, activations as peer stores into the next stage's HBM ring (hipIpc).  The accepted tokens must be
-    the reference greedy continuation; every started run comes back; stages only skip what the head cancelled."""
+    the reference greedy continuation; every started run comes back; stages only skip what the head cancelled.
+    host_rings: the fall-back every rank takes together when the peer mapping is not usable (PIPEINFER_TRANSPORT_HOST forces it): the HIP stages then copy
+    their activations through rings in the shared segment."""
     import json, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as sk:
@@ -254,17 +257,20 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
     out = tmp_path / "verdict.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "transport_gpu_worker.py"), str(out), tgt, dft, str(seed), ranges]
-    r = subprocess.run(cmd, env=dict(os.environ, PYTHONPATH=root, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, PYTHONPATH=root, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if host_rings:
+        env["PIPEINFER_TRANSPORT_HOST"] = "1"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     v = json.loads(out.read_text())
     print("transport:", {k: v[k] for k in ("device_mode", "stages")})
-    assert v["device_mode"], "the peer-store path was not usable: " + r.stderr[-2000:]
+    assert v["device_mode"] == (not host_rings), "the peer-store path was not usable: " + r.stderr[-2000:]
     for t in v["trials"]:
         assert t["out"] == t["want"], t
     last = v["trials"][-1]
     assert last["skipped"] <= last["cancel_notes"] <= sum(t["n_runs_canceled"] for t in v["trials"])
     assert any(t["n_runs_spec"] > 0 for t in v["trials"])
-    assert all(s["device_mode"] for s in v["stages"]) and v["stages"][0]["runs"] > 0 and v["stages"][1]["runs"] > 0
+    assert all(s["device_mode"] == (not host_rings) for s in v["stages"]) and v["stages"][0]["runs"] > 0 and v["stages"][1]["runs"] > 0
 
 
 @pytest.mark.parametrize("tgt,dft,n_layer", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 3), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 2), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0", 2)])
