@@ -338,9 +338,10 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     g.dyn = dyn_dev;
     const int rows = n_tok * (n_head / n_head_kv);
     // rows per workgroup: K/V are re-read (from L2) by every chunk of a kv head, so chunks stay as large as the launch can
-    // afford while still putting >= ~128 workgroups on the 256 CUs
+    // afford while still putting up to one workgroup on each of the 256 CUs
+    constexpr int wg_max = 256;          // (128 -> 256: a 4-token verify batch of the 70B model gets one row per workgroup, 16.4 -> ~11 us per layer; +1 % on the synchronous schedule)
     int rw = 1;
-    while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > 128) rw *= 2;
+    while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > wg_max) rw *= 2;
     static const int rw_env = getenv("PI_ATT_RW") ? atoi(getenv("PI_ATT_RW")) : 0;      // tuning / tests
     if (rw_env == 1 || rw_env == 2 || rw_env == 4 || rw_env == 8) rw = rw_env;
     // (the single-row instance also has 8 KiB of static LDS)
