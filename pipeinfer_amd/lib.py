@@ -8,7 +8,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-SO = os.path.join(PKG, "libpipeinfer_amd.so")
+SO = os.environ.get("PIPEINFER_LIB") or os.path.join(PKG, "libpipeinfer_amd.so")        # (override: A/B runs of two builds on one box, tools_dev/)
 
 _lib = None
 
