@@ -412,10 +412,12 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     const int words = (ctx->n_ctx + 31) / 32;                                   // fixed row stride of the visibility bitmap
     const size_t meta_bytes = (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4;
     pi_run * run = acquire_run(ctx, n_tokens, meta_bytes);
-    if (!run) { ctx->last_error = "out of pinned host memory"; return nullptr; }
+    // (a run that cannot be started gives the cells find_slot just allotted back: nothing was or will be written to them)
+    auto give_back = [&]() { ctx->cells->release_cells(kv_head, n_tokens); };
+    if (!run) { ctx->last_error = "out of pinned host memory"; give_back(); return nullptr; }
     run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us(); run->sink = nullptr;
     // (a segmented context's stream belongs to its feeder thread: the begin event is recorded there, in stream order with the run's segments)
-    if (!ctx->remote && ctx->seg_layers == 0 && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; ctx->pool.push_back(run); return nullptr; }
+    if (!ctx->remote && ctx->seg_layers == 0 && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; give_back(); ctx->pool.push_back(run); return nullptr; }
     // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
     run->want_logits.assign(n_tokens, 1);
     run->last_only = false;
@@ -438,7 +440,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
             run->launched = ok;
             ctx->stat_calls++;
         }
-        if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); ctx->pool.push_back(run); return nullptr; }
+        if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); give_back(); ctx->pool.push_back(run); return nullptr; }
         ctx->inflight.push_back(run);
         rc = 0;
         return run;
@@ -476,7 +478,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     if (!ok) {
         // the cells find_slot handed to this run go back: nothing was (or will be) written to them
         fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str());
-        for (int i = 0; i < n_tokens; i++) ctx->cells->seq_rm(-1, pos[i], pos[i] + 1);
+        give_back();
         urgent_end(ctx);
         ctx->pool.push_back(run);
         return nullptr;

@@ -118,6 +118,16 @@ void kv_cells::seq_rm(int seq_id, int p0, int p1) {
     if (new_head != (uint32_t) size_ && new_head < (uint32_t) head_) head_ = (int) new_head;
 }
 
+void kv_cells::release_cells(int first, int n) {
+    for (int i = first; i < first + n && i < size_; i++) {
+        if (i < 0) continue;
+        clear_cell(i);
+        if (pos_[i] >= 0) used_--;
+        pos_[i] = -1;
+    }
+    if (first >= 0 && first < head_) head_ = first;
+}
+
 void kv_cells::seq_cp(int src, int dst, int p0, int p1) {
     if (p0 < 0) p0 = 0;
     if (p1 < 0) p1 = INT_MAX;

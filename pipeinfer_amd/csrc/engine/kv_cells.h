@@ -36,6 +36,8 @@ public:
     void seq_rm(int seq_id, int p0, int p1);
     void seq_cp(int src, int dst, int p0, int p1);
     void seq_keep(int seq_id);
+    // gives the cells [first, first + n) back exactly (a run that was allotted them could not be started): no other cell is touched
+    void release_cells(int first, int n);
 
     // == for (s = first; s <= last; s++) seq_rm(s, p0, p1)
     void seq_rm_range(int first, int last, int p0, int p1);
