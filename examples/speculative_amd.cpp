@@ -42,6 +42,7 @@ int main(int argc, char ** argv) {
         else if (a == "-b" || a == "--batch-size")       n_batch = atoi(next());
         else if (a == "--ignore-eos")                    sp.ignore_eos = 1;
         else if (a == "--target-only")                   sp.mode = 2;
+        else if (a == "--orig" || a == "--synchronous")  sp.mode = 1;       // the schedule of examples/speculative_orig: draft a tree, verify it in one target batch
         else if (a == "--results")                       results_path = next();
         else { fprintf(stderr, "unknown argument: %s\n", a.c_str()); usage(argv[0]); return 2; }
     }
