@@ -287,7 +287,7 @@ def bench_main(args, rank, world):
                 return l0 <= int(name.split(".")[1]) < l1
             return (is_first and name.startswith("token_embd")) or (is_last and (name.startswith("output") or name.startswith("output_norm")))
         path = stage_file(f"stage{si}", mine)
-        backend = HipStage(path, l0, l1, is_first, is_last, args.n_ctx, 512, device_index=local, seg_layers=int(os.environ.get("PIPEINFER_SEG_LAYERS", "4")))
+        backend = HipStage(path, l0, l1, is_first, is_last, args.n_ctx, 512, device_index=local, seg_layers=int(os.environ.get("PIPEINFER_SEG_LAYERS", str(max(1, (l1 - l0 + 3) // 4)))))     # four segments per stage run: a cancelled run stops within a quarter of the stage
     dist.barrier()                                  # (stage files of a 70B target take a while to write: open the transport together)
     tp = Transport(job_name(), rank, world, n_embd, n_vocab, 512, args.n_ctx, device=local)
     if rank == 0:
