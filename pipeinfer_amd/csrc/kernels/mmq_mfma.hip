@@ -49,7 +49,7 @@ int pi_mmq_min_nt() {
     static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 3; return n < 2 ? 2 : n; }();
     return v;
 }
-bool pi_mmq_supported(int type) { return type == PI_Q4_K; }
+bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K; }
 
 static __device__ __forceinline__ pi_half2 h2_from_bits(uint32_t u) { return __builtin_bit_cast(pi_half2, u); }
 static __device__ __forceinline__ uint32_t h2_bits(pi_half2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -66,14 +66,16 @@ static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { retu
 
 template <int S> struct mq_q { uint4 v[2 / S]; };
 template <> struct mq_q<4> { uint2 v[1]; };
-template <int TYPE, int S> struct mq_w { uint32_t dd, rec; mq_q<S> q; };                  // one lane's share of one block (Q4_K): (d, dmin), its scales / mins record, 8 / S quant dwords
+template <int TYPE, int S> struct mq_w { uint32_t dd, rec; mq_q<S> q; mq_q<S> h; };       // one lane's share of one block: (d, dmin), its scales / mins record, 8 / S quant dwords (Q5_K: + as many dwords of fifth bits)
 
 template <int TYPE, int S, int R, int TB, bool NT8>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
-    static_assert(TYPE == PI_Q4_K, "types are added one by one");
+    static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K, "types are added one by one");
+    constexpr bool Q5 = TYPE == PI_Q5_K;
+    constexpr uint32_t TILE = Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q5 ? 832 : 320;
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = S == 1 ? 4 : 3;  // LW: vector loads per block of weights
+    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
     constexpr int FRAG = NT8 ? 512 : 1024, MQ_BLK_LDS = 8 * FRAG + 1024, NP = NT8 ? 5 : 9;   // NP: DMA pieces of 1 KB per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
@@ -111,17 +113,22 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         for (int i = 0; i < 4; i++) accm[cc][i] = 0.0f;
 
     // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = PI_MQ_TILE contiguous bytes
-    const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * PI_MQ_TILE;
-    const uint32_t dd_off = 4 * r, rec_off = 64 + 4 * lane, q_off = 320 + 16 * lane + (S == 1 ? 0 : S == 2 ? 1024 * s : 1024 * (s >> 1) + 8 * (s & 1));
+    const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * TILE;
+    const uint32_t dd_off = 4 * r, rec_off = 64 + 4 * lane, q_off = QOFF + 16 * lane + (S == 1 ? 0 : S == 2 ? 1024 * s : 1024 * (s >> 1) + 8 * (s & 1));
+    const uint32_t h_off = 320 + 32 * r + (S == 1 ? 0 : S == 2 ? 16 * s : 8 * s);       // Q5_K: the row's qh bytes 4k..4k+3 of this wave's accumulator lanes (the same for the four K-slices)
     auto load_w = [&](int b, mq_w<TYPE, S> & W) __attribute__((always_inline)) {
-        const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * (uint32_t) PI_MQ_TILE;     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
+        const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * TILE;     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
         W.dd = *(const uint32_t *) (wbase + (bo + dd_off));
         W.rec = *(const uint32_t *) (wbase + (bo + rec_off));
-        if constexpr (S == 4) W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off));
+        if constexpr (S == 4) { W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off)); if constexpr (Q5) W.h.v[0] = *(const uint2 *) (wbase + (bo + h_off)); }
         else {
 #pragma unroll
-            for (int i = 0; i < 2 / S; i++) W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + 1024 * i));
+            for (int i = 0; i < 2 / S; i++) { W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + 1024 * i)); if constexpr (Q5) W.h.v[i] = *(const uint4 *) (wbase + (bo + h_off + 16 * i)); }
         }
+    };
+    auto hdword = [&](const mq_w<TYPE, S> & W, int kk) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (S == 4) return kk ? W.h.v[0].y : W.h.v[0].x;
+        else { const uint4 v = W.h.v[kk >> 2]; return (kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w; }
     };
     auto qdword = [&](const mq_w<TYPE, S> & W, int kk) __attribute__((always_inline)) -> uint32_t {
         if constexpr (S == 4) return kk ? W.q.v[0].y : W.q.v[0].x;
@@ -171,10 +178,20 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         for (int kk = 0; kk < KS; kk++) {
             const uint32_t q = qdword(W, kk), qh = q >> 8;
             uint4 bw;
+            if constexpr (Q5) {
+                // fifth bits: bit 2gq (low-nibble sub-block) and 2gq+1 (high) of the row's qh bytes 4k..4k+3; 1024 + n + 16 b keeps b at mantissa bit 4 (low
+                // nibbles) and 1024 + 16 (n + 16 b) at bit 8 (high): <= 63 * 31 = 1953, still exact in f16
+                const uint32_t t = hdword(W, kk) >> (2 * gq), th = t >> 8;
+                bw.x = pk_fma((q & 0x000F000Fu) | magic | ((t & 0x00010001u) << 4), S1, C1);
+                bw.y = pk_fma((qh & 0x000F000Fu) | magic | ((th & 0x00010001u) << 4), S1, C1);
+                bw.z = pk_fma((q & 0x00F000F0u) | magic | ((t & 0x00020002u) << 7), S2, C2);
+                bw.w = pk_fma((qh & 0x00F000F0u) | magic | ((th & 0x00020002u) << 7), S2, C2);
+            } else {
             bw.x = pk_fma((q & 0x000F000Fu) | magic, S1, C1);                                              // sub-block 2gq:   bytes (i0, i2)
             bw.y = pk_fma((qh & 0x000F000Fu) | magic, S1, C1);                                             //                  bytes (i1, i3)
             bw.z = pk_fma((q & 0x00F000F0u) | magic, S2, C2);                                              // sub-block 2gq+1
             bw.w = pk_fma((qh & 0x00F000F0u) | magic, S2, C2);
+            }
             const uint4 af = *(const uint4 *) (blk + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));   // tokens' fragment of accumulator lane k
             const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
             if (dbg & 8) { acc[kk][0] += c[0] + c[1] + c[2] + c[3]; continue; }
@@ -190,6 +207,16 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         float nd[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) nd[i] = -dy[i] * dminx;
+        if constexpr (Q5) {
+            // Q5_K (ggml-quants.c:5998-6002): ONE scalar chain, summs += dmin * (float) sum_j m_j * (bs[2j] + bs[2j+1]) — a multiply, then an add; every K-slice
+            // contributes to the one product, so B is unmasked.  Wave 0 of the row group carries it.
+            if (s == 0) {
+                const uint4 bm = make_uint4(M0, M1, 0u, 0u);
+                const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const float prod = nd[i] * cm[i]; accm[0][i] = accm[0][i] + prod; }
+            }
+        } else {
 #pragma unroll
         for (int cc = 0; cc < CS; cc++) {
             const int c = s * CS + cc;
@@ -197,6 +224,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; i++) accm[cc][i] = fmaf(nd[i], cm[i], accm[cc][i]);                     // the products are integers below 2^24: exact in any form
+        }
         }
     };
 
@@ -266,7 +294,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             for (int k = 0; k < 8; k++) a[k] = F[(k * 16 + rr) * 17 + t];
             float v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
             const float m0 = FM[(0 * 16 + rr) * 17 + t], m1 = FM[(1 * 16 + rr) * 17 + t], m2 = FM[(2 * 16 + rr) * 17 + t], m3 = FM[(3 * 16 + rr) * 17 + t];
-            v = v + ((m0 + m2) + (m1 + m3));
+            v = Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
             if (rr < rows && t < nt) {
                 if (sg.store) X[rr * 16 + t] = v;
                 else {
@@ -322,16 +350,21 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
     else           mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
 }
 
-static void mmq_dispatch(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+template <int TYPE>
+static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int T8 = TYPE == PI_Q5_K ? 2 : 4;                 // blocks per tile at <= 8 tokens (Q5_K: the ring carries the fifth bits too)
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
-        case 17: mmq_go<PI_Q4_K, 1, 7, 2, 4>(g, groups, stream, ea, eb); break;
-        case 18: mmq_go<PI_Q4_K, 1, 8, 2, 4>(g, groups, stream, ea, eb); break;
-        case 14: mmq_go<PI_Q4_K, 1, 4, 2, 4>(g, groups, stream, ea, eb); break;
-        case 22: mmq_go<PI_Q4_K, 2, 2, 2, 4>(g, groups, stream, ea, eb); break;
-        case 24: mmq_go<PI_Q4_K, 2, 4, 2, 4>(g, groups, stream, ea, eb); break;
-        case 41: mmq_go<PI_Q4_K, 4, 1, 2, 4>(g, groups, stream, ea, eb); break;
-        default: mmq_go<PI_Q4_K, 4, 2, 2, 4>(g, groups, stream, ea, eb); break;
+        case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
+        case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;
+        case 14: mmq_go<TYPE, 1, 4, 2, T8>(g, groups, stream, ea, eb); break;
+        case 22: mmq_go<TYPE, 2, 2, 2, T8>(g, groups, stream, ea, eb); break;
+        case 24: mmq_go<TYPE, 2, 4, 2, T8>(g, groups, stream, ea, eb); break;
+        case 41: mmq_go<TYPE, 4, 1, 2, 4>(g, groups, stream, ea, eb); break;
+        default: mmq_go<TYPE, 4, 2, 2, 4>(g, groups, stream, ea, eb); break;
     }
+}
+static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (type == PI_Q5_K) mmq_dispatch_t<PI_Q5_K>(g, groups, cfg, stream, ea, eb); else mmq_dispatch_t<PI_Q4_K>(g, groups, cfg, stream, ea, eb);
 }
 static const int mmq_cfgs[] = { 17, 18, 14, 22, 24, 41, 42 };
 // dynamic-LDS limits of every instance, set once and outside any stream capture (a launch inside a captured graph must not change function attributes)
@@ -339,7 +372,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     static bool done = false;
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
-    for (int cfg : mmq_cfgs) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int type : { PI_Q4_K, PI_Q5_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
     done = true;
     PI_CHECK_LAUNCH();
     return 0;
@@ -353,7 +386,7 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
         if (i < L.nseg) { g.seg[i].wave0 = groups; groups += (g.seg[i].M + 15) / 16; }
         else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
     }
-    if (type != PI_Q4_K) { pi_set_error("pi_mmq_launch: weight type %d has no MFMA kernel", type); return -1; }
+    if (!pi_mmq_supported(type)) { pi_set_error("pi_mmq_launch: weight type %d has no MFMA kernel", type); return -1; }
     static const int dbg_env = getenv("PI_MMQ_DBG") ? atoi(getenv("PI_MMQ_DBG")) : 0;
     g.dbg = dbg_env;
     // (waves per row group, row groups per workgroup).  One wave per row group needs the fewest instructions per weight byte (the block scalars
@@ -361,12 +394,12 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
     // 8 waves that share the staged activations, while keeping >= 256 workgroups.  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
     static const int cfg_env = getenv("PI_MMQ_CFG") ? atoi(getenv("PI_MMQ_CFG")) : 0;
     int cfg;
-    if (groups >= 1536) cfg = groups % 7 == 0 || groups >= 2048 ? 17 : 14;
+    if (groups >= 1536) cfg = groups <= 7 * 256 ? 17 : 18;           // S = 1: the fewest row groups per workgroup (7 or 8) that still fit the launch into one round of 256 workgroups
     else if (groups >= 768) cfg = 24;
     else if (groups >= 384) cfg = 42;
     else cfg = 41;
     if (cfg_env) cfg = cfg_env;
-    mmq_dispatch(g, groups, cfg, stream, ea, eb);
+    mmq_dispatch(type, g, groups, cfg, stream, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;
 }

@@ -19,6 +19,7 @@
 //   Q4_1 / Q5_0 / Q5_1 (20 / 22 / 24 B)  as Q4_0:  p0: [groups][4 dwords c][4 blocks b] nibbles   p1: [groups][d x 4, m x 4] f16 (m = 0 for Q5_0)   p2: qh [groups][4] u32 (0 for Q4_1)
 //   F32 / F16     native rows
 #define PI_MQ_TILE 2368      /* bytes of one (16 rows x 256 values) tile of the tile-major Q4_K copy */
+#define PI_MQ_TILE_Q5 2880   /* Q5_K: + 16 rows x 32 bytes of fifth bits */
 
 struct pi_weight {
     int      type;
@@ -30,7 +31,7 @@ struct pi_weight {
     const uint8_t * p0, * p1, * p2, * p3;
     // second, TILE-MAJOR copy for the multi-token MFMA kernel (mmq_mfma.hip), null when the type has none or copies are off (PI_MMQ_COPIES=0):
     // that kernel reads 16 rows x one block per step, which streams at 1.3-1.6 TB/s from the row-major planes above and at ~5 TB/s when the
-    // 16 blocks are contiguous (tools_dev/pattern.hip).  [row group of 16][block][PI_MQ_TILE bytes]; scales / mins unpacked per lane, quants re-ordered (layout in runtime.hip)
+    // 16 blocks are contiguous (tools_dev/pattern.hip).  [row group of 16][block][PI_MQ_TILE (Q4_K) / PI_MQ_TILE_Q5 (Q5_K) bytes]; scales / mins unpacked per lane, quants re-ordered (layout in runtime.hip)
     const uint8_t * mq;
     void *   mq_base;
 };

@@ -117,7 +117,7 @@ __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restr
     // (row, p, h) reads the 64 contiguous bytes of half p and takes nibble-half h of every dword (mmq_mfma.hip)
     for (int k = 0; k < 8; k++) for (int m = 0; m < 4; m++) dq[(m >> 1) * 16 + k * 2 + (m & 1)] = sq[m * 8 + k];
 }
-// Q4_K, tile-major copy for the MFMA kernel (mmq_mfma.hip): tile (row group g, block b) = PI_MQ_TILE = 2368 contiguous bytes
+// Q4_K, tile-major copy for the MFMA kernel (mmq_mfma.hip; k_repack_mq_q45_K): tile (row group g, block b) = PI_MQ_TILE = 2368 contiguous bytes
 //   [  0,   64)  16 rows x (d, dmin) as the block's two f16
 //   [ 64,  320)  64 records of 4 bytes, record (r + 16 c) = s(2c), s(2c+1), m(2c), m(2c+1) of row r: the 6-bit scales / mins of sub-blocks
 //                2c, 2c+1 already unpacked (get_scale_min_k4, ggml-quants.c:1446-1453) — lane (r, c) of the kernel needs exactly these four
@@ -125,19 +125,23 @@ __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restr
 //                low nibbles = sub-block 2c, high nibbles = sub-block 2c+1, accumulator lane k)
 //   [1344, 2368) part 1: k = 4..7
 // Rows past the end of the matrix are zero (d = 0: they add nothing).
-__global__ void k_repack_mq_q4_K(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t rows, int64_t nb) {
+// Q5_K: the same tile with the block's 32 qh bytes of every row after the records ([320, 832): 16 rows x 32 B; bit j of byte l = fifth bit of weight l of
+// sub-block j), quants from 832: PI_MQ_TILE_Q5 = 2880 bytes.
+__global__ void k_repack_mq_q45_K(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t rows, int64_t nb, int q5) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;                  // (row group, block, row in group)
     const int64_t n_rg = (rows + 15) / 16;
     if (i >= n_rg * nb * 16) return;
     const int r = (int) (i & 15); const int64_t gb = i >> 4, g = gb / nb, b = gb % nb, row = g * 16 + r;
-    uint8_t * tile = dst + gb * PI_MQ_TILE;
-    uint32_t * dd = (uint32_t *) tile, * rec = (uint32_t *) (tile + 64), * q0 = (uint32_t *) (tile + 320), * q1 = (uint32_t *) (tile + 1344);
+    const int tile_sz = q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, qoff = q5 ? 832 : 320;
+    uint8_t * tile = dst + gb * tile_sz;
+    uint32_t * dd = (uint32_t *) tile, * rec = (uint32_t *) (tile + 64), * qh = (uint32_t *) (tile + 320), * q0 = (uint32_t *) (tile + qoff), * q1 = (uint32_t *) (tile + qoff + 1024);
     if (row >= rows) {
         dd[r] = 0;
+        if (q5) for (int k = 0; k < 8; k++) qh[r * 8 + k] = 0;
         for (int c = 0; c < 4; c++) { rec[r + 16 * c] = 0; for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = 0; q1[(r + 16 * c) * 4 + k] = 0; } }
         return;
     }
-    const uint8_t * blk = src + (row * nb + b) * 144;
+    const uint8_t * blk = src + (row * nb + b) * (q5 ? 176 : 144);
     const uint32_t * s = (const uint32_t *) blk;
     const uint8_t * sc = blk + 4;
     dd[r] = s[0];
@@ -146,7 +150,8 @@ __global__ void k_repack_mq_q4_K(const uint8_t * __restrict__ src, uint8_t * __r
         if (j < 4) { scl[j] = sc[j] & 63; mn[j] = sc[j + 4] & 63; }
         else { scl[j] = (sc[j + 4] & 0xF) | ((sc[j - 4] >> 6) << 4); mn[j] = (sc[j + 4] >> 4) | ((sc[j] >> 6) << 4); }
     }
-    const uint32_t * sq = s + 4;
+    if (q5) for (int k = 0; k < 8; k++) qh[r * 8 + k] = s[4 + k];
+    const uint32_t * sq = s + (q5 ? 12 : 4);
     for (int c = 0; c < 4; c++) {
         rec[r + 16 * c] = scl[2 * c] | scl[2 * c + 1] << 8 | mn[2 * c] << 16 | mn[2 * c + 1] << 24;
         for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = sq[c * 8 + k]; q1[(r + 16 * c) * 4 + k] = sq[c * 8 + 4 + k]; }
@@ -282,11 +287,12 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     }
     w->mq = nullptr; w->mq_base = nullptr;
     static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
-    if (mq_on && type == PI_Q4_K) {
+    if (mq_on && (type == PI_Q4_K || type == PI_Q5_K)) {
         const int64_t n_rg = (ne1 + 15) / 16;
-        if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * PI_MQ_TILE + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
+        const size_t tile_sz = type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
+        if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * tile_sz + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
         w->mq = (const uint8_t *) w->mq_base;
-        hipLaunchKernelGGL(k_repack_mq_q4_K, dim3((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads)), dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
+        hipLaunchKernelGGL(k_repack_mq_q45_K, dim3((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads)), dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb, type == PI_Q5_K ? 1 : 0);
     }
     const hipError_t e = hipStreamSynchronize(stream);
     (void) hipFree(staging);

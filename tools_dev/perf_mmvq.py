@@ -7,8 +7,9 @@ from pipeinfer_amd.tools import synth
 from pipeinfer_amd import lib as L
 lib = U.init()
 shapes = [(O.Q4_K, 4096, 4096), (O.Q4_K, 11008, 4096), (O.Q4_K, 4096, 11008), (O.Q6_K, 32000, 4096), (O.Q4_K, 2048, 2048), (O.Q4_K, 5632, 2048), (O.Q4_K, 256, 2048), (O.Q6_K, 4096, 11008), (O.Q4_0, 4096, 4096), (O.Q4_K, 22016, 4096), (O.Q3_K, 4096, 4096), (O.Q3_K, 22016, 4096), (O.Q3_K, 4096, 11008), (O.Q5_K, 4096, 4096), (O.Q8_0, 4096, 4096), (O.Q4_K, 8192, 8192), (O.Q4_K, 28672, 8192), (O.Q4_K, 8192, 28672), (O.Q2_K, 4096, 4096), (O.Q2_K, 22016, 4096)]
-if len(sys.argv) > 1:
-    shapes = [shapes[int(i)] for i in sys.argv[1].split(",")]
+if len(sys.argv) > 1:                               # indices into the list above, or explicit shapes "q5_K:8192:8192"
+    names = {v: k for k, v in O.TYPE_NAMES.items()}
+    shapes = [shapes[int(i)] if i.isdigit() else (names[i.split(":")[0]], int(i.split(":")[1]), int(i.split(":")[2])) for i in sys.argv[1].split(",")]
 nts = [int(x) for x in os.environ.get("NTS", "1,2,4,8").split(",")]
 for t, rows, k in shapes:
     rng = np.random.default_rng(1)
