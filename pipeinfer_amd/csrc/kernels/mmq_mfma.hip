@@ -49,7 +49,15 @@ int pi_mmq_min_nt() {
     static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 3; return n < 2 ? 2 : n; }();
     return v;
 }
-bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K; }
+bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
+// does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
+// accumulator lane and only wins from 5 tokens (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
+// and on short matrices (attn_v of a GQA model: 64 row groups) only past the VALU kernel's 8 tokens per pass
+bool pi_mmq_wants(int type, int n_tok, int64_t rows) {
+    if (!pi_mmq_supported(type) || n_tok < pi_mmq_min_nt()) return false;
+    if (type == PI_Q6_K) return n_tok >= 5 && (rows >= 4096 || n_tok > 8);
+    return true;
+}
 
 static __device__ __forceinline__ pi_half2 h2_from_bits(uint32_t u) { return __builtin_bit_cast(pi_half2, u); }
 static __device__ __forceinline__ uint32_t h2_bits(pi_half2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -66,16 +74,16 @@ static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { retu
 
 template <int S> struct mq_q { uint4 v[2 / S]; };
 template <> struct mq_q<4> { uint2 v[1]; };
-template <int TYPE, int S> struct mq_w { uint32_t dd, rec; mq_q<S> q; mq_q<S> h; };       // one lane's share of one block: (d, dmin), its scales / mins record, 8 / S quant dwords (Q5_K: + as many dwords of fifth bits)
+template <int TYPE, int S> struct mq_w { uint32_t dd, rec, rec2; mq_q<S> q; mq_q<S> h; };       // one lane's share of one block: (d, dmin), its scales / mins record, 8 / S quant dwords (Q5_K: + as many dwords of fifth bits)
 
 template <int TYPE, int S, int R, int TB, bool NT8>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
-    static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K, "types are added one by one");
-    constexpr bool Q5 = TYPE == PI_Q5_K;
-    constexpr uint32_t TILE = Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q5 ? 832 : 320;
+    static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
+    constexpr bool Q5 = TYPE == PI_Q5_K, Q6 = TYPE == PI_Q6_K;
+    constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q6 ? 1600 : Q5 ? 832 : 320;
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
+    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0) + (Q6 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
     constexpr int FRAG = NT8 ? 512 : 1024, MQ_BLK_LDS = 8 * FRAG + 1024, NP = NT8 ? 5 : 9;   // NP: DMA pieces of 1 KB per block
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
@@ -114,16 +122,17 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 
     // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = PI_MQ_TILE contiguous bytes
     const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * TILE;
-    const uint32_t dd_off = 4 * r, rec_off = 64 + 4 * lane, q_off = QOFF + 16 * lane + (S == 1 ? 0 : S == 2 ? 1024 * s : 1024 * (s >> 1) + 8 * (s & 1));
-    const uint32_t h_off = 320 + 32 * r + (S == 1 ? 0 : S == 2 ? 16 * s : 8 * s);       // Q5_K: the row's qh bytes 4k..4k+3 of this wave's accumulator lanes (the same for the four K-slices)
+    const uint32_t dd_off = 4 * r, rec_off = 64 + (Q6 ? 8 : 4) * lane, q_off = QOFF + 16 * lane + (S == 1 ? 0 : S == 2 ? 1024 * s : 1024 * (s >> 1) + 8 * (s & 1));
+    const uint32_t h_off = (Q6 ? 576 + 64 * r + 32 * (gq >> 1) : 320 + 32 * r) + (S == 1 ? 0 : S == 2 ? 16 * s : 8 * s);       // Q6_K: qh of the row's half n = gq >> 1;       // Q5_K: the row's qh bytes 4k..4k+3 of this wave's accumulator lanes (the same for the four K-slices)
     auto load_w = [&](int b, mq_w<TYPE, S> & W) __attribute__((always_inline)) {
         const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * TILE;     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
         W.dd = *(const uint32_t *) (wbase + (bo + dd_off));
-        W.rec = *(const uint32_t *) (wbase + (bo + rec_off));
-        if constexpr (S == 4) { W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off)); if constexpr (Q5) W.h.v[0] = *(const uint2 *) (wbase + (bo + h_off)); }
+        if constexpr (Q6) { const uint2 rr = *(const uint2 *) (wbase + (bo + rec_off)); W.rec = rr.x; W.rec2 = rr.y; }
+        else W.rec = *(const uint32_t *) (wbase + (bo + rec_off));
+        if constexpr (S == 4) { W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off)); if constexpr (Q5 || Q6) W.h.v[0] = *(const uint2 *) (wbase + (bo + h_off)); }
         else {
 #pragma unroll
-            for (int i = 0; i < 2 / S; i++) { W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + 1024 * i)); if constexpr (Q5) W.h.v[i] = *(const uint4 *) (wbase + (bo + h_off + 16 * i)); }
+            for (int i = 0; i < 2 / S; i++) { W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + 1024 * i)); if constexpr (Q5 || Q6) W.h.v[i] = *(const uint4 *) (wbase + (bo + h_off + 16 * i)); }
         }
     };
     auto hdword = [&](const mq_w<TYPE, S> & W, int kk) __attribute__((always_inline)) -> uint32_t {
@@ -160,7 +169,48 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     // (lgkmcnt), the DMA writes it issued have landed (the caller's MQ_WAIT_VM)
     auto wg_barrier = [&]() __attribute__((always_inline)) { if (!(dbg & 6)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+    // ---- Q6_K (ggml-quants.c:6741-6810): sumi[k] = sum over the eight 32-groups of sc * sum_{i<4} (u - 32) * y, sc an int8: sc * (u - 32) does not fit f16's 11 bits,
+    //      so sc = 16 * sh + sl is split and the lane sum comes from TWO accumulating MFMAs with operands 16 sh (u - 32) and sl (u - 32) (both exact: |.| <= 4096 in
+    //      steps of 16, and <= 480).  K-slice (n, hh) = the groups g = hh (low nibbles) and hh + 2 (high nibbles) of half n; the activation fragment pairs 32-groups
+    //      (2c, 2c+1), so the two 8-byte halves of the operand come from two fragment lanes.  No mins (symmetric format). ----
+    auto compute_q6 = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
+        const int n = gq >> 1, hh = gq & 1;
+        const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
+        const float4 dy4 = *(const float4 *) (blk + 8 * FRAG + 16 * gq);
+        const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = dy[i] * dx;                                                     // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+        const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const uint32_t aoff = (NT8 ? ((2 * n) * 8 + (r & 7)) : (r + 32 * n)) * 16 + 8 * hh;                // fragment lane (token, 2n), half hh; lane (token, 2n+1) is 16 lanes (NT8: 8) further
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+            const int half = S == 1 ? (kk >> 2) : S == 2 ? s : (s >> 1);                                   // accumulator lanes k < 4 use the first scale of a 32-group, k >= 4 the second
+            const uint32_t selA = 0x04000400u + (uint32_t) half * 0x00010001u, selB = selA + 0x00020002u;
+            const uint32_t SLa = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, selA), 0xE400E400u);                     // (sl, sl) of the low-nibble group
+            const uint32_t SHa = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec2, selA), 0x4C004C00u, 0xF408F408u);       // (1024 + sh + 8) * 16 - 16512 = 16 sh
+            const uint32_t SLb = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, selB), 0x2C002C00u, 0xD400D400u);        // (1024 + sl) / 16 - 64 = sl / 16 (the high-nibble operand is 16 w)
+            const uint32_t SHb = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec2, selB), 0xE408E408u);                     // (1024 + sh + 8) - 1032 = sh
+            const uint32_t q = qdword(W, kk), q8 = q >> 8;
+            const uint32_t h = hdword(W, kk) >> (2 * hh), h8 = h >> 8;
+            // 1024 + u (u = nibble | top2 << 4) resp. 1024 + 16 u, minus 1056 resp. 1536 = u - 32 resp. 16 (u - 32)
+            const uint32_t w0 = pk_add((q & 0x000F000Fu) | magic | ((h & 0x00030003u) << 4), 0xE420E420u);
+            const uint32_t w1 = pk_add((q8 & 0x000F000Fu) | magic | ((h8 & 0x00030003u) << 4), 0xE420E420u);
+            const uint32_t w2 = pk_add((q & 0x00F000F0u) | magic | ((h & 0x00300030u) << 4), 0xE600E600u);
+            const uint32_t w3 = pk_add((q8 & 0x00F000F0u) | magic | ((h8 & 0x00300030u) << 4), 0xE600E600u);
+            const uint4 b1 = make_uint4(pk_mul(w0, SHa), pk_mul(w1, SHa), pk_mul(w2, SHb), pk_mul(w3, SHb));
+            const uint4 b2 = make_uint4(pk_mul(w0, SLa), pk_mul(w1, SLa), pk_mul(w2, SLb), pk_mul(w3, SLb));
+            const uint8_t * fr = blk + (s * KS + kk) * FRAG + aoff;
+            const uint2 a_lo = *(const uint2 *) fr, a_hi = *(const uint2 *) (fr + (NT8 ? 8 : 16) * 16);
+            const uint4 af = make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
+            pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b1), z, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b2), c, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[kk][i] = fmaf(d[i], c[i], acc[kk][i]);
+        }
+    };
     auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk, bool live) __attribute__((always_inline)) {
+        if constexpr (Q6) { compute_q6(W, blk); return; }
         // ---- block scalars: d, dmin of the row; this lane's two scales and two mins, bytes of one record ----
         const uint32_t ddl = live ? W.dd : 0u;
         const float dx = pi_h2f((uint16_t) (ddl & 0xffff)), dminx = pi_h2f((uint16_t) (ddl >> 16));
@@ -294,7 +344,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             for (int k = 0; k < 8; k++) a[k] = F[(k * 16 + rr) * 17 + t];
             float v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
             const float m0 = FM[(0 * 16 + rr) * 17 + t], m1 = FM[(1 * 16 + rr) * 17 + t], m2 = FM[(2 * 16 + rr) * 17 + t], m3 = FM[(3 * 16 + rr) * 17 + t];
-            v = Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
+            v = Q6 ? v : Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
             if (rr < rows && t < nt) {
                 if (sg.store) X[rr * 16 + t] = v;
                 else {
@@ -352,19 +402,21 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
 
 template <int TYPE>
 static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int T8 = TYPE == PI_Q5_K ? 2 : 4;                 // blocks per tile at <= 8 tokens (Q5_K: the ring carries the fifth bits too)
+    constexpr int T8 = TYPE == PI_Q4_K ? 4 : 2;                 // blocks per tile at <= 8 tokens (Q5_K: the ring carries the fifth bits too)
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;
         case 14: mmq_go<TYPE, 1, 4, 2, T8>(g, groups, stream, ea, eb); break;
         case 22: mmq_go<TYPE, 2, 2, 2, T8>(g, groups, stream, ea, eb); break;
         case 24: mmq_go<TYPE, 2, 4, 2, T8>(g, groups, stream, ea, eb); break;
-        case 41: mmq_go<TYPE, 4, 1, 2, 4>(g, groups, stream, ea, eb); break;
-        default: mmq_go<TYPE, 4, 2, 2, 4>(g, groups, stream, ea, eb); break;
+        case 41: mmq_go<TYPE, 4, 1, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
+        default: mmq_go<TYPE, 4, 2, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
     }
 }
 static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    if (type == PI_Q5_K) mmq_dispatch_t<PI_Q5_K>(g, groups, cfg, stream, ea, eb); else mmq_dispatch_t<PI_Q4_K>(g, groups, cfg, stream, ea, eb);
+    if (type == PI_Q6_K) mmq_dispatch_t<PI_Q6_K>(g, groups, cfg, stream, ea, eb);
+    else if (type == PI_Q5_K) mmq_dispatch_t<PI_Q5_K>(g, groups, cfg, stream, ea, eb);
+    else mmq_dispatch_t<PI_Q4_K>(g, groups, cfg, stream, ea, eb);
 }
 static const int mmq_cfgs[] = { 17, 18, 14, 22, 24, 41, 42 };
 // dynamic-LDS limits of every instance, set once and outside any stream capture (a launch inside a captured graph must not change function attributes)
@@ -372,7 +424,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     static bool done = false;
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
-    for (int type : { PI_Q4_K, PI_Q5_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
     done = true;
     PI_CHECK_LAUNCH();
     return 0;

@@ -931,7 +931,9 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     const int64_t nbq = vdt == PI_Q8_K ? K / 256 : w0->ng;
     // batches of PI_MMQ_MIN_NT tokens and more go to the matrix cores, 16 tokens per pass over the weights (mmq_mfma.hip); everything else
     // (single tokens, types without an MFMA kernel) takes the VALU mat-vec, 8 tokens per pass
-    bool mfma = vdt == PI_Q8_K && n_tok >= pi_mmq_min_nt() && pi_mmq_supported(w0->type);
+    int64_t rows_all = 0;
+    for (int i = 0; i < n_w; i++) rows_all += ws[i]->ne1;
+    bool mfma = vdt == PI_Q8_K && pi_mmq_wants(w0->type, n_tok, rows_all);
     for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
     if (mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
@@ -964,7 +966,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         }
         int rc = -1;
         if (mfma) {
-            L.g.frag = base + (w0->type == PI_Q6_K ? ofb : ofa) + (size_t) (t0 / 16) * nbq * 8192;
+            L.g.frag = base + ofa + (size_t) (t0 / 16) * nbq * 8192;
             L.g.aux = base + oax + (size_t) (t0 / 16) * nbq * 1024;
             L.g.nt = nt;
             hipEvent_t ea = nullptr, eb = nullptr;

@@ -40,5 +40,6 @@ struct mmvq_launch { mmvq_args g; int nseg; int64_t m_total, m_min; double wbyte
 
 // mmq_mfma.hip: 1 when the MFMA kernel handles this weight type
 bool pi_mmq_supported(int type);
+bool pi_mmq_wants(int type, int n_tok, int64_t rows);
 // launches k_mmq_kq for L (segments filled in, g.frag / g.aux / g.nt set); ea / eb: optional events bracketing the kernel (sampled timing)
 int  pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);

@@ -157,6 +157,41 @@ __global__ void k_repack_mq_q45_K(const uint8_t * __restrict__ src, uint8_t * __
         for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = sq[c * 8 + k]; q1[(r + 16 * c) * 4 + k] = sq[c * 8 + 4 + k]; }
     }
 }
+// Q6_K, tile-major copy for the MFMA kernel: tile (row group, block) = PI_MQ_TILE_Q6 = 3648 bytes.  K-slice c = (half n, hh) of a row covers the two
+// 32-groups that share ql bytes: g = hh (low nibbles of ql[64n + 32hh ..]) and g = hh + 2 (high nibbles); qh[32n ..] carries both groups' top bits.
+//   [   0,   64)  16 rows x d (f16 in a dword)
+//   [  64,  576)  64 records of 8 bytes, record (r + 16 c): the four int8 scales of the slice — sub-blocks 8n+2hh, 8n+2hh+1 (accumulator lanes k < 4, k >= 4 of the
+//                 low-nibble group) and 8n+2hh+4, 8n+2hh+5 (high-nibble group) — split so that both parts are exact as f16 weights: bytes 0..3 = sc & 15,
+//                 bytes 4..7 = (sc >> 4) + 8   (sc = 16 * (sc >> 4) + (sc & 15), arithmetic shift)
+//   [ 576, 1600)  16 rows x 2 halves x 32 bytes of qh
+//   [1600, 3648)  part 0 / part 1: lane (r + 16 c) x 16 bytes = dwords k = 0..3 / 4..7 of ql[64n + 32hh + 4k ..]
+__global__ void k_repack_mq_q6_K(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t rows, int64_t nb) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;                  // (row group, block, row in group)
+    const int64_t n_rg = (rows + 15) / 16;
+    if (i >= n_rg * nb * 16) return;
+    const int r = (int) (i & 15); const int64_t gb = i >> 4, g = gb / nb, b = gb % nb, row = g * 16 + r;
+    uint8_t * tile = dst + gb * PI_MQ_TILE_Q6;
+    uint32_t * dd = (uint32_t *) tile, * rec = (uint32_t *) (tile + 64), * qh = (uint32_t *) (tile + 576), * q0 = (uint32_t *) (tile + 1600), * q1 = (uint32_t *) (tile + 2624);
+    if (row >= rows) {
+        dd[r] = 0;
+        for (int k = 0; k < 16; k++) qh[r * 16 + k] = 0;
+        for (int c = 0; c < 4; c++) { rec[(r + 16 * c) * 2] = 0; rec[(r + 16 * c) * 2 + 1] = 0x08080808u; for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = 0; q1[(r + 16 * c) * 4 + k] = 0; } }
+        return;
+    }
+    const uint8_t * blk = src + (row * nb + b) * 210;                                    // 2-byte aligned only: assemble dwords from bytes
+    auto ld = [&](int off) { return (uint32_t) blk[off] | (uint32_t) blk[off + 1] << 8 | (uint32_t) blk[off + 2] << 16 | (uint32_t) blk[off + 3] << 24; };
+    dd[r] = (uint32_t) blk[208] | (uint32_t) blk[209] << 8;
+    for (int k = 0; k < 16; k++) qh[r * 16 + k] = ld(128 + 4 * k);
+    const int8_t * sc = (const int8_t *) (blk + 192);
+    for (int c = 0; c < 4; c++) {
+        const int n = c >> 1, hh = c & 1;
+        const int idx[4] = { 8 * n + 2 * hh, 8 * n + 2 * hh + 1, 8 * n + 2 * hh + 4, 8 * n + 2 * hh + 5 };
+        uint32_t lo = 0, hi = 0;
+        for (int j = 0; j < 4; j++) { const int v = sc[idx[j]]; lo |= (uint32_t) (v & 15) << (8 * j); hi |= (uint32_t) ((v >> 4) + 8) << (8 * j); }
+        rec[(r + 16 * c) * 2] = lo; rec[(r + 16 * c) * 2 + 1] = hi;
+        for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = ld(64 * n + 32 * hh + 4 * k); q1[(r + 16 * c) * 4 + k] = ld(64 * n + 32 * hh + 16 + 4 * k); }
+    }
+}
 __global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint16_t * d, int64_t nblocks) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks) return;
@@ -287,12 +322,14 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
     }
     w->mq = nullptr; w->mq_base = nullptr;
     static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
-    if (mq_on && (type == PI_Q4_K || type == PI_Q5_K)) {
+    if (mq_on && (type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) {
         const int64_t n_rg = (ne1 + 15) / 16;
-        const size_t tile_sz = type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
+        const size_t tile_sz = type == PI_Q6_K ? PI_MQ_TILE_Q6 : type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
         if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * tile_sz + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
         w->mq = (const uint8_t *) w->mq_base;
-        hipLaunchKernelGGL(k_repack_mq_q45_K, dim3((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads)), dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb, type == PI_Q5_K ? 1 : 0);
+        const dim3 mgrid((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads));
+        if (type == PI_Q6_K) hipLaunchKernelGGL(k_repack_mq_q6_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
+        else hipLaunchKernelGGL(k_repack_mq_q45_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb, type == PI_Q5_K ? 1 : 0);
     }
     const hipError_t e = hipStreamSynchronize(stream);
     (void) hipFree(staging);
