@@ -85,3 +85,20 @@ def test_model_scenarios_golden(stem):
         cur = int(np.argmax(lg[0]))
     assert toks == list(g["greedy_tokens"])
     m.close()
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_rope_composition_property(mode):
+    """the reference's tests/test-rope.cpp:138-215: rotating by p0 and then by delta equals rotating by p0 + delta (relative error < 1e-4);
+    modes 0 (Llama pairs 2i, 2i+1) and 2 (NeoX halves)"""
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(5 + mode)
+    n_tok, n_head, hd = 7, 4, 128
+    x = rng.uniform(-1.0, 1.0, (n_tok, n_head, hd)).astype(np.float32)
+    p0 = (np.arange(n_tok) * 3 + 11).astype(np.int32)
+    delta = (np.arange(n_tok) * 5 + 2).astype(np.int32)
+    r0 = o.rope(x, p0, mode)
+    r1 = o.rope(r0, delta, mode)
+    r2 = o.rope(x, p0 + delta, mode)
+    err = float(np.sqrt(np.sum((r1 - r2).astype(np.float64) ** 2)) / np.sqrt(np.sum(r2.astype(np.float64) ** 2)))
+    assert err < 1e-4, err

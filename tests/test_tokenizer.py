@@ -106,3 +106,56 @@ def test_bpe_contractions_and_runs(falcon):
     for text in ("I'm sure they're here, we've seen it'll work; don't", "a1b22c333 4444  55555   x", "tabs\t\tand\n\nnewlines  \n ", "'" * 4 + "s't'"):
         toks = falcon.tokenize(text, add_bos=False)
         assert b"".join(falcon.token_to_piece(t) for t in toks).decode("utf-8") == text
+
+
+# ---- the reference's tests/test-tokenizer-1-{llama,bpe}.cpp: every token and every codepoint survives detokenize . tokenize ----------------------
+def _detok_spm(m, toks):
+    """common.cpp:1129-1147 llama_detokenize_spm: the first non-BOS piece loses its leading space"""
+    out = b""
+    for i, t in enumerate(toks):
+        piece = m.token_to_piece(t)
+        if ((toks[0] == 1 and i == 1) or (toks[0] != 1 and i == 0)) and piece[:1] == b" ":
+            piece = piece[1:]
+        out += piece
+    return out
+
+
+def _detok_bpe(m, toks):
+    return b"".join(m.token_to_piece(t) for t in toks)
+
+
+def test_spm_every_token_and_codepoint_round_trips(model):
+    for i in range(model.n_vocab):                                               # test-tokenizer-1-llama.cpp:63-72
+        s = _detok_spm(model, [i])
+        try:
+            text = s.decode("utf-8")
+        except UnicodeDecodeError:
+            continue                                                             # byte tokens that are not text on their own
+        assert _detok_spm(model, model.tokenize(text, add_bos=False)) == s, i
+    step = int(os.environ.get("PI_TOKENIZER_CP_STEP", "1"))
+    for cp in list(range(0, 0xffff, step)) + list(range(0x10000, 0x110000, 7 * step)):      # :74-95 (the astral planes sampled every 7th codepoint)
+        if 0xd800 <= cp <= 0xdfff or cp == 9601 or cp == 0:
+            continue
+        text = chr(cp)
+        assert _detok_spm(model, model.tokenize(text, add_bos=False)) == text.encode("utf-8"), hex(cp)
+
+
+def test_bpe_every_token_and_codepoint_round_trips(falcon):
+    for i in range(falcon.n_vocab):                                              # test-tokenizer-1-bpe.cpp:65-80
+        s = _detok_bpe(falcon, [i])
+        try:
+            text = s.decode("utf-8")
+        except UnicodeDecodeError:
+            continue
+        if "\x00" in text:
+            continue                                                             # (the C API takes the text by length, the ctypes wrapper by bytes: fine, but keep NULs out)
+        assert _detok_bpe(falcon, falcon.tokenize(text, add_bos=False)) == s, i
+    skip = set(range(0x03, 0x06)) | {0x0b, 0x11, 0x19} | set(range(0x13, 0x18)) | set(range(0x1c, 0x1f))      # :83 "the GPT2 tokenizer doesn't want to interfere with some ASCII control characters"
+    for cp in range(1, 0xffff):
+        if cp in skip or 0xd800 <= cp <= 0xdfff:
+            continue
+        text = " " + chr(cp)
+        assert _detok_bpe(falcon, falcon.tokenize(text, add_bos=False)) == text.encode("utf-8"), hex(cp)
+    for cp in range(0x10000, 0x40000, 5):                                        # :96-97 "restrict to assigned unicode planes" (sampled)
+        text = chr(cp)
+        assert _detok_bpe(falcon, falcon.tokenize(text, add_bos=False)) == text.encode("utf-8"), hex(cp)
