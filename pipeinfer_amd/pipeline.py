@@ -210,9 +210,9 @@ class HipStage:
         self.sums = np.zeros(n_batch, np.float32)
 
     def run(self, n_tokens, meta, x_in, x_out):
-        """meta: int32 numpy block; x_in / x_out: device tensors or None.  Returns (ids, vals, sums, logits) on the last stage."""
-        rc = self.lib.pipeinfer_stage_run(self.ctx.h, n_tokens, meta.ctypes.data, meta.nbytes,
-                                          x_in.data_ptr() if x_in is not None else None, x_out.data_ptr() if x_out is not None else None,
+        """meta: int32 numpy block; x_in / x_out: device buffers or None.  Returns (ids, vals, sums, logits) on the last stage."""
+        ptr = lambda b: None if b is None else (b.data_ptr() if hasattr(b, "data_ptr") else b.ptr)      # a torch tensor or any object with a device address in .ptr
+        rc = self.lib.pipeinfer_stage_run(self.ctx.h, n_tokens, meta.ctypes.data, meta.nbytes, ptr(x_in), ptr(x_out),
                                           self.logits.ctypes.data, self.ids.ctypes.data, self.vals.ctypes.data, self.sums.ctypes.data)
         if rc != 0:
             raise RuntimeError("pipeinfer_stage_run: " + self.lib.pipeinfer_context_error(self.ctx.h).decode())

@@ -4,14 +4,11 @@ import os
 import sys
 
 import numpy as np
-import torch
 
-assert torch.cuda.is_available()                    # torch first: it must own the HIP runtime before libpipeinfer_amd.so is loaded
-torch.zeros(1, device="cuda")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pipeinfer_amd import llama as LL, pipeline as P          # noqa: E402
-from tests import scenarios as S                              # noqa: E402
+from tests import gpu_util as U, scenarios as S               # noqa: E402      (no torch anywhere: device buffers through the C ABI)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20}
@@ -24,7 +21,7 @@ class InProcessPipeline:
     def __init__(self, P, path, ranges, n_ctx, n_batch):
         self.P = P
         self.stages = [P.HipStage(path, l0, l1, i == 0, i == len(ranges) - 1, n_ctx, n_batch) for i, (l0, l1) in enumerate(ranges)]
-        self.x = [torch.empty((n_batch, self.stages[0].n_embd), dtype=torch.float32, device="cuda") for _ in ranges]
+        self.x = [U.Dev(nbytes=4 * n_batch * self.stages[0].n_embd) for _ in ranges]
         self.done = {}
         self.ops = P.RemoteOps(None, P.START_FN(self._start), P.POLL_FN(lambda u: 1 if self.done else 0), P.WAIT_FN(self._wait), P.CANCEL_FN(lambda u, b: None))
 
@@ -37,7 +34,7 @@ class InProcessPipeline:
         block = np.frombuffer(C.string_at(meta, (nbytes + 3) // 4 * 4), dtype=np.int32).copy()
         res = None
         for i, st in enumerate(self.stages):
-            res = st.run(n, block, None if i == 0 else self.x[i - 1][:n], None if i == len(self.stages) - 1 else self.x[i][:n])
+            res = st.run(n, block, None if i == 0 else self.x[i - 1], None if i == len(self.stages) - 1 else self.x[i])
         self.done[run_seq] = tuple(np.array(a) for a in res)
         return 0
 

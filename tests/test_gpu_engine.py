@@ -233,7 +233,7 @@ def test_target_only_mode_matches(LL):
 @pytest.mark.parametrize("stem,ranges", [("tiny_llama_b_q4_k_m", "0-1,1-3"), ("tiny_llama_q4_k_m", "0-2"), ("tiny_falcon40_q4_k_m", "0-1,1-2")])
 def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
     """head proxy context + pipeinfer_stage_run on layer ranges == the whole model in one context (tests/pipeline_gpu_worker.py).
-    Runs in its own process because torch has to initialise the GPU before libpipeinfer_amd.so is loaded (see pipeline.py)."""
+    Runs in its own process (several contexts of several models; keeps the parent's device state clean)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "pipeline_gpu_worker.py"), stem, ranges], capture_output=True, text=True, timeout=600,
