@@ -847,10 +847,13 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         // rows per wave: pairs (row, token) share the chain phase (8 per pass) and the activation registers, so more rows
         // amortise them; fewer rows give more waves.  Keep >= ~2048 waves when the matrices allow.  PI_MMVQ_R overrides.
         static const int r_env = getenv("PI_MMVQ_R") ? atoi(getenv("PI_MMVQ_R")) : 0;
-        constexpr int RMAX = 2;                                    // measured on the whole decode: 2 rows per wave beats 4 (3.57 vs 3.75 ms per 7B token) although 4 wins on isolated launches
-        int R = RMAX;
+        // measured on the whole decode: at 7B sizes 2 rows per wave beat 4 (3.57 vs 3.75 ms per token) although 4 win on isolated launches; at 70B sizes
+        // (K >= 8192, >= 8192 rows) 4 rows win both ways: 28672 x 8192 29.5 -> 28.1 us, 8192 x 28672 34.3 -> 32.1 us, 86.5 -> 88.0 tok/s (same-box A/B)
+        constexpr int RMAX = 4;
+        int R = g.K >= 8192 ? 4 : 2;
         while (R > 1 && L.m_total / R < 2048) R >>= 1;
         if (r_env) R = r_env < RMAX ? r_env : RMAX;
+        if (R == 3) R = 2;
         if (L.rope && R < 2) R = 2;                               // the RoPE epilogue needs both rows of a pair in one wave
         int waves = 0;
         for (int i = 0; i < MMVQ_MAX_SEG; i++) {

@@ -109,6 +109,8 @@ def test_mul_mat_golden_blocks(gpu, t):
                                           # the loop-free decode instances: single tile up to 4 tokens, tile per wave (2..16 tiles) up to 2, longer rows fall back to the loop
                                           (4096, 33, 3), (4096, 33, 4), (8192, 40, 1), (28672, 17, 1), (28672, 17, 2), (65536, 5, 1), (69632, 6, 1), (69632, 6, 2), (3840, 9, 2),
                                           (8192, 24, 3), (8192, 24, 4), (5120, 10, 3), (8192, 24, 2), (14336, 12, 2), (14336, 12, 3),
+                                          # 70B-sized launches: four rows per wave group (K >= 8192 and >= 8192 rows), ragged last group
+                                          (8192, 8198, 1), (8192, 8198, 2),
                                           # matrix-core kernel (2..16 tokens per pass, 1/2/4/8 waves per 16-row group, ragged row groups, prompts in chunks of 16)
                                           (4096, 64, 16), (4096, 49, 9), (8192, 2064, 12), (28672, 40, 16), (2048, 16, 2), (512, 4100, 13), (4096, 80, 17), (1024, 32, 37),
                                           # Q4_0 / Q8_0 range-per-wave kernel: 4, 8, 12 groups per wave, ragged last wave, rows not a multiple of 8
