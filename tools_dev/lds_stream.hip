@@ -51,6 +51,24 @@ __global__ void __launch_bounds__(T) k_small(const uint4 * __restrict__ p, size_
     for (int u = 0; u < L; u++) acc ^= v[u].x ^ v[u].w;
     if (acc == 0x12345678u) out[0] = acc;
 }
+// D: the decode mat-vec's own load pattern without its arithmetic: workgroup = 2 waves (K = 8192: two tiles of 16 blocks), R rows per workgroup; lane (q, c) of wave t loads, for each
+//    row, the block header (16 B, the four lanes of a quad the same), and two 16-byte pieces at 16 + 16c and 80 + 16c of block 16t + q (144-byte blocks, rows 32 blocks = 4608 B apart)
+//    PLANES = 1: the same bytes re-laid per tile as [16 headers][64 x 16 B][64 x 16 B] so that every wave instruction reads one contiguous piece
+template <int R, int PLANES>
+__global__ void __launch_bounds__(128) k_pattern(const uint8_t * __restrict__ w, size_t nrows, uint32_t * out) {
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6, q = lane >> 2, c = lane & 3;
+    uint4 v[R][3]; uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        size_t row = (size_t) blockIdx.x * R + i; if (row >= nrows) row = nrows - 1;
+        const uint8_t * tile = w + row * 4608 + (size_t) t * 2304;
+        if (PLANES) { v[i][0] = *(const uint4 *) (tile + q * 16); v[i][1] = *(const uint4 *) (tile + 256 + lane * 16); v[i][2] = *(const uint4 *) (tile + 1280 + lane * 16); }
+        else { const uint8_t * b = tile + q * 144; v[i][0] = *(const uint4 *) b; v[i][1] = *(const uint4 *) (b + 16 + 16 * c); v[i][2] = *(const uint4 *) (b + 80 + 16 * c); }
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) acc ^= v[i][0].x ^ v[i][1].y ^ v[i][2].w;
+    if (acc == 0x12345678u) out[0] = acc;
+}
 int main() {
     uint32_t * out; CK(hipMalloc(&out, 1 << 22));
     for (size_t nbytes : { (size_t) 37748736, (size_t) 132120576, (size_t) 264241152 }) {
@@ -85,6 +103,13 @@ int main() {
         small(std::integral_constant<int, 256>{}, std::integral_constant<int, 10>{}, "registers, 256 threads x 10 loads (40 KB per WG)");
         small(std::integral_constant<int, 512>{}, std::integral_constant<int, 10>{}, "registers, 512 threads x 10 loads (80 KB per WG)");
         small(std::integral_constant<int, 1024>{}, std::integral_constant<int, 10>{}, "registers, 1024 threads x 10 loads (160 KB per WG)");
+        {
+            const size_t nrows = nbytes / 4608;
+            timeit([&](uint8_t * p) { hipLaunchKernelGGL((k_pattern<2, 0>), dim3((unsigned) ((nrows + 1) / 2)), dim3(128), 0, 0, p, nrows, out); }, "decode pattern, 2 rows per WG (144-byte blocks)");
+            timeit([&](uint8_t * p) { hipLaunchKernelGGL((k_pattern<2, 1>), dim3((unsigned) ((nrows + 1) / 2)), dim3(128), 0, 0, p, nrows, out); }, "decode pattern, 2 rows per WG, per-tile planes");
+            timeit([&](uint8_t * p) { hipLaunchKernelGGL((k_pattern<4, 0>), dim3((unsigned) ((nrows + 3) / 4)), dim3(128), 0, 0, p, nrows, out); }, "decode pattern, 4 rows per WG (144-byte blocks)");
+            timeit([&](uint8_t * p) { hipLaunchKernelGGL((k_pattern<4, 1>), dim3((unsigned) ((nrows + 3) / 4)), dim3(128), 0, 0, p, nrows, out); }, "decode pattern, 4 rows per WG, per-tile planes");
+        }
         for (auto bb : bufs) CK(hipFree(bb));
     }
     return 0;
