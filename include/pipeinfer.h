@@ -56,6 +56,9 @@ LLAMA_API void pipeinfer_context_set_remote(struct llama_context * ctx, const st
 LLAMA_API int  pipeinfer_context_set_stage(struct llama_context * ctx, int32_t l0, int32_t l1, int32_t is_first, int32_t is_last);
 /* layer ranges of the reference's --mpi-layer-split (ggml-mpi.c:541-557): ranges[2*i], ranges[2*i+1] = [start, end) of stage i */
 LLAMA_API void pipeinfer_split_layers(int32_t n_layer, const float * weights, int32_t n_stage, int32_t * ranges);
+/* llama_split_layers_weighted (llama.cpp:8929-8938) for ONE stage process: the rule above on the model's layer count, then set_stage for
+ * stage `stage` of `n_stage` (first stage: embedding, last: norm + output).  l0_out / l1_out (optional) receive the range. */
+LLAMA_API int  pipeinfer_context_set_stage_weighted(struct llama_context * ctx, const float * weights, int32_t n_stage, int32_t stage, int32_t * l0_out, int32_t * l1_out);
 /* one run on this stage; x_in_dev / x_out_dev: device fp32 [n_tokens][n_embd] (ignored on the first / last stage); the last
  * stage fills the host buffers.  Returns after the stage's stream is idle. */
 LLAMA_API int  pipeinfer_stage_run(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,

@@ -287,6 +287,16 @@ extern "C" void pipeinfer_split_layers(int32_t n_layer, const float * weights, i
     }
 }
 
+// llama_split_layers_weighted for ONE stage process (llama.cpp:8929-8938): the split rule above on this model's layer count, then set_stage
+extern "C" int pipeinfer_context_set_stage_weighted(struct llama_context * ctx, const float * weights, int32_t n_stage, int32_t stage, int32_t * l0_out, int32_t * l1_out) {
+    if (n_stage < 1 || stage < 0 || stage >= n_stage || !weights) { ctx->last_error = "pipeinfer_context_set_stage_weighted: bad stage index"; return -1; }
+    std::vector<int32_t> ranges((size_t) 2 * n_stage);
+    pipeinfer_split_layers(ctx->model->hparams.n_layer, weights, n_stage, ranges.data());
+    if (l0_out) *l0_out = ranges[2 * stage];
+    if (l1_out) *l1_out = ranges[2 * stage + 1];
+    return pipeinfer_context_set_stage(ctx, ranges[2 * stage], ranges[2 * stage + 1], stage == 0, stage == n_stage - 1);
+}
+
 extern "C" int pipeinfer_stage_run_abortable(struct llama_context * ctx, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * x_in_dev, float * x_out_dev,
                                              float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void *), void * user) {
     return pi::stage_run(ctx, n_tokens, meta, meta_bytes, x_in_dev, x_out_dev, logits_host, topk_ids, topk_vals, topk_sum, should_abort, user);

@@ -206,6 +206,48 @@ def test_cli_driver_with_the_reference_flags(tmp_path):
     assert r2.returncode == 0 and "decoded" in r2.stdout, r2.stderr[-2000:]
 
 
+@pytest.mark.parametrize("split,host_rings", [("0.34,0.66/1.0", False), ("1.0", False), ("0.34,0.33,0.33", True)])
+def test_cli_driver_layer_split_across_processes(tmp_path, split, host_rings):
+    """--mpi-layer-split: the same command line started once per rank (the reference: once per MPI rank, speculative.cpp:116-139); rank 0 drives and
+    drafts, the other ranks serve the target's layer ranges through pipeinfer_transport_*.  All ranks share this box's one GPU.  The ids must be the
+    golden continuation, speculation must have run, and every stage must exit cleanly after the head's shutdown."""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "speculative_amd")
+    subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "speculative_amd.cpp"),
+                    "-L" + os.path.join(root, "pipeinfer_amd"), "-lpipeinfer_amd", "-Wl,-rpath," + os.path.join(root, "pipeinfer_amd"), "-o", exe], check=True)
+    tgt, dft = "tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"
+    prompt, want = greedy_reference(tgt, 8, 24)
+    world = len(split.split("/")[0].split(",")) + 1
+    base = [exe, "-m", os.path.join(GOLD, tgt + ".gguf"), "-md", os.path.join(GOLD, dft + ".gguf"), "--prompt-tokens", ",".join(str(t) for t in prompt),
+            "-n", "23", "--draft", "4", "-np", "2", "-pa", "0.05", "-ps", "0.9", "-c", "256", "-b", "64", "--mpi-layer-split", split, "--device", "0"]
+    env = dict(os.environ, PIPEINFER_JOB=f"pi-cli-{os.getpid()}-{world}", PIPEINFER_WORLD=str(world))
+    if host_rings:
+        env["PIPEINFER_TRANSPORT_HOST"] = "1"
+    procs = [subprocess.Popen(base, env=dict(env, PIPEINFER_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace") for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][1][-2000:])
+    toks = [l for l in outs[0][0].splitlines() if l.startswith("tokens:")][0].split()[1:]
+    assert [int(t) for t in toks][:24] == want, (toks, want)
+    assert "host rings" in outs[0][1] if host_rings else "peer stores" in outs[0][1], outs[0][1][-500:]
+    assert int([l for l in outs[0][0].splitlines() if l.startswith("n_drafted =")][0].split()[-1]) > 0
+    for r in range(1, world):
+        assert f"rank {r} serves layers" in outs[r][1] and " runs, " in outs[r][1], outs[r][1][-500:]
+    # the wrong number of processes for the split is refused before anything is opened
+    bad = subprocess.run(base, env=dict(env, PIPEINFER_RANK="0", PIPEINFER_WORLD=str(world + 1)), capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "start" in bad.stderr
+
+
 def test_pipeinfer_driver_lossless_under_timing_jitter(LL):
     """the driver's control flow depends on which run finishes first, so repeat one configuration with fresh contexts
     (this caught target and draft contexts racing on a shared top-k scratch buffer)."""
