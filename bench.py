@@ -42,6 +42,8 @@ WORKLOADS = {
     "tiny": ("tiny-llama-b", "q4_k_m", "tiny-llama", "q4_k_m"),
     "1b": ("tinyllama-1.1b", "q4_k_m", "tinyllama-1.1b", "q4_k_m"),          # the draft model on its own (use with --mode 2)
     "70b-q3km": ("llama-2-70b", "q3_k_m", "tinyllama-1.1b", "q4_k_m"),       # the paper's Dolphin-70B Q3_K_M setup (README.md:165)
+    "falcon40b": ("falcon-40b", "q5_k_m", "falcon-7b", "q4_0"),               # BASELINE configs[3] (two-norm Falcon block, GQA 128/8, 65024-token BPE vocabulary)
+    "goliath": ("goliath-120b", "q4_k_m", "llama-2-7b", "q4_k_m"),            # BASELINE configs[4] (137 layers of 70B shape; Xwin-7B = Llama-2-7B shape; run with --n-draft 8)
 }
 TYPE_NAMES = {10: "Q2_K", 11: "Q3_K", 12: "Q4_K", 13: "Q5_K", 14: "Q6_K", 2: "Q4_0", 8: "Q8_0"}
 

@@ -331,15 +331,18 @@ def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_lay
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("workload,n_predict", [("7b", 48), ("70b-l4", 48)])
-def test_every_run_equals_the_oracle_at_full_size_shapes(workload, n_predict):
+@pytest.mark.parametrize("workload,n_predict,n_draft,n_parallel,p_accept", [("7b", 48, 3, 3, 0.1), ("70b-l4", 48, 3, 3, 0.1), ("falcon40b-l4", 40, 3, 3, 0.002), ("goliath-l4", 40, 8, 2, 0.002)])
+def test_every_run_equals_the_oracle_at_full_size_shapes(workload, n_predict, n_draft, n_parallel, p_accept):
     """the same per-run comparison at the shapes of BASELINE's configurations: the whole Llama-2-7B Q4_K_M (K = 4096 / 11008, 32 layers), and
     Llama-2-70B shapes (GQA 64/8, K = 8192 / 28672: the tile-per-wave decode instances, the matrix-core kernel on verify batches and prompt
-    chunks) cut to four layers so that the CPU oracle keeps up.  Every run the driver launches — prompt batches, single tokens, speculative
+    chunks) cut to four layers so that the CPU oracle keeps up; BASELINE configs[3]: Falcon-40B Q5_K_M shapes (two-norm block, fused QKV of 9216 rows,
+    GQA 128/8 with 64-wide heads, K = 8192 / 32768, Q8_0 lm_head of 65024 rows) with the whole Falcon-7B Q4_0 as the draft (K = 4544 / 18176, MQA);
+    configs[4]: Goliath-120B Q4_K_M shapes with a Llama-2-7B-shaped draft and depth-8 drafts (8-token verify batches).  (The synthetic Falcon and 7B-shaped drafts spread their
+    probability widely, hence the low p_accept there.)  Every run the driver launches — prompt batches, single tokens, speculative
     batches, accepted or cancelled — must give the oracle's logits bit for bit on the cells it was given."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "trace_compare_worker.py"), workload, "0.02", str(n_predict)], capture_output=True, text=True, timeout=1500,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "trace_compare_worker.py"), workload, "0.02", str(n_predict), str(n_draft), str(n_parallel), str(p_accept)], capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]

@@ -10,10 +10,13 @@ from pipeinfer_amd import llama as LL, lib as L, pipeline as P
 from tests import oracle_lib as O
 import bench as B
 
-# usage: trace_compare_worker.py <workload | target.gguf:draft.gguf:n_layer> [latency_s] [n_predict]
+# usage: trace_compare_worker.py <workload | target.gguf:draft.gguf:n_layer> [latency_s] [n_predict] [n_draft] [n_parallel] [p_accept]
 wl = sys.argv[1] if len(sys.argv) > 1 else "7b"
 latency = float(sys.argv[2]) if len(sys.argv) > 2 else 0.008
 n_predict = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+n_draft = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+n_parallel = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+p_accept_arg = float(sys.argv[6]) if len(sys.argv) > 6 else None
 lib = L.load(); L.check(lib.pi_device_init(0))
 if ":" in wl:
     tgt_path, dft_path, nl = wl.split(":")
@@ -28,7 +31,7 @@ else:
     cache = os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models")
     tgt_path = B.ensure_model(cache, tspec, tft, 0x5EED, 1.0, 0.8, layers=cut)
     dft_path = B.ensure_model(cache, dspec, dft, 0xD4AF, 1.0, 0.8)
-    N_LAYER, N_CTX, N_PROMPT = (cut[1] if cut else {"7b": 32, "tiny": 3, "70b": 80}[wl]), 1024, 32
+    N_LAYER, N_CTX, N_PROMPT = (cut[1] if cut else {"7b": 32, "tiny": 3, "70b": 80, "falcon40b": 60, "goliath": 137}[wl]), 1024, 32
 o = O.oracle()
 o.o_set_threads(int(os.environ.get("ORACLE_THREADS", "64")))
 oh = o.o_model_load(tgt_path.encode(), N_CTX, 8)
@@ -91,7 +94,7 @@ for mode, check in ((2, False), (0, True)):
     both.attach(ct)
     if mode == 0:                                    # the oracle's KV cache has to see the same history: replay the prompt through it
         pass
-    out, res = LL.speculative(ct, cd, prompt, n_predict=n_predict, n_draft=3, n_parallel=3, p_accept=0.05 if N_CTX == 256 else 0.1, p_split=0.9, ignore_eos=1, mode=mode)
+    out, res = LL.speculative(ct, cd, prompt, n_predict=n_predict, n_draft=n_draft, n_parallel=n_parallel, p_accept=p_accept_arg if p_accept_arg is not None else (0.05 if N_CTX == 256 else 0.1), p_split=0.9, ignore_eos=1, mode=mode)
     outs[mode] = [int(x) for x in out[:n_predict]]
     print("mode", mode, "runs", both.n, "oracle mismatches", len(both.bad), both.bad[:5], {k: res[k] for k in ("n_runs_spec", "n_runs_canceled", "n_accept_clean")})
     ct.free(); cd.free()
