@@ -108,6 +108,10 @@ LLAMA_API void pipeinfer_transport_get_stats(pipeinfer_transport * tp, struct pi
  * or the backend's run().  A sender thread overlaps each hop with the next run's compute. */
 LLAMA_API int  pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_context * stage_ctx, const struct pipeinfer_stage_backend * backend, struct pipeinfer_transport_stats * out);
 
+/* Offline quantisation of one run of fp32 values into `type` (ggml type id: 0 f32, 1 f16, 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 10..14 Q2_K..Q6_K) with the
+ * reference's deterministic quantize_row_*_reference arithmetic (ggml-quants.c:428-640, 1458-2316) — what llama_model_quantize applies to every row.
+ * k: number of values, a multiple of the block size.  Returns the bytes written, -1 on a bad type / length. */
+LLAMA_API int64_t pipeinfer_quantize_row(int32_t type, const float * x, void * y, int64_t k);
 LLAMA_API int  pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp);
 
 struct pipeinfer_stats {

@@ -67,6 +67,7 @@ bool gguf_file::open(const std::string & path, std::string & err) {
     for (uint64_t i = 0; i < n_kv && r.ok; i++) {
         std::string key = r.str();
         gguf_value v;
+        const uint8_t * const raw0 = r.p;
         v.type = r.get<uint32_t>();
         switch (v.type) {
             case 0: v.u = r.get<uint8_t>(); break;   case 1: v.i = r.get<int8_t>(); break;
@@ -86,6 +87,7 @@ bool gguf_file::open(const std::string & path, std::string & err) {
         }
         if (v.type == 1 || v.type == 3 || v.type == 5 || v.type == 11) v.u = (uint64_t) v.i;
         if (v.type == 0 || v.type == 2 || v.type == 4 || v.type == 10) v.i = (int64_t) v.u;
+        kv_raw.push_back({ key, raw0, r.p });
         kv.emplace(std::move(key), std::move(v));
     }
     tensors.resize(n_tensors);

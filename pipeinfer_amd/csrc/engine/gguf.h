@@ -41,6 +41,8 @@ public:
     const gguf_tensor * tensor(const std::string & name) const;
 
     std::map<std::string, gguf_value> kv;
+    struct raw_kv { std::string key; const uint8_t * begin; const uint8_t * end; };     // [type id + value] bytes in the mapping, in file order (the quantiser copies them through)
+    std::vector<raw_kv> kv_raw;
     std::vector<gguf_tensor> tensors;
     uint32_t version = 0;
     size_t   file_size = 0;

@@ -84,7 +84,7 @@ extern "C" void llama_dump_timing_info_yaml(FILE * stream, const struct llama_co
 extern "C" struct llama_model_quantize_params llama_model_quantize_default_params(void) {
     struct llama_model_quantize_params p; memset(&p, 0, sizeof p); p.ftype = LLAMA_FTYPE_MOSTLY_Q5_1; p.quantize_output_tensor = true; return p;   // llama.cpp:8614-8625
 }
-extern "C" int llama_model_quantize(const char *, const char *, const llama_model_quantize_params *) { out_of_scope("llama_model_quantize"); return 1; }
+// llama_model_quantize: quantize.cpp
 extern "C" int llama_apply_lora_from_file(struct llama_context *, const char *, float, const char *, int) { out_of_scope("llama_apply_lora_from_file (LoRA)"); return 1; }
 extern "C" int llama_model_apply_lora_from_file(const struct llama_model *, const char *, float, const char *, int) { out_of_scope("llama_model_apply_lora_from_file (LoRA)"); return 1; }
 extern "C" struct ggml_tensor * llama_get_model_tensor(struct llama_model *, const char *) { out_of_scope("llama_get_model_tensor (weights live in HBM in kernel layouts)"); return nullptr; }

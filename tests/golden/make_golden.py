@@ -146,6 +146,32 @@ def kernel_vectors_legacy():
     np.savez_compressed(os.path.join(HERE, "kernels_legacy.npz"), **out)
 
 
+QUANT_TYPES = [(2, "q4_0"), (3, "q4_1"), (6, "q5_0"), (7, "q5_1"), (8, "q8_0"), (10, "q2_K"), (11, "q3_K"), (12, "q4_K"), (13, "q5_K"), (14, "q6_K")]
+
+
+def quantize_inputs(k=1024, seed=77):
+    """rows that exercise the searches of the offline quantisers: gaussian weights, zeros, a constant, mixed magnitudes, one-sided, heavy tails, sparse"""
+    rng = np.random.default_rng(seed)
+    rows = [rng.standard_normal(k) * 0.02, np.zeros(k), np.full(k, 0.37), rng.standard_normal(k) * rng.choice([1e-6, 1, 300], k), rng.uniform(0, 1, k), -rng.uniform(0, 1, k),
+            rng.standard_t(2, k), np.where(rng.uniform(size=k) < 0.9, 0, rng.standard_normal(k)), rng.standard_normal(k) * 1e-7, rng.standard_normal(k) * 2e3]
+    return np.stack(rows).astype(np.float32)
+
+
+def quantize_vectors():
+    """tests/golden/quantize.npz: the reference's quantize_row_*_reference (what llama_model_quantize writes) on quantize_inputs(), one byte row per (type, input row)"""
+    r = O.ref()
+    x = quantize_inputs()
+    out = {"x": x}
+    for t, name in QUANT_TYPES:
+        n = O.row_size(t, x.shape[1])
+        y = np.zeros((x.shape[0], n), np.uint8)
+        for i in range(x.shape[0]):
+            r.ref_quantize_reference(t, O._ptr(x[i]), O._ptr(y[i]), x.shape[1])
+        out[name] = y
+    np.savez_compressed(os.path.join(HERE, "quantize.npz"), **out)
+    print("quantize.npz", {k: v.shape for k, v in out.items()})
+
+
 def model_vectors(only=None):
     q = ref_quantizer()
     for stem, spec, ftype, seed in MODELS:
@@ -183,6 +209,8 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["legacy"]:
         kernel_vectors_legacy()
         model_vectors(only=["tiny_llama_q5_1", "tiny_llama_q5_0", "tiny_llama_q4_1"])
+    elif sys.argv[1:] == ["quantize"]:
+        quantize_vectors()
     elif sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
         model_vectors(only=["tiny_llama_q3_k_m"])
@@ -194,4 +222,5 @@ if __name__ == "__main__":
         kernel_vectors_q3k()
         kernel_vectors_q3k(O.Q2_K, "kernels_q2k.npz")
         kernel_vectors_legacy()
+        quantize_vectors()
         model_vectors()

@@ -248,6 +248,37 @@ def test_cli_driver_layer_split_across_processes(tmp_path, split, host_rings):
     assert bad.returncode == 2 and "start" in bad.stderr
 
 
+@pytest.mark.parametrize("spec,ftype,ftype_id", [("tiny-llama-b", "q4_k_m", 15), ("tiny-llama", "q3_k_m", 12), ("tiny-falcon40", "q5_k_m", 17), ("tiny-llama", "q5_0", 8)])
+def test_engine_runs_the_files_its_quantiser_writes(LL, tmp_path, spec, ftype, ftype_id):
+    """llama_model_quantize (csrc/engine/quantize.cpp) turns an fp32 model into the mixture the reference would write; the engine then decodes that
+    file and gives the oracle's logits bit for bit (prompt batch and single tokens)."""
+    import ctypes as C
+    from pipeinfer_amd.tools import synth
+    from tests import oracle_lib as O
+    from tests.test_quantize import QuantizeParams
+    src, dst = str(tmp_path / "f32.gguf"), str(tmp_path / "q.gguf")
+    synth.write_model(src, spec, "f32", seed=9, structure="random", std=0.05)
+    lib = LL.api()
+    lib.llama_model_quantize.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(QuantizeParams)]
+    lib.llama_model_quantize_default_params.restype = QuantizeParams
+    p = lib.llama_model_quantize_default_params()
+    p.ftype, p.nthread = ftype_id, 2
+    assert lib.llama_model_quantize(src.encode(), dst.encode(), C.byref(p)) == 0
+    m = LL.Model(dst)
+    c = LL.Context(m, n_ctx=128, n_batch=32)
+    o = O.OracleModel(dst, n_ctx=128, max_seq=2)
+    toks = [3, 17, 400, 250, 99, 12, 7]
+    got = c.decode(toks, list(range(len(toks))), [[0]] * len(toks))
+    want = o.decode(toks, list(range(len(toks))), [[0]] * len(toks))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for i in range(6):
+        t = int(np.argmax(got[-1]))
+        got = c.decode([t], [len(toks) + i], [[0]])
+        want = o.decode([t], [len(toks) + i], [[0]])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
+    o.close(); c.free(); m.free()
+
+
 def test_pipeinfer_driver_lossless_under_timing_jitter(LL):
     """the driver's control flow depends on which run finishes first, so repeat one configuration with fresh contexts
     (this caught target and draft contexts racing on a shared top-k scratch buffer)."""
