@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE — see oracle.h.  KV-cell bookkeeping of the reference (llama.cpp:1292-1301, 1593-1765) and the
-// PipeInfer attention-mask rule (llama.cpp:5200-5240), restated one operation at a time.  PARITY UNPINNED: llama.cpp
-// cannot be built here and the reference ships no test for these paths; the statements below follow the source text.
+// PipeInfer attention-mask rule (llama.cpp:5200-5240), restated one operation at a time.  PINNED: tests/test_kv_cells.py runs random operation
+// sequences through this file, the engine's table and the reference's own functions (llama.cpp compiled by ref_kv_harness.cpp into _ref/libref_kv.so);
+// restated only: o_kv_pre_decode / o_kv_post_decode / o_kv_n / o_kv_build_mask, whose originals sit inside llama_decode_internal.
 #include "oracle.h"
 
 #include <limits.h>

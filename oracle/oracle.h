@@ -5,9 +5,9 @@
 // (paths relative to /root/reference).  Parity status: PINNED for the tensor arithmetic (quantisers, dot
 // products, norms, RoPE, softmax, activations, attention, whole-model logits) against the real reference
 // library built by `make ref` (oracle/_ref/, tests/test_oracle_vs_ref.py) and against committed golden vectors
-// generated from it (tests/golden/).  UNPINNED for KV-cell bookkeeping and the attention-mask rule
-// (oracle/kvcache.c): llama.cpp cannot be compiled in this image (needs <mpi.h>) and the reference has no test
-// for those paths; they are restated from source and cross-checked only against hand-worked cases.
+// generated from it (tests/golden/); PINNED for KV-cell bookkeeping (oracle/kvcache.c) against the reference's own
+// llama_kv_cache_* functions, compiled from llama.cpp by ref_kv_harness.cpp (tests/test_kv_cells.py).  Restated only: the
+// decode-level head rules and the mask loop, which sit inside llama_decode_internal / the graph callback.
 //
 // Where the reference has several SIMD arms, the oracle follows the x86 AVX2/FMA/F16C arm (the one `make ref`
 // compiles and the one the paper's x86 CPU clusters ran), *including its floating-point summation order*

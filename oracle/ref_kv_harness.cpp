@@ -1,0 +1,41 @@
+// TEST INFRASTRUCTURE.  The REAL reference KV-cache bookkeeping: this translation unit includes the reference's llama.cpp from where it
+// lies under $(REF) (never copied) and calls its file-static functions — llama_kv_cache_find_slot (llama.cpp:1593-1644), _cell_max (:1647),
+// _clear (:1657), _seq_rm (:1666), _seq_cp (:1699), _seq_keep (:1717) — on a bare `struct llama_kv_cache` (cells only, no tensors).
+// llama.cpp is compiled with -DGGML_USE_MPI exactly as PipeInfer builds it: ggml-mpi.h declares the MPI layer without including <mpi.h>, so
+// the file compiles with plain g++; the ggml_mpi_* functions stay undefined in the shared object and are never reached from here (the
+// KV-cell functions touch no communicator), the library is opened with lazy binding.  Nothing stands in for MPI.
+// The decode-level rules around find_slot (head reset :5548-5550, n = min(n_ctx, max(32, cell_max)) :5571, head advance :5708-5713) sit
+// inside llama_decode_internal and cannot be called on their own: the test applies them from oracle/kvcache.c on top of these functions.
+#include "llama.cpp"
+
+#define REFKV_API extern "C" __attribute__((visibility("default")))
+
+REFKV_API void * refkv_new(int n_ctx) {
+    llama_kv_cache * c = new llama_kv_cache();
+    c->size = (uint32_t) n_ctx;
+    c->cells.clear();
+    c->cells.resize((size_t) n_ctx);                                       // llama_kv_cache_init, llama.cpp:1538-1539
+    return c;
+}
+REFKV_API void refkv_free(void * c) { delete (llama_kv_cache *) c; }
+
+REFKV_API int refkv_find_slot(void * vc, int n_tokens, const int32_t * pos, const int32_t * n_seq_id, const int32_t * seq_ids_flat, int stride) {
+    llama_kv_cache & c = *(llama_kv_cache *) vc;
+    std::vector<llama_seq_id *> rows((size_t) n_tokens);
+    for (int i = 0; i < n_tokens; i++) rows[i] = const_cast<llama_seq_id *>(seq_ids_flat) + (size_t) i * stride;
+    llama_batch b;
+    memset(&b, 0, sizeof b);
+    b.n_tokens = n_tokens; b.pos = const_cast<llama_pos *>(pos); b.n_seq_id = const_cast<int32_t *>(n_seq_id); b.seq_id = rows.data();
+    return llama_kv_cache_find_slot(c, b) ? (int) c.head : -1;
+}
+REFKV_API int  refkv_cell_max(void * c) { return llama_kv_cache_cell_max(*(llama_kv_cache *) c); }
+REFKV_API void refkv_clear(void * c) { llama_kv_cache_clear(*(llama_kv_cache *) c); }
+REFKV_API void refkv_seq_rm(void * c, int seq, int p0, int p1) { llama_kv_cache_seq_rm(*(llama_kv_cache *) c, seq, p0, p1); }
+REFKV_API void refkv_seq_cp(void * c, int src, int dst, int p0, int p1) { llama_kv_cache_seq_cp(*(llama_kv_cache *) c, src, dst, p0, p1); }
+REFKV_API void refkv_seq_keep(void * c, int seq) { llama_kv_cache_seq_keep(*(llama_kv_cache *) c, seq); }
+REFKV_API int  refkv_head(void * c) { return (int) ((llama_kv_cache *) c)->head; }
+REFKV_API void refkv_set_head(void * c, int h) { ((llama_kv_cache *) c)->head = (uint32_t) h; }
+REFKV_API int  refkv_used(void * c) { return (int) ((llama_kv_cache *) c)->used; }
+REFKV_API int  refkv_cell_pos(void * c, int i) { return ((llama_kv_cache *) c)->cells[(size_t) i].pos; }
+REFKV_API int  refkv_cell_has(void * c, int i, int seq) { return ((llama_kv_cache *) c)->cells[(size_t) i].has_seq_id(seq) ? 1 : 0; }
+REFKV_API int  refkv_cell_nseq(void * c, int i) { return (int) ((llama_kv_cache *) c)->cells[(size_t) i].seq_id.size(); }

@@ -95,6 +95,42 @@ def have_ref():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libref_harness.so"))
 
 
+_ref_kv = None
+
+
+def ref_kv():
+    """The REAL reference KV-cell functions: the reference's llama.cpp compiled with oracle/ref_kv_harness.cpp (oracle/_ref/libref_kv.so); None where it
+    was never built.  The object keeps the MPI layer's functions undefined (nothing here reaches them), so it is opened with lazy binding — ctypes itself
+    always asks for RTLD_NOW."""
+    global _ref_kv
+    if _ref_kv is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_kv.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference"):
+                subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+            else:
+                return None
+        ref()                                                                # libggml_ref.so first, from the same directory
+        libc = C.CDLL(None)
+        libc.dlopen.restype, libc.dlopen.argtypes = C.c_void_p, [C.c_char_p, C.c_int]
+        h = libc.dlopen(path.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+        assert h, path
+        lib = C.CDLL(path, handle=h)
+        lib.refkv_new.restype, lib.refkv_new.argtypes = C.c_void_p, [C.c_int]
+        lib.refkv_free.argtypes = [C.c_void_p]
+        lib.refkv_find_slot.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        for f in ("refkv_cell_max", "refkv_clear", "refkv_head", "refkv_used"):
+            getattr(lib, f).argtypes = [C.c_void_p]
+        lib.refkv_set_head.argtypes = [C.c_void_p, C.c_int]
+        lib.refkv_seq_rm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.refkv_seq_cp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.refkv_seq_keep.argtypes = [C.c_void_p, C.c_int]
+        lib.refkv_cell_pos.argtypes = lib.refkv_cell_nseq.argtypes = [C.c_void_p, C.c_int]
+        lib.refkv_cell_has.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _ref_kv = lib
+    return _ref_kv
+
+
 def ref():
     """The REAL reference kernels (ggml) behind our harness; None where oracle/_ref was never built."""
     global _ref

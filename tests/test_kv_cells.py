@@ -1,5 +1,6 @@
 """CPU: the engine's host KV-cell table (pipeinfer_amd/csrc/engine/kv_cells.cpp) against the oracle's restatement of the
-reference (oracle/kvcache.c) on random PipeInfer-style operation sequences, and the closed-form range operations against
+reference (oracle/kvcache.c) AND against the reference's own functions (llama.cpp compiled into oracle/_ref/libref_kv.so) on random
+PipeInfer-style operation sequences, and the closed-form range operations against
 the loops of single operations they replace (speculative.cpp:603-612, 1252-1268)."""
 import ctypes as C
 
@@ -64,6 +65,33 @@ class Orc:
         return out == 0
 
 
+class Ref:
+    """the reference's own llama.cpp functions (oracle/_ref/libref_kv.so): find_slot, seq_rm / cp / keep, cell_max on the real llama_kv_cache.  The three
+    decode-level lines around find_slot live inside llama_decode_internal, so they are applied here as the reference writes them: llama.cpp:5548-5550
+    (head back to 0 when it ran far ahead of the used cells), :5571 (n = min(n_ctx, max(32, cell_max))), :5708-5713 (head advances past the slot)."""
+
+    def __init__(self):
+        self.lib = O.ref_kv()
+        self.h = self.lib.refkv_new(N_CTX)
+
+    def decode(self, pos, seq_ids):
+        l, n = self.lib, len(pos)
+        cnt, flat = flatten_seq_ids(seq_ids, MAX_SEQ)
+        p = np.asarray(pos, np.int32)
+        if l.refkv_head(self.h) > l.refkv_used(self.h) + 2 * n:
+            l.refkv_set_head(self.h, 0)
+        head = l.refkv_find_slot(self.h, n, O._ptr(p), O._ptr(cnt), O._ptr(flat), MAX_SEQ)
+        if head >= 0:
+            nh = head + n
+            l.refkv_set_head(self.h, 0 if nh >= N_CTX else nh)
+        return head
+
+    def state(self):
+        l = self.lib
+        return (l.refkv_head(self.h), l.refkv_used(self.h), min(N_CTX, max(32, l.refkv_cell_max(self.h))),
+                [(l.refkv_cell_pos(self.h, i), tuple(s for s in range(MAX_SEQ) if l.refkv_cell_has(self.h, i, s))) for i in range(N_CTX)])
+
+
 def random_ops(rng, n_ops):
     ops = []
     n_past = 0
@@ -92,14 +120,14 @@ def apply(b, op):
     if op[0] == "decode":
         return b.decode(op[1], op[2])
     lib, h = b.lib, b.h
-    eng = isinstance(b, Eng)
+    pre = "pi_kvcells_" if isinstance(b, Eng) else "refkv_" if isinstance(b, Ref) else "o_kv_"
     if op[0] == "rm":
-        (lib.pi_kvcells_seq_rm if eng else lib.o_kv_seq_rm)(h, *op[1:])
+        getattr(lib, pre + "seq_rm")(h, *op[1:])
     elif op[0] == "cp":
         if op[1] != op[2]:                       # the public wrapper returns early for src == dst (llama.cpp:9303-9305)
-            (lib.pi_kvcells_seq_cp if eng else lib.o_kv_seq_cp)(h, *op[1:])
+            getattr(lib, pre + "seq_cp")(h, *op[1:])
     elif op[0] == "keep":
-        (lib.pi_kvcells_seq_keep if eng else lib.o_kv_seq_keep)(h, op[1])
+        getattr(lib, pre + "seq_keep")(h, op[1])
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -112,6 +140,30 @@ def test_engine_cells_equal_oracle_cells(seed):
         if op[0] == "decode":
             n_kv = e.state()[2]
             assert np.array_equal(e.mask(n_kv, op[1], op[2]), o.mask(n_kv, op[1], op[2]))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_engine_and_oracle_cells_equal_the_reference_functions(seed):
+    """pins the restatement (oracle/kvcache.c) AND the engine's bitset table to the reference's own code: the same random PipeInfer-style operation
+    sequences through llama.cpp's llama_kv_cache_find_slot / seq_rm / seq_cp / seq_keep / cell_max, compiled from the reference sources"""
+    if O.ref_kv() is None:
+        pytest.skip("oracle/_ref/libref_kv.so is not built here (needs the reference sources)")
+    rng = np.random.default_rng(1000 + seed)
+    e, o, r = Eng(), Orc(), Ref()
+    n_dec = 0
+    for op in random_ops(rng, 200):
+        got_r = apply(r, op)
+        assert apply(e, op) == got_r and apply(o, op) == got_r, op
+        sr = r.state()
+        assert e.state() == sr and o.state() == sr, op
+        if op[0] == "decode" and got_r >= 0:
+            # the attention mask is written inside the graph callback (llama.cpp:5212-5232: cell i is hidden from token j unless it carries one of the token's
+            # sequence ids and cells[i].pos <= pos[j]); stated here on the REFERENCE's cells
+            n_kv, cells = sr[2], sr[3]
+            want = np.array([[any(sq in cells[i][1] for sq in op[2][j]) and cells[i][0] <= op[1][j] for i in range(n_kv)] for j in range(len(op[1]))])
+            assert np.array_equal(e.mask(n_kv, op[1], op[2]), want) and np.array_equal(o.mask(n_kv, op[1], op[2]), want), op
+        n_dec += op[0] == "decode" and got_r is not None and got_r >= 0
+    assert n_dec > 20
 
 
 @pytest.mark.parametrize("seed", range(12))
