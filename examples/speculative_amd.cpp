@@ -153,10 +153,11 @@ int main(int argc, char ** argv) {
     if (tp) { pipeinfer_transport_shutdown(tp); }
     if (n < 0) { fprintf(stderr, "%s: generation failed (%d)\n", argv[0], n); if (tp) pipeinfer_transport_close(tp); return 1; }
 
-    char piece[64];
+    std::vector<char> piece(64);
     for (int i = 0; i < n; i++) {
-        const int len = llama_token_to_piece(mt, out[i], piece, (int) sizeof piece);
-        if (len > 0) fwrite(piece, 1, (size_t) len, stdout);
+        int len = llama_token_to_piece(mt, out[i], piece.data(), (int) piece.size());
+        if (len < 0) { piece.resize((size_t) -len); len = llama_token_to_piece(mt, out[i], piece.data(), (int) piece.size()); }   // -len = the size the piece needs (common.cpp:1112-1127)
+        if (len > 0) fwrite(piece.data(), 1, (size_t) len, stdout);
     }
     printf("\n\ntokens:");
     for (int i = 0; i < n; i++) printf(" %d", out[i]);

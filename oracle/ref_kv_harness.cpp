@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE.  The REAL reference KV-cache bookkeeping: this translation unit includes the reference's llama.cpp from where it
+// TEST INFRASTRUCTURE.  The REAL reference KV-cache bookkeeping (and, at the end, its tokenizers): this translation unit includes the reference's llama.cpp from where it
 // lies under $(REF) (never copied) and calls its file-static functions — llama_kv_cache_find_slot (llama.cpp:1593-1644), _cell_max (:1647),
 // _clear (:1657), _seq_rm (:1666), _seq_cp (:1699), _seq_keep (:1717) — on a bare `struct llama_kv_cache` (cells only, no tensors).
 // llama.cpp is compiled with -DGGML_USE_MPI exactly as PipeInfer builds it: ggml-mpi.h declares the MPI layer without including <mpi.h>, so
@@ -39,3 +39,20 @@ REFKV_API int  refkv_used(void * c) { return (int) ((llama_kv_cache *) c)->used;
 REFKV_API int  refkv_cell_pos(void * c, int i) { return ((llama_kv_cache *) c)->cells[(size_t) i].pos; }
 REFKV_API int  refkv_cell_has(void * c, int i, int seq) { return ((llama_kv_cache *) c)->cells[(size_t) i].has_seq_id(seq) ? 1 : 0; }
 REFKV_API int  refkv_cell_nseq(void * c, int i) { return (int) ((llama_kv_cache *) c)->cells[(size_t) i].seq_id.size(); }
+
+// ---- the reference's tokenizers (llm_tokenizer_spm / llm_tokenizer_bpe behind llama_tokenize, llama.cpp:5970-6640) on a vocabulary-only model ----------
+// llama_load_model_from_file with vocab_only reads the GGUF header and the vocabulary and reaches no MPI call.
+static void reftok_quiet(ggml_log_level, const char *, void *) {}
+REFKV_API void * reftok_load(const char * path) {
+    llama_log_set(reftok_quiet, NULL);
+    llama_model_params p = llama_model_default_params();
+    p.vocab_only = true;
+    return llama_load_model_from_file(path, p);
+}
+REFKV_API void reftok_free(void * m) { llama_free_model((llama_model *) m); }
+REFKV_API int  reftok_n_vocab(void * m) { return llama_n_vocab((llama_model *) m); }
+REFKV_API int  reftok_tokenize(void * m, const char * text, int len, int32_t * out, int cap, int add_bos, int special) {
+    try { return llama_tokenize((llama_model *) m, text, len, out, cap, add_bos != 0, special != 0); }
+    catch (const std::exception &) { return -1000000; }                   // (the reference lets "byte not found in vocab" escape to its caller)
+}
+REFKV_API int  reftok_piece(void * m, int32_t token, char * buf, int cap) { return llama_token_to_piece((llama_model *) m, token, buf, cap); }

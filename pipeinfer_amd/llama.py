@@ -171,6 +171,9 @@ class Model:
     def token_to_piece(self, tok):
         buf = C.create_string_buffer(64)
         n = self.lib.llama_token_to_piece(self.h, tok, buf, 64)
+        if n < 0:                                      # -n = the length the piece needs (llama.cpp:10112-10150), like the reference's common.cpp helper
+            buf = C.create_string_buffer(-n)
+            n = self.lib.llama_token_to_piece(self.h, tok, buf, -n)
         return buf.raw[:max(n, 0)]
 
     def free(self):

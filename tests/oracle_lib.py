@@ -127,6 +127,10 @@ def ref_kv():
         lib.refkv_seq_keep.argtypes = [C.c_void_p, C.c_int]
         lib.refkv_cell_pos.argtypes = lib.refkv_cell_nseq.argtypes = [C.c_void_p, C.c_int]
         lib.refkv_cell_has.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.reftok_load.restype, lib.reftok_load.argtypes = C.c_void_p, [C.c_char_p]
+        lib.reftok_free.argtypes = lib.reftok_n_vocab.argtypes = [C.c_void_p]
+        lib.reftok_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.reftok_piece.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int]
         _ref_kv = lib
     return _ref_kv
 

@@ -159,3 +159,52 @@ def test_bpe_every_token_and_codepoint_round_trips(falcon):
     for cp in range(0x10000, 0x40000, 5):                                        # :96-97 "restrict to assigned unicode planes" (sampled)
         text = chr(cp)
         assert _detok_bpe(falcon, falcon.tokenize(text, add_bos=False)) == text.encode("utf-8"), hex(cp)
+
+
+# ---- against the reference's own tokenizers (llama.cpp compiled into oracle/_ref/libref_kv.so, see oracle/ref_kv_harness.cpp) -----------------------------
+FUZZ_POOL = [" ", "  ", "\n", "\t", "a", "b", "Hello", "world", "the", " the", "ing", "1", "22", "333", "4444", "'s", "'t", "'re", "'ll", "n't", ".", ",", "!", "?", "...", "-", "_", "(", ")",
+             "é", "ü", "ß", "Ж", "привет", "日本", "語", "中文", "한국어", "🦙", "😶‍🌫️", "✅", "́", "‍", " ", "　", "\x01", "\x7f", "<s>", "</s>", "<unk>", "<|endoftext|>",
+             ">>TITLE<<", "İ", "ǅ", "ﬁ", "０", "²", "½", "\r\n", "\x0b"]
+
+
+@pytest.mark.parametrize("which", ["llama", "falcon"])
+def test_random_text_tokenizes_like_the_reference_tokenizer(which, model, falcon):
+    """differential test beyond the reference's known answers: random mixtures of words, digit runs, contractions, white space of every kind, accented / CJK /
+    emoji / combining / control characters and special-token texts go through llama_tokenize of the reference's llama.cpp and through ours, with and without
+    BOS, with and without special-token parsing; plus every token's piece"""
+    import ctypes as C
+    import numpy as np
+    from tests import oracle_lib as O
+    r = O.ref_kv()
+    if r is None:
+        pytest.skip("oracle/_ref/libref_kv.so is not built here (needs the reference sources)")
+    mine = model if which == "llama" else falcon
+    ref = r.reftok_load((VOCAB if which == "llama" else VOCAB_FALCON).encode())
+    assert ref and r.reftok_n_vocab(ref) == mine.n_vocab
+
+    def ref_tok(text, bos, special):
+        b = text.encode("utf-8")
+        out = np.zeros(len(b) + 16, np.int32)
+        n = r.reftok_tokenize(ref, b, len(b), out.ctypes.data, out.size, int(bos), int(special))
+        return None if n == -1000000 else [int(x) for x in out[:n]]          # None: the reference throws ("byte not found in vocab")
+
+    rng = np.random.default_rng(3 if which == "llama" else 4)
+    compared = 0
+    for trial in range(700):
+        n = int(rng.integers(1, 12))
+        if trial % 7 == 0:
+            text = "".join(chr(int(c)) for c in rng.integers(32, 0x3000, n))
+        else:
+            text = "".join(FUZZ_POOL[int(i)] for i in rng.integers(0, len(FUZZ_POOL), n))
+        for bos in (False, True):
+            for special in (False, True):
+                want = ref_tok(text, bos, special)
+                if want is not None:
+                    assert mine.tokenize(text, add_bos=bos, special=special) == want, (text, bos, special)
+                    compared += 1
+    assert compared > 2000
+    buf = C.create_string_buffer(256)
+    for t in range(mine.n_vocab):
+        n = r.reftok_piece(ref, t, buf, 256)
+        assert mine.token_to_piece(t) == buf.raw[:n], t
+    r.reftok_free(ref)
