@@ -131,6 +131,10 @@ def ref_kv():
         lib.reftok_free.argtypes = lib.reftok_n_vocab.argtypes = [C.c_void_p]
         lib.reftok_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.reftok_piece.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int]
+        lib.refmodel_load.restype, lib.refmodel_load.argtypes = C.c_void_p, [C.c_char_p, C.c_int, C.c_int]
+        lib.refmodel_kv.restype, lib.refmodel_kv.argtypes = C.c_void_p, [C.c_void_p]
+        lib.refmodel_free.argtypes = lib.refmodel_n_vocab.argtypes = [C.c_void_p]
+        lib.refmodel_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _ref_kv = lib
     return _ref_kv
 
@@ -331,6 +335,42 @@ class OracleModel:
 
     def close(self):
         self.lib.o_model_free(self.h)
+
+
+class RefLlama:
+    """the reference's OWN model code: llama.cpp's loader, KV cache, graph builders (build_llama / build_falcon) and ggml kernels, compiled from the reference
+    sources into oracle/_ref/libref_kv.so (oracle/ref_kv_harness.cpp: only the MPI-calling shells of llama_new_context_with_model / llama_decode_internal are
+    replaced by their own few lines).  Same interface as OracleModel."""
+
+    def __init__(self, path, n_ctx=128, max_seq=8, n_threads=2):
+        self.lib = ref_kv()
+        self.h = self.lib.refmodel_load(path.encode(), n_ctx, n_threads)
+        assert self.h, path
+        self.kv = self.lib.refmodel_kv(self.h)
+        self.n_vocab = self.lib.refmodel_n_vocab(self.h)
+        self.stride = max_seq
+
+    def decode(self, tokens, pos, seq_ids):
+        from tests.scenarios import flatten_seq_ids
+        n = len(tokens)
+        cnt, flat = flatten_seq_ids(seq_ids, self.stride)
+        t = np.asarray(tokens, np.int32); p = np.asarray(pos, np.int32)
+        out = np.zeros((n, self.n_vocab), np.float32)
+        assert self.lib.refmodel_decode(self.h, n, _ptr(t), _ptr(p), _ptr(cnt), _ptr(flat), self.stride, _ptr(out)) >= 0
+        return out
+
+    def seq_rm(self, s, p0, p1):
+        self.lib.refkv_seq_rm(self.kv, s, p0, p1)
+
+    def seq_cp(self, a, b, p0, p1):
+        if a != b:                                   # the public wrapper returns early (llama.cpp:9303-9305)
+            self.lib.refkv_seq_cp(self.kv, a, b, p0, p1)
+
+    def seq_keep(self, s):
+        self.lib.refkv_seq_keep(self.kv, s)
+
+    def close(self):
+        self.lib.refmodel_free(self.h)
 
 
 class RefModel:

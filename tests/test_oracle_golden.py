@@ -87,6 +87,35 @@ def test_model_scenarios_golden(stem):
     m.close()
 
 
+@pytest.mark.parametrize("stem", MODELS)
+def test_model_scenarios_through_the_reference_graph_builders(stem):
+    """the strongest pin of the whole-model path: the reference's own llama.cpp — GGUF loader, KV cache, build_llama / build_falcon graphs, ggml kernels —
+    decodes the PipeInfer-style KV script and the greedy continuation of every fixture (O.RefLlama); the oracle's logits are the same BITS on every decode,
+    and the committed goldens (made through our own one-node graphs on the reference kernels) agree"""
+    if O.ref_kv() is None:
+        pytest.skip("oracle/_ref/libref_kv.so is not built here (needs the reference sources)")
+    g = np.load(os.path.join(GOLD, stem + ".npz"))
+    path = os.path.join(GOLD, stem + ".gguf")
+    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20}[stem]
+    r, m = O.RefLlama(path, n_ctx=128, max_seq=8), O.OracleModel(path, n_ctx=128, max_seq=8)
+    ops = S.scenario_spec_like(m.n_vocab, seed=seed)
+    outs_r, outs_m = S.run_scenario(ops, r), S.run_scenario(ops, m)
+    for i, (a, b) in enumerate(zip(outs_r, outs_m)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (stem, i, np.abs(a - b).max())
+        assert np.allclose(a, g[f"spec_like_{i}"], rtol=0, atol=1e-5)
+    assert r.lib.refkv_head(r.kv) == m.lib.o_kv_head(m.kv) and r.lib.refkv_used(r.kv) == m.lib.o_kv_used(m.kv)
+    r.close(); m.close()
+    prompt, n_gen = S.scenario_greedy(512, seed=seed)
+    r = O.RefLlama(path, n_ctx=128, max_seq=8)
+    lg = r.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
+    toks, cur = [], int(np.argmax(lg[-1]))
+    for i in range(n_gen):
+        toks.append(cur)
+        cur = int(np.argmax(r.decode([cur], [len(prompt) + i], [[0]])[0]))
+    assert toks == list(g["greedy_tokens"])                  # the losslessness ground truth of every engine test
+    r.close()
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 def test_rope_composition_property(mode):
     """the reference's tests/test-rope.cpp:138-215: rotating by p0 and then by delta equals rotating by p0 + delta (relative error < 1e-4);
