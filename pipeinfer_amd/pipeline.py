@@ -244,7 +244,17 @@ def bench_main(args, rank, world):
     # gloo only: rendezvous, barriers and the statistics gather.  torch never touches the GPU in this process (no import-order constraint
     # between torch's HIP runtime state and libpipeinfer_amd.so), and nothing below is called per run.
     if not dist.is_initialized():
-        dist.init_process_group("gloo")
+        # gloo announces its mesh ("[Gloo] Rank 0 is connected to ...") on STDOUT, which belongs to the one JSON line: park fd 1 on stderr meanwhile
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     lib = L.load()
     n_dev = max(1, lib.pi_device_count())
     local = int(os.environ.get("LOCAL_RANK", str(rank))) % n_dev
