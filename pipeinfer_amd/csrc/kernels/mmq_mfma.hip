@@ -56,6 +56,11 @@ bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || t
 bool pi_mmq_wants(int type, int n_tok, int64_t rows) {
     if (!pi_mmq_supported(type) || n_tok < pi_mmq_min_nt()) return false;
     if (type == PI_Q6_K) return n_tok >= 5 && (rows >= 4096 || n_tok > 8);
+    // short launches: a row group walks its K / 256 blocks one after the other (13.4 us at K = 8192 however few rows there are), while the VALU kernel's
+    // tile-per-wave instances put every tile of a short matrix in flight at once.  Measured (us, 3 / 4 / 8 tokens, matrix cores vs VALU): 1024 x 8192 Q5_K (attn_v of
+    // a GQA model) 14.5 / 14.5 / 14.5 vs 6.4 / 7.0 / 9.9; 2048 x 8192 13.7 / 13.5 / 13.6 vs 8.5 / 10.4 / 14.9; 4096 x 8192 14.4 / 14.1 / 13.9 vs 12.0 / 13.6 / 21.3;
+    // 8192 x 8192 17.1 / 16.3 / 16.3 vs 19.4 / 22.1 / 44.8; 4096 x 4096 9.4 / 9.0 / 8.9 vs 7.9 / 8.4 / 12.1; 2048 x 2048 6.3 / 6.0 / 5.9 vs 5.8 / 5.9 / 7.6
+    if (n_tok <= 8 && rows * n_tok < 16384) return false;
     return true;
 }
 
