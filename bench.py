@@ -93,7 +93,11 @@ def committed_traffic(workload, kernel_key):
 
 def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):
     from tests import oracle_lib as O
-    if O.have_ref() and O.ref() is not None:
+    if O.have_ref() and O.ref_kv() is not None:
+        # the reference's own llama.cpp — loader, KV cache, graph builder, ggml thread pool — compiled from its sources (oracle/ref_kv_harness.cpp)
+        m = O.RefLlama(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2, n_threads=cores)
+        kind = "reference"
+    elif O.have_ref() and O.ref() is not None:
         m = O.RefModel(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2, n_threads=cores)
         kind = "reference"
     else:
@@ -118,7 +122,7 @@ def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):
 
 
 def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_prompt=4):
-    """Reference CPU kernels (oracle/_ref: the reference's ggml compiled from its own sources) decoding the target model token by
+    """The reference's CPU path (oracle/_ref: its llama.cpp graph builder on its ggml kernels, compiled from its own sources) decoding the target model token by
     token on the host cores; falls back to our C port of them (oracle/liboracle.so).  Test infrastructure: only this leg of bench.py
     touches oracle/.  Models that fit the time budget are decoded whole; the 70B target is timed on two depth-truncated copies (4 and 8
     layers with the tensor types of layers 8..15 of the 80 — half of them "more bits" layers, like the whole model) and extrapolated
