@@ -113,6 +113,8 @@ def test_mul_mat_golden_blocks(gpu, t):
                                           (8192, 8198, 1), (8192, 8198, 2),
                                           # matrix-core kernel (2..16 tokens per pass, 1/2/4/8 waves per 16-row group, ragged row groups, prompts in chunks of 16)
                                           (4096, 64, 16), (4096, 49, 9), (8192, 2064, 12), (28672, 40, 16), (2048, 16, 2), (512, 4100, 13), (4096, 80, 17), (1024, 32, 37),
+                                          # ... batches of <= 8 tokens reach it from rows x tokens >= 16384 (half-size fragments); 513..768 row groups run three to a workgroup
+                                          (512, 4100, 5), (1024, 2100, 8), (256, 5500, 3), (512, 9222, 5), (256, 8200, 3), (768, 12288, 16), (512, 12000, 2),
                                           # Q4_0 / Q8_0 range-per-wave kernel: 4, 8, 12 groups per wave, ragged last wave, rows not a multiple of 8
                                           (1024, 19, 1), (4544, 71, 1), (4544, 71, 2), (16384, 9, 1), (18176, 13, 1), (24576, 11, 1), (24576, 11, 2), (32768, 8, 1)])
 def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
