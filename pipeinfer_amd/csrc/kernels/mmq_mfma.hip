@@ -452,7 +452,7 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
     // 8 waves that share the staged activations, while keeping >= 256 workgroups.  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
     static const int cfg_env = getenv("PI_MMQ_CFG") ? atoi(getenv("PI_MMQ_CFG")) : 0;
     int cfg;
-    if (groups >= 1536) cfg = groups <= 7 * 256 ? 17 : 18;           // S = 1: the fewest row groups per workgroup (7 or 8) that still fit the launch into one round of 256 workgroups
+    if (groups > 1152) cfg = groups <= 7 * 256 ? 17 : 18;            // (measured crossover against S = 2: 1024 row groups 32.5 vs 34.0 us, 1280: 42.3 vs 36.3, 1376 at K = 4096: 25.5 vs 22.3)           // S = 1: the fewest row groups per workgroup (7 or 8) that still fit the launch into one round of 256 workgroups
     else if (groups > 768) cfg = 24;
     else if (groups > 512) cfg = 43;                                    // 513..768 row groups: three per workgroup keep the launch in ONE round of <= 256 workgroups (two per workgroup: 288-384
                                                                         // workgroups, a second round at the kernel's latency floor): 9216 x 8192 23.9 -> 19.9 us, 12288 x 4096 17.1 -> 13.6, 11008 x 4096 15.6 -> 13.8
