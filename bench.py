@@ -95,30 +95,36 @@ def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):
     from tests import oracle_lib as O
     if O.have_ref() and O.ref_kv() is not None:
         # the reference's own llama.cpp — loader, KV cache, graph builder, ggml thread pool — compiled from its sources (oracle/ref_kv_harness.cpp)
-        m = O.RefLlama(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2, n_threads=cores)
+        m = O.RefLlama(path, n_ctx=max(64, n_prompt + 2 * n_tokens + 8), max_seq=2, n_threads=cores)
         kind = "reference"
     elif O.have_ref() and O.ref() is not None:
-        m = O.RefModel(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2, n_threads=cores)
+        m = O.RefModel(path, n_ctx=max(64, n_prompt + 2 * n_tokens + 8), max_seq=2, n_threads=cores)
         kind = "reference"
     else:
         O.oracle().o_set_threads(cores)
-        m = O.OracleModel(path, n_ctx=max(64, n_prompt + n_tokens + 8), max_seq=2)
+        m = O.OracleModel(path, n_ctx=max(64, n_prompt + 2 * n_tokens + 8), max_seq=2)
         kind = "port"
     rng = np.random.default_rng(7)
     prompt = [int(x) for x in rng.integers(3, m.n_vocab, n_prompt)]
     lg = m.decode(prompt, list(range(n_prompt)), [[0]] * n_prompt)
     cur = int(np.argmax(lg[-1]))
-    t0 = time.time()
-    done = 0
-    for i in range(n_tokens):
-        lg = m.decode([cur], [n_prompt + i], [[0]])
-        cur = int(np.argmax(lg[0]))
-        done += 1
-        if time.time() - t0 > budget_s:          # bounded sample
-            break
-    dt = time.time() - t0
+    # two passes of n_tokens, the faster one counts: ggml's spin-waiting thread pool is sensitive to whatever else the host is doing at that moment
+    best, done_best, pos = None, 0, n_prompt
+    for rep in range(2):
+        t0 = time.time()
+        done = 0
+        for i in range(n_tokens):
+            lg = m.decode([cur], [pos], [[0]])
+            cur = int(np.argmax(lg[0]))
+            pos += 1
+            done += 1
+            if time.time() - t0 > budget_s / 2:  # bounded sample
+                break
+        spt = (time.time() - t0) / done
+        if best is None or spt < best:
+            best, done_best = spt, done
     m.close()
-    return dt / done, done, kind
+    return best, done_best, kind
 
 
 def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_prompt=4):
