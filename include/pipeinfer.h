@@ -112,6 +112,8 @@ LLAMA_API int  pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
  * reference's deterministic quantize_row_*_reference arithmetic (ggml-quants.c:428-640, 1458-2316) — what llama_model_quantize applies to every row.
  * k: number of values, a multiple of the block size.  Returns the bytes written, -1 on a bad type / length. */
 LLAMA_API int64_t pipeinfer_quantize_row(int32_t type, const float * x, void * y, int64_t k);
+/* the inverse direction (dequantize_row_*, ggml-quants.c:1074-1188, 1535-2310): k stored values of `type` as fp32, bit-identical to the reference.  Returns k or -1. */
+LLAMA_API int64_t pipeinfer_dequantize_row(int32_t type, const void * x, float * y, int64_t k);
 LLAMA_API int  pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp);
 
 struct pipeinfer_stats {

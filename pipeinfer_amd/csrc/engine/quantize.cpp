@@ -411,6 +411,100 @@ void row_q6_K(const float * x, uint8_t * out, int64_t k) {                      
     }
 }
 
+// ---- back to fp32 (dequantize_row_*, ggml-quants.c:1074-1188, 1535-1575, 1711-1757, 1917-1954, 2117-2165, 2263-2310): what --allow-requantize feeds the quantisers.
+//      Every value is ONE product (and at most one add or subtract) in the reference's order, so the floats are the reference's bit for bit. ----
+void deq_legacy(int type, const uint8_t * in, float * y, int64_t k) {
+    const bool affine = type == 3 || type == 7, five = type == 6 || type == 7;
+    const int bytes = 2 + (affine ? 2 : 0) + (five ? 4 : 0) + 16;
+    for (int64_t b = 0; b < k / 32; b++, in += bytes, y += 32) {
+        uint16_t dh, mh = 0; memcpy(&dh, in, 2);
+        if (affine) memcpy(&mh, in + 2, 2);
+        const float d = half_to_float(dh), m = half_to_float(mh);
+        const uint8_t * p = in + 2 + (affine ? 2 : 0);
+        uint32_t qh = 0;
+        if (five) { memcpy(&qh, p, 4); p += 4; }
+        for (int j = 0; j < 16; j++) {
+            const int h0 = five ? (int) (((qh >> j) << 4) & 0x10) : 0, h1 = five ? (int) ((qh >> (j + 12)) & 0x10) : 0;
+            const int lo = (p[j] & 0x0F) | h0, hi = (p[j] >> 4) | h1;
+            if (affine) { y[j] = lo * d + m; y[j + 16] = hi * d + m; }
+            else { const int off = five ? 16 : 8; y[j] = (lo - off) * d; y[j + 16] = (hi - off) * d; }
+        }
+    }
+}
+void deq_q8_0(const uint8_t * in, float * y, int64_t k) {
+    for (int64_t b = 0; b < k / 32; b++, in += 34, y += 32) {
+        uint16_t dh; memcpy(&dh, in, 2);
+        const float d = half_to_float(dh);
+        for (int j = 0; j < 32; j++) y[j] = (int8_t) in[2 + j] * d;
+    }
+}
+void deq_q2_K(const uint8_t * in, float * y, int64_t k) {
+    for (int64_t b = 0; b < k / 256; b++, in += 84) {
+        uint16_t dh, mh; memcpy(&dh, in + 80, 2); memcpy(&mh, in + 82, 2);
+        const float d = half_to_float(dh), mn = half_to_float(mh);
+        const uint8_t * sc = in, * q = in + 16;
+        int is = 0;
+        for (int n = 0; n < 256; n += 128, q += 32)
+            for (int j = 0, shift = 0; j < 4; j++, shift += 2)
+                for (int half = 0; half < 2; half++) {
+                    const uint8_t s8 = sc[is++];
+                    const float dl = d * (s8 & 0xF), ml = mn * (s8 >> 4);
+                    for (int l = 0; l < 16; l++) *y++ = dl * ((int8_t) ((q[l + 16 * half] >> shift) & 3)) - ml;
+                }
+    }
+}
+void deq_q3_K(const uint8_t * in, float * y, int64_t k) {
+    for (int64_t b = 0; b < k / 256; b++, in += 110) {
+        uint16_t dh; memcpy(&dh, in + 108, 2);
+        const float d_all = half_to_float(dh);
+        const uint8_t * hm = in, * q = in + 32, * sp = in + 96;
+        int8_t s6[16];                                                                        // the sixteen 6-bit scales: low nibbles in bytes 0..7, top two bits in bytes 8..11
+        for (int j = 0; j < 16; j++) s6[j] = (int8_t) ((j < 8 ? sp[j] & 0xF : sp[j - 8] >> 4) | (((sp[8 + j % 4] >> (2 * (j / 4))) & 3) << 4));
+        int is = 0;
+        uint8_t m = 1;
+        for (int n = 0; n < 256; n += 128, q += 32)
+            for (int j = 0, shift = 0; j < 4; j++, shift += 2, m = (uint8_t) (m << 1))
+                for (int half = 0; half < 2; half++) {
+                    const float dl = d_all * (s6[is++] - 32);
+                    for (int l = 0; l < 16; l++) *y++ = dl * ((int8_t) ((q[l + 16 * half] >> shift) & 3) - ((hm[l + 16 * half] & m) ? 0 : 4));
+                }
+    }
+}
+template <int BITS>
+void deq_q45_K(const uint8_t * in, float * y, int64_t k) {
+    constexpr int BYTES = BITS == 4 ? 144 : 176;
+    for (int64_t b = 0; b < k / 256; b++, in += BYTES) {
+        uint16_t dh, mh; memcpy(&dh, in, 2); memcpy(&mh, in + 2, 2);
+        const float d = half_to_float(dh), mn = half_to_float(mh);
+        const uint8_t * sc = in + 4, * qh = in + 16, * ql = in + (BITS == 4 ? 16 : 48);
+        uint8_t u1 = 1, u2 = 2;
+        for (int j = 0, is = 0; j < 256; j += 64, ql += 32, is += 2, u1 = (uint8_t) (u1 << 2), u2 = (uint8_t) (u2 << 2)) {
+            uint8_t s, m;
+            unpack_scale_min(is, sc, s, m);
+            const float d1 = d * s, m1 = mn * m;
+            unpack_scale_min(is + 1, sc, s, m);
+            const float d2 = d * s, m2 = mn * m;
+            for (int l = 0; l < 32; l++) *y++ = d1 * ((ql[l] & 0xF) + (BITS == 5 && (qh[l] & u1) ? 16 : 0)) - m1;
+            for (int l = 0; l < 32; l++) *y++ = d2 * ((ql[l] >> 4) + (BITS == 5 && (qh[l] & u2) ? 16 : 0)) - m2;
+        }
+    }
+}
+void deq_q6_K(const uint8_t * in, float * y, int64_t k) {
+    for (int64_t b = 0; b < k / 256; b++, in += 210) {
+        uint16_t dh; memcpy(&dh, in + 208, 2);
+        const float d = half_to_float(dh);
+        const uint8_t * ql = in, * qh = in + 128;
+        const int8_t * sc = (const int8_t *) (in + 192);
+        for (int n = 0; n < 256; n += 128, y += 128, ql += 64, qh += 32, sc += 8)
+            for (int l = 0; l < 32; l++) {
+                const int is = l / 16;
+                const int8_t q1 = (int8_t) ((int8_t) ((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32), q2 = (int8_t) ((int8_t) ((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32);
+                const int8_t q3 = (int8_t) ((int8_t) ((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32), q4 = (int8_t) ((int8_t) ((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32);
+                y[l] = d * sc[is] * q1; y[l + 32] = d * sc[is + 2] * q2; y[l + 64] = d * sc[is + 4] * q3; y[l + 96] = d * sc[is + 6] * q4;
+            }
+    }
+}
+
 enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14 };
 
 int block_elems(int type) { return type >= T_Q2_K ? 256 : (type >= T_Q4_0 ? 32 : 1); }
@@ -429,6 +523,21 @@ bool quantize_elems(int type, const float * x, uint8_t * out, int64_t k) {
         case T_Q4_K: row_q45_K<4>(x, out, k); return true;
         case T_Q5_K: row_q45_K<5>(x, out, k); return true;
         case T_Q6_K: row_q6_K(x, out, k); return true;
+    }
+    return false;
+}
+
+bool dequantize_elems(int type, const uint8_t * in, float * y, int64_t k) {
+    switch (type) {
+        case T_F32:  memcpy(y, in, (size_t) k * 4); return true;
+        case T_F16:  for (int64_t i = 0; i < k; i++) { uint16_t h; memcpy(&h, in + 2 * i, 2); y[i] = half_to_float(h); } return true;
+        case T_Q4_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: deq_legacy(type, in, y, k); return true;
+        case T_Q8_0: deq_q8_0(in, y, k); return true;
+        case T_Q2_K: deq_q2_K(in, y, k); return true;
+        case T_Q3_K: deq_q3_K(in, y, k); return true;
+        case T_Q4_K: deq_q45_K<4>(in, y, k); return true;
+        case T_Q5_K: deq_q45_K<5>(in, y, k); return true;
+        case T_Q6_K: deq_q6_K(in, y, k); return true;
     }
     return false;
 }
@@ -500,6 +609,13 @@ extern "C" int64_t pipeinfer_quantize_row(int32_t type, const float * x, void * 
     return (int64_t) pi::type_row_size(type, k);
 }
 
+// fp32 values of k stored values of `type` (dequantize_row_*); returns k, -1 on a bad type / length
+extern "C" int64_t pipeinfer_dequantize_row(int32_t type, const void * x, float * y, int64_t k) {
+    const int be = block_elems(type);
+    if (k < 0 || k % be != 0 || pi::type_row_size(type, be) == 0) return -1;
+    return dequantize_elems(type, (const uint8_t *) x, y, k) ? k : -1;
+}
+
 extern "C" int llama_model_quantize(const char * fname_inp, const char * fname_out, const llama_model_quantize_params * params) {
     int base;
     switch (params->ftype) {                                                                  // llama.cpp:8013-8036
@@ -545,8 +661,8 @@ extern "C" int llama_model_quantize(const char * fname_inp, const char * fname_o
             if (!params->pure) nt = mixture_type(st, nt, t.name, t.ne[0], ftype);
             q = nt != t.type;
         }
-        if (q && t.type != T_F32 && t.type != T_F16) {
-            fprintf(stderr, "llama_model_quantize: %s is already quantised (type %d): requantising is %s\n", t.name.c_str(), t.type, params->allow_requantize ? "not implemented here" : "disabled");
+        if (q && t.type != T_F32 && t.type != T_F16 && !params->allow_requantize) {                         // llama.cpp:8159-8161
+            fprintf(stderr, "llama_model_quantize: requantizing %s from type %d is disabled\n", t.name.c_str(), t.type);
             return 1;
         }
         if (q && t.ne[0] % block_elems(nt) != 0) { fprintf(stderr, "llama_model_quantize: %s: %lld columns are not a multiple of %d\n", t.name.c_str(), (long long) t.ne[0], block_elems(nt)); return 1; }
@@ -591,10 +707,9 @@ extern "C" int llama_model_quantize(const char * fname_inp, const char * fname_o
             const size_t row_out = pi::type_row_size(plans[i].type, k);
             work.resize(plans[i].bytes);
             const float * src = (const float *) t.data;
-            if (t.type == T_F16) {
+            if (t.type != T_F32) {                                                                            // llama_convert_tensor_internal (llama.cpp:7838-7893): f16 or, with allow_requantize, any block format
                 f32.resize((size_t) rows * k);
-                const uint8_t * hsrc = t.data;
-                for (size_t e = 0; e < f32.size(); e++) { uint16_t hv; memcpy(&hv, hsrc + 2 * e, 2); f32[e] = half_to_float(hv); }
+                if (!dequantize_elems(t.type, t.data, f32.data(), rows * k)) { fprintf(stderr, "llama_model_quantize: cannot read %s (type %d)\n", t.name.c_str(), t.type); fclose(f); return 1; }
                 src = f32.data();
             }
             std::atomic<int64_t> next(0);

@@ -282,7 +282,7 @@ extern "C" llama_token llama_sample_token_mirostat_v2(struct llama_context * ctx
 std::string dump_kv_cache_view_seqs(const llama_kv_cache_view & view, int row_size) {
     static const char slot_chars[] = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz+";
     std::string out;
-    char buf[128];
+    char buf[256];
     snprintf(buf, sizeof buf, "=== Dumping KV cache. total cells %d, max sequences per cell %d, populated cells %d, total tokens in cache %d, largest empty slot=%d @ %d\n",
              view.n_cells, view.n_max_seq, view.used_cells, view.token_count, view.max_contiguous, view.max_contiguous_idx);
     out += buf;

@@ -64,6 +64,37 @@ def test_rows_equal_the_reference_functions(lib, t, name):
         assert np.array_equal(quantize(lib, t, x), want), (name, trial)
 
 
+@pytest.mark.parametrize("t,name", TYPES)
+def test_dequantize_equals_the_reference(lib, t, name):
+    """pipeinfer_dequantize_row (what --allow-requantize reads with) against dequantize_row_* of the reference: the golden blocks, and blocks of random bytes"""
+    lib.pipeinfer_dequantize_row.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.pipeinfer_dequantize_row.restype = C.c_int64
+    g = np.load(os.path.join(GOLD, "quantize.npz"))
+    k = g["x"].shape[1]
+    for i in range(g["x"].shape[0]):
+        blocks = np.ascontiguousarray(g[name][i])
+        y = np.zeros(k, np.float32)
+        assert lib.pipeinfer_dequantize_row(t, blocks.ctypes.data, y.ctypes.data, k) == k
+        x = g["x"][i]
+        tol = np.abs(x).max() * {"q2_K": 1.1, "q3_K": 0.6, "q8_0": 0.01}.get(name, 0.3) + 1e-6      # (a sanity bound: it IS the inverse of the quantiser; tiny rows sit in the f16 subnormals of d)
+        assert np.abs(y - x).max() <= tol, (name, i)
+    if not O.have_ref() or O.ref() is None:
+        return
+    r = O.ref()
+    rng = np.random.default_rng(300 + t)
+    k = 256 * 16
+    n = O.row_size(t, k)
+    for trial in range(8):
+        blocks = rng.integers(0, 256, n, dtype=np.uint8)
+        h = blocks.view(np.uint16) if n % 2 == 0 else None
+        if h is not None:                                         # keep every f16 finite (random bytes make NaN / inf scales, whose payload bits are not the point)
+            h[(h & 0x7c00) == 0x7c00] &= 0xbfff
+        want, got = np.zeros(k, np.float32), np.zeros(k, np.float32)
+        r.ref_dequantize(t, O._ptr(blocks), O._ptr(want), k)
+        assert lib.pipeinfer_dequantize_row(t, blocks.ctypes.data, got.ctypes.data, k) == k
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (name, trial)
+
+
 def test_bad_arguments(lib):
     x = np.zeros(300, np.float32)
     out = np.zeros(4096, np.uint8)
@@ -125,6 +156,18 @@ def test_model_quantize_refuses_what_it_cannot_do(lib, tmp_path):
     assert lib.llama_model_quantize(src.encode(), dst.encode(), C.byref(p)) == 1
     p.ftype = FTYPES["q4_0"]
     assert lib.llama_model_quantize(str(tmp_path / "missing.gguf").encode(), dst.encode(), C.byref(p)) == 1
+    p.ftype, p.allow_requantize = FTYPES["q4_k_m"], True                                          # --allow-requantize: dequantise, then quantise (llama.cpp:7838-7893, 8162-8165)
+    assert lib.llama_model_quantize(src.encode(), dst.encode(), C.byref(p)) == 0
+    lib.pipeinfer_dequantize_row.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    _, t0 = G.read_gguf(src)
+    _, t1 = G.read_gguf(dst)
+    ne, tt, data = t1["blk.0.ffn_up.weight"]
+    assert tt == 12 and t0["blk.0.ffn_up.weight"][1] == 2
+    src_blocks = np.ascontiguousarray(t0["blk.0.ffn_up.weight"][2])
+    f32 = np.zeros(ne[0] * ne[1], np.float32)
+    assert lib.pipeinfer_dequantize_row(2, src_blocks.ctypes.data, f32.ctypes.data, f32.size) == f32.size
+    assert np.array_equal(np.asarray(data), quantize(lib, 12, f32))
+    p.ftype, p.allow_requantize = FTYPES["q4_0"], False
     p.only_copy = True                                                                            # a copy keeps every tensor and the input's file type
     assert lib.llama_model_quantize(src.encode(), dst.encode(), C.byref(p)) == 0
     kv0, t0 = G.read_gguf(src)
