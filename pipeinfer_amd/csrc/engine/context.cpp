@@ -16,6 +16,7 @@
 #define OP_OK(expr)  do { if ((expr) != 0) { ctx->last_error = std::string(#expr) + ": " + pi_last_error(); return false; } } while (0)
 
 llama_context::~llama_context() {
+    pi::urgent_drop_all(this);
     if (feeder.joinable()) {
         { std::lock_guard<std::mutex> lk(fmu); fstop = true; }
         fcv.notify_all();
@@ -335,14 +336,21 @@ static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta,
 // is not back: without the credit the target would make no progress at all while the draft is busy; with it the two alternate, one target
 // segment per draft step, whatever the timing of the calls.
 static std::atomic<int> g_urgent{0}, g_credit{0};
-static void urgent_begin(llama_context * ctx) { if (ctx->stream_priority > 0) g_urgent.fetch_add(1); }
-static void urgent_end(llama_context * ctx) { if (ctx->stream_priority > 0) { g_credit.store(1); g_urgent.fetch_sub(1); } }
+// (every context counts its own pending urgent runs: a priority context that is freed, or changes its priority, with runs it never finished must not
+// leave g_urgent raised — every segmented feeder in the process would wait for a credit that no one is left to give)
+static void urgent_begin(llama_context * ctx) { if (ctx->stream_priority > 0) { ctx->urgent_pending++; g_urgent.fetch_add(1); } }
+static void urgent_end(llama_context * ctx) { if (ctx->urgent_pending > 0) { ctx->urgent_pending--; g_credit.store(1); g_urgent.fetch_sub(1); } }
+void urgent_drop_all(llama_context * ctx) { while (ctx->urgent_pending > 0) urgent_end(ctx); }
 static void yield_to_urgent(const llama_context * ctx) {
     if (ctx->stream_priority > 0) return;
+    // bounded: the claim is released when the CALLER finishes the urgent run, and a caller that blocks on THIS context's run first would wait for ever.
+    // 50 ms is several times the longest legitimate wait (a draft step queued behind one 70B target segment, ~7 ms).
+    const int64_t t0 = time_us();
     for (int spin = 0; g_urgent.load() > 0; spin++) {
         int c = g_credit.load();
         if (c > 0 && g_credit.compare_exchange_strong(c, c - 1)) return;
-        if (spin < 4000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (spin < 4000) std::this_thread::yield();
+        else { if (time_us() - t0 > 50000) return; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
     }
 }
 

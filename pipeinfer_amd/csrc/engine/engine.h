@@ -116,6 +116,7 @@ struct llama_context {
     // queued it waits for two segments.
     int seg_layers = 0;                      // 0: the whole stage is one graph, launched by the caller (no feeder)
     std::thread feeder; std::mutex fmu; std::condition_variable fcv; std::deque<pi_run *> fqueue; bool fstop = false;
+    int urgent_pending = 0;                 // runs of this (priority) context counted in the device arbiter and not finished yet (caller's thread only)
     uint64_t stat_segments = 0, stat_segments_skipped = 0;
     hipEvent_t seg_events[2] = { nullptr, nullptr };
     bool prepared = false, prepare_failed = false;      // device state fully allocated / an attempt failed half-way (never retried)
@@ -146,6 +147,7 @@ bool context_prepare(llama_context * ctx, std::string & err);          // upload
 pi_run * context_start(llama_context * ctx, const llama_batch & batch, int & rc);   // rc: 0 ok, 1 no slot, <0 error
 int  context_finish(llama_context * ctx, pi_run * run);
 bool context_poll_oldest(llama_context * ctx);
+void urgent_drop_all(llama_context * ctx);                                  // the context gives up its claim on the device arbiter (destructor, priority change)
 bool context_wait(llama_context * ctx, pi_run * run);                    // blocks until the run's results are in host memory
 int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,

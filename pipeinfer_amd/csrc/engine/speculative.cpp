@@ -404,8 +404,9 @@ struct driver {
 
         while (true) {
             if (failed) {                                                 // drain and report (the output so far is valid, the generation is not complete)
-                while (!tgt_runs.empty()) { auto r = tgt_runs.back(); llama_finish_async_decode(tgt, r->batch.view(), r->ticket); tgt_runs.pop_back(); }
+                // (the draft first: on one GPU its pending runs hold the device arbiter, and the target's feeder launches its remaining segments only on their credit)
                 while (!dft_runs.empty()) { auto r = dft_runs.back(); llama_finish_async_decode(dft, r->batch.view(), r->ticket); dft_runs.pop_back(); }
+                while (!tgt_runs.empty()) { auto r = tgt_runs.back(); llama_finish_async_decode(tgt, r->batch.view(), r->ticket); tgt_runs.pop_back(); }
                 return -3;
             }
             int i_dft = 0, s_keep = 0;
@@ -516,9 +517,10 @@ struct driver {
         }
         const int64_t t_dec_end = pi::time_us();
 
-        // drain what is still in flight (speculative.cpp:735-747)
-        while (!tgt_runs.empty()) { auto r = tgt_runs.back(); llama_finish_async_decode(tgt, r->batch.view(), r->ticket); tgt_runs.pop_back(); }
+        // drain what is still in flight (speculative.cpp:735-747) — the draft first: a pending draft run holds the single-GPU arbiter (context.cpp), and waiting for a
+        // target run whose feeder is waiting for that draft run's credit would never end
         while (!dft_runs.empty()) { auto r = dft_runs.back(); llama_finish_async_decode(dft, r->batch.view(), r->ticket); dft_runs.pop_back(); }
+        while (!tgt_runs.empty()) { auto r = tgt_runs.back(); llama_finish_async_decode(tgt, r->batch.view(), r->ticket); tgt_runs.pop_back(); }
 
         R.t_enc_s = (t_enc_end - t_enc_start) / 1e6; R.t_dec_s = (t_dec_end - t_dec_start) / 1e6;
         R.encode_tps = n_input / R.t_enc_s; R.decode_tps = R.n_predict / R.t_dec_s;

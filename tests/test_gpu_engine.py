@@ -503,6 +503,26 @@ def test_driver_lossless_with_a_segmented_target_and_a_priority_draft(LL, tgt, d
     mt.free(); md.free()
 
 
+@pytest.mark.timeout(120)
+def test_a_priority_context_freed_with_unfinished_runs_releases_the_device_arbiter(LL):
+    """the single-GPU arbiter lets a segmented (target) feeder launch its next segment only when no priority (draft) context has a run pending, or on a credit
+    given when such a run finishes.  A priority context that is freed with runs it never finished must give its claim back: otherwise every segmented context of
+    the process waits forever (seen as a rare stall of later tests)."""
+    m = LL.Model(os.path.join(GOLD, "tiny_llama_b_q4_k_m.gguf"))
+    d = LL.Context(m, n_ctx=256, n_batch=64)
+    d.set_priority(1)
+    d.start([5, 9, 13], [0, 1, 2], [[0]] * 3)                    # started, never finished
+    d.start([7], [3], [[0]])
+    d.free()
+    t, ref = LL.Context(m, n_ctx=256, n_batch=64), LL.Context(m, n_ctx=256, n_batch=64)
+    t.set_segments(1)                                            # its feeder thread asks the arbiter before every segment
+    prompt = [5, 9, 13, 200, 77, 31, 8, 19]
+    a = t.decode(prompt, list(range(8)), [[0]] * 8)
+    b = ref.decode(prompt, list(range(8)), [[0]] * 8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    t.free(); ref.free(); m.free()
+
+
 def test_cancel_of_a_run_in_flight_stops_it_at_a_segment_boundary(LL):
     """llama_cancel_run after llama_start_async_decode (llama.cpp:9981-9993 + the abort callback :5665-5687): the run completes "empty", the
     context stays usable and later runs compute the same bits as on a fresh context"""
