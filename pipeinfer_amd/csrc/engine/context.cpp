@@ -293,18 +293,28 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
         llama_context::graph_entry & ge = ctx->graphs[std::make_pair(n_tokens, seg)];
         bool ok = true;
         if (!ge.exec) {
-            hipGraph_t graph = nullptr;
+            // One capture at a time in the process, and a few attempts: on this runtime a capture (thread-local mode) is now and then invalidated by what ANOTHER
+            // thread does meanwhile — the caller's thread starting the draft's first runs (pinned allocations, its own first captures) while this context's feeder
+            // captures — and every launch then fails with "previous error during capture".  Nothing has run at that point: end the capture and record it again.
+            static std::mutex capture_mu;
+            std::lock_guard<std::mutex> lk(capture_mu);
             ge.sink.every = 16;
-            ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                pi_kt_set_sink(&ge.sink);                          // launch counts are part of the graph; they are only read while timing is on
-                const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
-                pi_kt_set_sink(nullptr);
-                ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
+            for (int attempt = 0; attempt < 8 && !ge.exec; attempt++) {
+                hipGraph_t graph = nullptr;
+                if (attempt) { (void) hipGetLastError(); std::this_thread::sleep_for(std::chrono::microseconds(300 * attempt)); }
+                ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    pi_kt_set_sink(&ge.sink);                      // launch counts are part of the graph; they are only read while timing is on
+                    if (attempt) { ge.sink.samples.clear(); ge.sink.launches.clear(); }
+                    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+                    pi_kt_set_sink(nullptr);
+                    ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
+                }
+                if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void) hipGraphDestroy(graph);
+                if (!ok) ge.exec = nullptr;
             }
-            if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
-            if (graph) (void) hipGraphDestroy(graph);
-            if (!ok) { ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error; ge.exec = nullptr; }
+            if (!ok) ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error;
         }
         if (ok) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
         if (ok && sink_out && seg == 0) *sink_out = &ge.sink;

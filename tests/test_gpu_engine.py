@@ -497,7 +497,7 @@ def test_driver_lossless_with_a_segmented_target_and_a_priority_draft(LL, tgt, d
     for trial in range(4):
         ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
         ct.set_segments(1); cd.set_priority(1)
-        out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=3, n_parallel=3, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec)
+        out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=3, n_parallel=3, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec, verbose=int(os.environ.get("PIPEINFER_VERBOSE", "0")))
         assert out[:24] == want, (trial, out, want, res)
         ct.free(); cd.free()
     mt.free(); md.free()
