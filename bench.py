@@ -198,6 +198,35 @@ def kernel_timing_table(lib):
     return rows
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) as CHILD processes through torch.distributed.run,
+    wait for them, print rank 0's single JSON line and return non-zero if any rank failed.  Nothing here initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: the peer rings between the stage processes need it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:                                       # rank 0's JSON line is the only thing that belongs on stdout
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+    if rc != 0 or line is None:
+        print(f"[bench] {n}-rank job failed: exit code {rc}" + ("" if line is not None else ", no result line"), file=sys.stderr)
+        sys.exit(rc if rc != 0 else 1)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +255,10 @@ def main():
     ap.add_argument("--adaptive-pause", type=int, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as ONE command (the reference starts every rank from one mpirun: ggml-mpi.c:58-61 MPI_Init_thread, speculative.cpp:116-139 comm split):
+        # this process only spawns the ranks and forwards rank 0's line — it never touches the GPU itself
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:
@@ -325,6 +358,13 @@ def main():
     roofline["target_all_calls"] = {"calls": st_t["n_calls"], "gpu_ms_per_call": round(st_t["gpu_ms"] / max(1, st_t["n_calls"]), 4),
                                     "GBps": round(st_t["alg_bytes"] / max(1e-9, st_t["gpu_ms"] * 1e-3) / 1e9, 1)}
     roofline["target_segments"] = {"layers_per_segment": seg_layers, "launched": st_t["n_segments"], "skipped_by_cancel": st_t["n_segments_skipped"]}
+    # early cancellation: runs that llama_cancel_run reached AFTER their start return from every kernel on entry from then on (abort word) and the feeder drops their
+    # unlaunched segments; `skipped_frac` = 1 - (GPU time those runs still took) / (what the same number of complete calls takes)
+    avg_call_ms = st_t["gpu_ms"] / max(1, st_t["n_calls"] - st_t["n_cancel_runs"])
+    roofline["target_cancelled_runs"] = {"finished_as_cancelled": st_t["n_cancel_runs"], "cancelled_after_start": st_t["n_cancel_runs_started"],
+                                         "gpu_ms_still_spent": round(st_t["cancel_gpu_ms"], 2), "gpu_ms_of_as_many_complete_calls": round(st_t["n_cancel_runs_started"] * avg_call_ms, 2),
+                                         "skipped_frac": round(1.0 - st_t["cancel_gpu_ms"] / max(1e-9, st_t["n_cancel_runs_started"] * avg_call_ms), 4) if st_t["n_cancel_runs_started"] else None,
+                                         "kernel_abort_word": os.environ.get("PI_NO_ABORT_WORD") is None}
     roofline["draft_decode_call"] = {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
                                      "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}
 

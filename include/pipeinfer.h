@@ -126,6 +126,9 @@ struct pipeinfer_stats {
     double   gpu_ms_1;
     uint64_t alg_bytes_1;
     uint64_t n_segments, n_segments_skipped;   /* segmented launch: segments launched / dropped by a mid-run cancel */
+    uint64_t n_cancel_runs;      /* runs finished as cancelled (before or after their start) */
+    uint64_t n_cancel_runs_started; /* ... of which llama_cancel_run arrived after llama_start_async_decode: their kernels return on entry from then on (abort word) */
+    double   cancel_gpu_ms;      /* GPU time (first to last event) those started-then-cancelled runs still took */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
 LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);

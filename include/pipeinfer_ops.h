@@ -45,6 +45,15 @@ PI_API int     pi_memset(void * dst_dev, int value, size_t bytes, void * stream)
 PI_API int     pi_stream_sync(void * stream);
 PI_API int     pi_device_sync(void);
 
+/* Kernel-granular early cancellation (reference: the abort callback polled between graph nodes, ggml.c:15748-15811, llama.cpp:5614-5628, 5665-5687).
+ * word_dev: one int32 per context in device memory holding (run id << 1 | aborted).  Every hot-path kernel launched — or captured into a
+ * graph — by the calling thread after pi_set_abort_word(word_dev) reads it on entry and returns at once when bit 0 is set (NULL: no check).
+ *   pi_op_abort_begin   (in stream order, ahead of a run's kernels)  word = run_id << 1 | (*host_flag != 0); host_flag: pinned host memory, nullable
+ *   pi_op_abort_cancel  (any stream, any time)                        if word == run_id << 1 then word |= 1: only the run that is executing NOW is hit */
+PI_API void    pi_set_abort_word(const int32_t * word_dev);
+PI_API int     pi_op_abort_begin(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, void * stream);
+PI_API int     pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * stream);
+
 /* sampled per-launch timing of the quantised mat-vec kernels (HIP events on the launch stream around every Nth launch) */
 PI_API void    pi_kernel_timing(int on, int sample_every);
 PI_API int     pi_kernel_timing_report(int weight_type, int n_tok, double * avg_us, double * avg_bytes, uint64_t * n_sampled, uint64_t * n_launches);

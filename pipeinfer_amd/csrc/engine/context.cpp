@@ -33,6 +33,9 @@ llama_context::~llama_context() {
     }
     for (auto & kv : graphs) if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
     for (hipEvent_t e : seg_events) if (e) (void) hipEventDestroy(e);
+    if (ctl_stream) { (void) hipStreamSynchronize(ctl_stream); (void) hipStreamDestroy(ctl_stream); }
+    if (abort_host) (void) hipHostFree(abort_host);
+    pi_free(abort_dev);
     void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, q8c, tokens_dev, pos_dev, dyn_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev, topk_scratch_dev };
     for (void * b : bufs) pi_free(b);
     if (rope) pi_rope_table_free(rope);
@@ -101,6 +104,15 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
         !(ctx->up = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->gate = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->q16 = (uint16_t *) dev((size_t) 2 * nb * n_embd)) ||
         !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev(64)))
         return false;
+    {   // abort word + cancel flags + the control stream cancels travel on (highest priority: a cancel must not queue behind the run it stops)
+        int lo = 0, hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (!(ctx->abort_dev = (int32_t *) dev(256))) return false;
+        pi_memset(ctx->abort_dev, 0, 256, nullptr);
+        if (hipHostMalloc((void **) &ctx->abort_host, 256 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc(abort flags) failed"; return false; }
+        memset(ctx->abort_host, 0, 256 * sizeof(int32_t));
+        if (hipStreamCreateWithPriority(&ctx->ctl_stream, hipStreamNonBlocking, hi) != hipSuccess) { err = "hipStreamCreate(control) failed"; return false; }
+    }
     ctx->use_graphs = getenv("PI_NO_GRAPHS") == nullptr;
     if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0 || pi_op_mul_mat_reserve() != 0) { err = pi_last_error(); return false; }
     ctx->mask_cap_words = (size_t) nb * ((ctx->n_ctx + 31) / 32);
@@ -140,7 +152,7 @@ static pi_run * acquire_run(llama_context * ctx, int n_tokens, size_t meta_bytes
         r->meta_cap = std::max(meta_bytes, (size_t) 4096);
         if (!host_alloc((void **) &r->meta_host, r->meta_cap)) return nullptr;
     }
-    r->canceled = r->launched = r->finished = false;
+    r->canceled = r->launched = r->finished = r->failed = false;
     return r;
 }
 
@@ -280,6 +292,14 @@ static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, 
     if (!ok) ctx->last_error = "H2D of batch metadata failed";
     return ok;
 }
+// PI_NO_ABORT_WORD=1 (A/B measurements, tests): kernels are launched without an abort word, cancels then act between segments only
+static bool abort_checks_on() { static const bool on = getenv("PI_NO_ABORT_WORD") == nullptr; return on; }
+// ahead of a run's kernels, in stream order: the abort word takes the run's identity (and a cancel that has arrived already)
+static bool launch_abort_begin(llama_context * ctx, const pi_run * run) {
+    if (!ctx->abort_dev) return true;
+    if (pi_op_abort_begin(ctx->abort_dev, run->run_id, ctx->abort_host + (run->run_id & 255), ctx->stream) != 0) { ctx->last_error = std::string("pi_op_abort_begin: ") + pi_last_error(); return false; }
+    return true;
+}
 // segment `seg` of the forward pass: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device memory that
 // launch_inputs refreshed, so replaying the captured graph IS this call's segment
 static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out) {
@@ -306,7 +326,9 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
                 if (ok) {
                     pi_kt_set_sink(&ge.sink);                      // launch counts are part of the graph; they are only read while timing is on
                     if (attempt) { ge.sink.samples.clear(); ge.sink.launches.clear(); }
+                    pi_set_abort_word(abort_checks_on() ? ctx->abort_dev : nullptr);      // the captured kernels carry the context's abort word
                     const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+                    pi_set_abort_word(nullptr);
                     pi_kt_set_sink(nullptr);
                     ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
                 }
@@ -320,7 +342,10 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
         if (ok && sink_out && seg == 0) *sink_out = &ge.sink;
         return ok;
     }
-    return forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+    pi_set_abort_word(abort_checks_on() ? ctx->abort_dev : nullptr);
+    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+    pi_set_abort_word(nullptr);
+    return fwd;
 }
 static bool launch_outputs(llama_context * ctx, pi_run * run) {
     if (!ctx->is_last) return true;
@@ -377,7 +402,8 @@ static void feed_run(llama_context * ctx, pi_run * run) {
             if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
             yield_to_urgent(ctx);
             if (run->cancel_req.load()) break;                                  // llama_cancel_run arrived while the run was in flight
-            ok = launch_segment(ctx, run->n_tokens, kv_head, seg, &run->sink);
+            ok = launch_abort_begin(ctx, run);
+            if (ok) ok = launch_segment(ctx, run->n_tokens, kv_head, seg, &run->sink);
             if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
         }
         run->segments_run = seg;
@@ -387,7 +413,11 @@ static void feed_run(llama_context * ctx, pi_run * run) {
     }
     run->launched = ok && full;
     if (hipEventRecord(run->done, ctx->stream) != hipSuccess) ok = false;
-    if (!ok) fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.c_str());
+    if (!ok) {                                                                 // NOT the same thing as a cancelled run: finish reports it (the driver ends the generation)
+        run->failed = true;
+        std::lock_guard<std::mutex> lk(ctx->fmu);
+        fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.c_str());
+    }
     run->state.store(2);
 }
 static void feeder_main(llama_context * ctx) {
@@ -434,6 +464,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     auto give_back = [&]() { ctx->cells->release_cells(kv_head, n_tokens); };
     if (!run) { ctx->last_error = "out of pinned host memory"; give_back(); return nullptr; }
     run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us(); run->sink = nullptr;
+    run->run_id = (++ctx->run_counter) & 0x3fffffff; run->kv_head = kv_head;
     // (a segmented context's stream belongs to its feeder thread: the begin event is recorded there, in stream order with the run's segments)
     if (!ctx->remote && ctx->seg_layers == 0 && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; give_back(); ctx->pool.push_back(run); return nullptr; }
     // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
@@ -449,6 +480,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     ctx->cells->post_decode(n_tokens);
 
     run->canceled = ctx->canceled_batches.count(run->batch_id) > 0;
+    if (ctx->abort_host) ctx->abort_host[run->run_id & 255] = run->canceled ? 1 : 0;
     bool ok = true;
     if (ctx->remote) {                                                        // the layers live in other processes: ship the metadata block
         if (!run->canceled) {
@@ -468,7 +500,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     if (ctx->seg_layers > 0) {                                                // segmented: the feeder thread launches (and may cut short) the run
         if (!ctx->feeder.joinable()) {
             if (hipEventCreateWithFlags(&ctx->seg_events[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->seg_events[1], hipEventDisableTiming) != hipSuccess) {
-                ctx->last_error = "hipEventCreate failed"; urgent_end(ctx); ctx->pool.push_back(run); return nullptr;
+                ctx->last_error = "hipEventCreate failed"; urgent_end(ctx); give_back(); ctx->pool.push_back(run); return nullptr;
             }
             ctx->feeder = std::thread(feeder_main, ctx);
         }
@@ -484,7 +516,8 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         return run;
     }
     if (!run->canceled) {                                                     // a cancelled run still occupies its cells and completes "empty" (llama.cpp:5627-5716)
-        ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
+        ok = launch_abort_begin(ctx, run);
+        if (ok) ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
         if (ok) ok = launch_outputs(ctx, run);
         run->launched = ok;
         ctx->stat_calls++;
@@ -587,6 +620,24 @@ int context_finish(llama_context * ctx, pi_run * run) {
         while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
         if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; urgent_end(ctx); return -1; }
         urgent_end(ctx);
+        if (run->failed) {
+            // a launch of this run failed (graph capture, a kernel launch, a copy): that is an error, not a cancelled run — the caller gets -1, the cells
+            // find_slot allotted go back (nothing valid was written to them) and the run leaves the queue
+            { std::lock_guard<std::mutex> lk(ctx->fmu); if (ctx->last_error.empty()) ctx->last_error = "a launch of the run failed"; }
+            ctx->cells->release_cells(run->kv_head, run->n_tokens);
+            ctx->last_n_tokens = 0;
+            for (auto it = ctx->inflight.begin(); it != ctx->inflight.end(); ++it) if (*it == run) { ctx->inflight.erase(it); break; }
+            run->finished = true;
+            ctx->pool.push_back(run);
+            return -1;
+        }
+        const bool cut = run->cancel_req.load();                               // cancelled after the start: its kernels returned on entry from some point on — nothing it wrote is a result
+        if (run->canceled || cut) {
+            float ms = 0.0f;
+            ctx->stat_cancel_runs++;
+            if (!run->canceled) { ctx->stat_cancel_runs_started++; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_cancel_gpu_ms += ms; }
+        }
+        if (cut) run->launched = false;
     }
     const size_t nv = ctx->model->hparams.n_vocab;
     const int n = run->n_tokens;

@@ -80,6 +80,9 @@ struct pi_run {                                // one llama_start_async_decode .
     std::atomic<int>  state{0};             // 0 queued, 1 being launched, 2 completion event recorded (the run's fields are final)
     std::atomic<bool> cancel_req{false};    // llama_cancel_run after the start: the feeder stops launching its segments
     int segments_run = 0;                   // segments that were launched before a cancel took effect (statistics)
+    int32_t run_id = 0;                     // per-context counter: the identity the device-side abort word carries (pi_op_abort_begin / _cancel)
+    bool failed = false;                    // a launch of this run failed (distinct from cancelled / cut short): finish reports -1 and gives the cells back
+    int kv_head = 0;                        // first cell find_slot allotted (released again when the run failed)
 };
 
 struct llama_context {
@@ -119,6 +122,12 @@ struct llama_context {
     int urgent_pending = 0;                 // runs of this (priority) context counted in the device arbiter and not finished yet (caller's thread only)
     uint64_t stat_segments = 0, stat_segments_skipped = 0;
     hipEvent_t seg_events[2] = { nullptr, nullptr };
+    // Kernel-granular early cancellation (reference: abort callback between graph nodes, ggml.c:15748-15811; llama.cpp:5614-5628, 5665-5687, 9981-9993):
+    // every kernel of this context reads abort_dev = (id of the run whose kernels are executing << 1 | aborted) on entry.  A run's launches are preceded, in
+    // stream order, by pi_op_abort_begin (which also picks up a cancel that arrived before: abort_host[id & 255], pinned); llama_cancel_run of a run already
+    // handed to the GPU sets that flag and enqueues pi_op_abort_cancel on ctl_stream — a compare-and-swap that only hits while that very run is executing.
+    int32_t * abort_dev = nullptr; int32_t * abort_host = nullptr; hipStream_t ctl_stream = nullptr; int32_t run_counter = 0;
+    uint64_t stat_cancel_runs = 0, stat_cancel_runs_started = 0; double stat_cancel_gpu_ms = 0.0;     // cancelled runs: all / handed to the GPU before the cancel / GPU time they still took
     bool prepared = false, prepare_failed = false;      // device state fully allocated / an attempt failed half-way (never retried)
     int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr; void * topk_scratch_dev = nullptr;
     size_t mask_cap_words = 0;

@@ -100,6 +100,11 @@ struct driver {
         cand c[8]; int n;
         top_candidates(ctx, idx, c, n);
         ctx->n_sample++;
+        if (n == 0) {                                                     // no results behind this row (a run that failed or was cut short must never be sampled): an error, not a token
+            fprintf(stderr, "pipeinfer_speculative: no logits for row %d of the last %s run: %s\n", idx, ctx == tgt ? "target" : "draft", pipeinfer_context_error(ctx));
+            failed = true;
+            return 0;
+        }
         return c[0].id;
     }
 
@@ -359,13 +364,15 @@ struct driver {
         if (n_input < 2 || n_input > llama_n_ctx(tgt) - 4) return -1;
         // the KV cache must hold the prompt, the generation and the cells of the speculative runs that can be in flight at once
         // (the reference aborts in find_slot when it cannot; say so before anything is launched)
-        {
-            const int inflight = P.mode == 2 ? 0 : (P.max_inflight > 0 ? P.max_inflight : 4);
-            const int need = n_input + P.n_predict + 2 + (P.mode == 2 ? 0 : (P.n_draft + 1) * n_seq_dft * inflight);
-            if (need > llama_n_ctx(tgt)) {
-                fprintf(stderr, "pipeinfer_speculative: n_ctx %d cannot hold %d prompt + %d generated tokens + %d speculative cells\n", llama_n_ctx(tgt), n_input, P.n_predict, need - n_input - P.n_predict - 2);
-                return -1;
-            }
+        // Hard bound only (like run_sync): the reference fails when find_slot cannot place a batch (llama.cpp:5562-5565), not up front; a run that cannot be
+        // placed ends the generation through the failed / drain path.  The cells speculative runs in flight may occupy are a warning.
+        if (n_input + P.n_predict + 2 > llama_n_ctx(tgt)) {
+            fprintf(stderr, "pipeinfer_speculative: n_ctx %d cannot hold %d prompt + %d generated tokens\n", llama_n_ctx(tgt), n_input, P.n_predict);
+            return -1;
+        }
+        if (P.mode != 2 && P.verbose) {
+            const int need = n_input + P.n_predict + 2 + (P.n_draft + 1) * n_seq_dft * (P.max_inflight > 0 ? P.max_inflight : 4);
+            if (need > llama_n_ctx(tgt)) fprintf(stderr, "pipeinfer_speculative: warning: n_ctx %d may run short of cells with several speculative runs in flight (%d wanted)\n", llama_n_ctx(tgt), need);
         }
         R.n_input = n_input;
 
@@ -428,8 +435,9 @@ struct driver {
                     if (run->speculative) free_offsets.push_back(run->seq_offset);
                     continue;
                 }
-                llama_finish_async_decode(tgt, run->batch.view(), run->ticket);
+                const int frc = llama_finish_async_decode(tgt, run->batch.view(), run->ticket);
                 tgt_runs.pop_back();
+                if (frc < 0) { fprintf(stderr, "pipeinfer_speculative: target run %d failed: %s\n", run->batch.batch_id, pipeinfer_context_error(tgt)); failed = true; continue; }
                 spec_past_tgt = n_past_tgt; spec_past_dft = n_past_dft;
                 first_run = true;
             } else if (!tgt_runs.empty()) {
@@ -443,6 +451,7 @@ struct driver {
             keeps.push_back(s_keep);
             while (!keeps.empty()) {
                 id = sample_greedy(tgt, drafts[keeps[0]].i_batch_tgt[i_dft]);
+                if (failed) break;
                 if (current.n_past_tgt + i_dft == n_past_tgt - 1) {
                     any_match = true;
                     ++R.n_predict;
@@ -472,6 +481,7 @@ struct driver {
                 }
             }
 
+            if (failed) continue;
             if (!any_match) {
                 if (current.speculative) free_offsets.push_back(current.seq_offset);
                 continue;
@@ -499,7 +509,7 @@ struct driver {
                 begin_non_spec_run(dft, dft_runs, n_past_dft);
                 std::shared_ptr<async_run> d = dft_runs.back();
                 dft_runs.pop_back();
-                llama_finish_async_decode(dft, d->batch.view(), d->ticket);
+                if (llama_finish_async_decode(dft, d->batch.view(), d->ticket) < 0) { failed = true; continue; }
             } else {
                 if (P.mode != 2) { lag_tokens.emplace_back(id, n_past_dft); R.n_draft_paused++; }      // the draft sits this token out (caught up later in one batch)
                 n_past_dft++;
@@ -541,6 +551,10 @@ struct driver {
         eos = llama_token_eos(llama_get_model(tgt));
         const int n_input = n_prompt;
         if (n_input < 2 || n_input > llama_n_ctx(tgt) - 4) return -1;
+        if (n_input + P.n_predict + 2 > llama_n_ctx(tgt)) {
+            fprintf(stderr, "pipeinfer_speculative: n_ctx %d cannot hold %d prompt + %d generated tokens\n", llama_n_ctx(tgt), n_input, P.n_predict);
+            return -1;
+        }
         R.n_input = n_input;
         std::vector<llama_seq_id> seq_ids(n_seq_dft + 1);
         for (int i = 0; i <= n_seq_dft; i++) seq_ids[i] = i;
@@ -571,6 +585,7 @@ struct driver {
             int i_dft = 0, s_keep = 0;
             while (true) {
                 id = sample_greedy(tgt, drafts[s_keep].i_batch_tgt[i_dft]);
+                if (failed) return -3;
                 if (has_run_first_token) {
                     if (first_token) { ttft = pi::time_us() - ttft; first_token = false; }
                     else itl.push_back(pi::time_us() - itt_start);

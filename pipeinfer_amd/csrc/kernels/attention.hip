@@ -36,6 +36,7 @@ struct att_args {
     const uint16_t * exp_tab;
     float scale;
     const int32_t * dyn;                                    // optional {kv_head, n_kv} in device memory: lets one captured graph serve every call
+    const int32_t * abort_w;                                // abort word of the run (pi_device.h), nullable
 };
 
 // x[i] + x[i + n] inside a row of 16 lanes (lanes whose partner is outside read 0 and are not used)
@@ -54,6 +55,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     extern __shared__ float smem[];
     __shared__ float redf[RW][4];
     __shared__ unsigned long long redu[RW][4];
+    if (pi_aborted(ga.abort_w)) return;
     att_args g = ga;
     const int s_stride = ga.n_kv;                           // LDS rows keep the static stride
     if (ga.dyn) g.n_kv = ga.dyn[1];
@@ -335,7 +337,7 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     g.n_head = n_head; g.n_head_kv = n_head_kv; g.n_tok = n_tok; g.n_kv = n_kv; g.mask_words = (n_kv + 31) / 32;
     g.exp_tab = pi_get_tables().exp_f16;
     g.scale = 1.0f / sqrtf((float) hd);                      // KQ_scale, llama.cpp:5189-5193
-    g.dyn = dyn_dev;
+    g.dyn = dyn_dev; g.abort_w = pi_abort_word();
     const int rows = n_tok * (n_head / n_head_kv);
     // rows per workgroup: K/V are re-read (from L2) by every chunk of a kv head, so chunks stay as large as the launch can
     // afford while still putting up to one workgroup on each of the 256 CUs

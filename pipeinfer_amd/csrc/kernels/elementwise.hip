@@ -14,7 +14,8 @@ static __device__ __forceinline__ void k4_scale_min(int j, const uint8_t * q, in
     else       { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
 }
 
-__global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, float * __restrict__ out) {
+__global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, float * __restrict__ out, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int t = blockIdx.y;
     const int64_t e = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= w.ne0) return;
@@ -88,7 +89,7 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
 
 extern "C" int pi_op_get_rows(const pi_weight * w, const int32_t * tokens, int n_tok, float * out, void * stream) {
     if (n_tok <= 0) return 0;
-    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) ((w->ne0 + 255) / 256), n_tok), dim3(256), 0, (hipStream_t) stream, *w, tokens, out);
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) ((w->ne0 + 255) / 256), n_tok), dim3(256), 0, (hipStream_t) stream, *w, tokens, out, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -109,7 +110,8 @@ static __device__ __forceinline__ double block_sum_f64(double v, double * sh) {
 }
 
 __global__ void __launch_bounds__(256) k_norm(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b,
-                                              float * __restrict__ y, int n, float eps, int rms) {
+                                              float * __restrict__ y, int n, float eps, int rms, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     __shared__ double sh[8];
     const float * xr = x + (int64_t) blockIdx.x * n;
     float * yr = y + (int64_t) blockIdx.x * n;
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(256) k_norm(const float * __restrict__ x, cons
 
 extern "C" int pi_op_norm(const float * x, const float * w, const float * b, float * y, int n, int n_tok, float eps, int rms, void * stream) {
     if (n_tok <= 0) return 0;
-    hipLaunchKernelGGL(k_norm, dim3(n_tok), dim3(256), 0, (hipStream_t) stream, x, w, b, y, n, eps, rms);
+    hipLaunchKernelGGL(k_norm, dim3(n_tok), dim3(256), 0, (hipStream_t) stream, x, w, b, y, n, eps, rms, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -165,7 +167,8 @@ static __device__ __forceinline__ void wave_emit_frags(const q8k_frags & F, cons
     if (lane == 0) *(float *) (F.aux + cb * 1024 + tl * 4) = d;
 }
 
-__global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F) {
+__global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int t = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
     const int64_t nb = k >> 8;
     const float4 v = *(const float4 *) (x + (int64_t) t * k + (int64_t) blk * 256 + lane * 4);
@@ -205,7 +208,8 @@ static __device__ __forceinline__ void q8_0_store_scale(const int q[4], float d,
 }
 
 // one wave = 8 blocks of 32 = two groups of 4 blocks; values past k belong to the zero padding of the last group
-__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int64_t ng, uint32_t * __restrict__ qs, uint16_t * __restrict__ dd, float * __restrict__ ss) {
+__global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int64_t ng, uint32_t * __restrict__ qs, uint16_t * __restrict__ dd, float * __restrict__ ss, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int t = blockIdx.y, lane = threadIdx.x;
     const int64_t e0 = (int64_t) blockIdx.x * 256 + lane * 4;
     if (e0 >= ng * 128) return;
@@ -267,7 +271,8 @@ static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int
 // norm (rms / layer) * weight (+ bias) straight into the quantised activation planes; optionally also the fp32 result.
 // One workgroup per token; every wave normalises and quantises whole 256-value chunks (a Q8_K block, or eight Q8_0 blocks).
 __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ yf,
-                                                      int n, float eps, int rms, int vdt, int64_t ng, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F) {
+                                                      int n, float eps, int rms, int vdt, int64_t ng, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     __shared__ double sh[16];
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const float * xr = x + (int64_t) t * n;
@@ -383,14 +388,15 @@ extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float
     const int64_t ng = (n / 32 + 3) / 4;
     const int chunks = (int) ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const int threads = 64 * (chunks < 16 ? chunks : 16);
-    hipLaunchKernelGGL(k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base));
+    hipLaunchKernelGGL(k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
 
 // act(gate) [* up] straight into the quantised activation planes: which = 0 silu(gate)*up, 1 gelu(gate).  One wave per 256 values.
 __global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g, const float * __restrict__ u, int which, int64_t n, int vdt, int64_t ng,
-                                                    const uint16_t * __restrict__ tab, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F) {
+                                                    const uint16_t * __restrict__ tab, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c0 = ((int64_t) blockIdx.x * 4 + wave) * 256, e0 = c0 + lane * 4;
     const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
@@ -418,7 +424,7 @@ extern "C" int pi_op_act_quantize(const float * gate, const float * up, int whic
     const int64_t chunks = ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const pi_tables & tb = pi_get_tables();
     hipLaunchKernelGGL(k_act_quant, dim3((unsigned) ((chunks + 3) / 4), n_tok), dim3(256), 0, (hipStream_t) stream, gate, up, which, n, vdt, ng,
-                       which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base));
+                       which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -430,12 +436,12 @@ extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, vo
     uint8_t * base = (uint8_t *) q8;
     if (vdt == PI_Q8_K) {
         if (k % 256) { pi_set_error("pi_op_quantize: Q8_K needs k %% 256 == 0 (k=%lld)", (long long) k); return -1; }
-        hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob), frags_of(vdt, k, n_tok, base));
+        hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob), frags_of(vdt, k, n_tok, base), pi_abort_word());
     } else if (vdt == PI_Q8_0 || vdt == PI_Q8_1) {
         if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 / Q8_1 need k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
         const int64_t ng = (k / 32 + 3) / 4;
         hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((ng * 128 + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, ng, (uint32_t *) (base + oq), (uint16_t *) (base + od),
-                           vdt == PI_Q8_1 ? (float *) (base + ob) : nullptr);
+                           vdt == PI_Q8_1 ? (float *) (base + ob) : nullptr, pi_abort_word());
     } else { pi_set_error("pi_op_quantize: unsupported activation type %d", vdt); return -1; }
     PI_CHECK_LAUNCH();
     return 0;
@@ -471,7 +477,8 @@ extern "C" void pi_rope_table_free(void * t_) { pi_rope_table * t = (pi_rope_tab
 // grid (n_tok, n_head + 2*n_head_kv) — one workgroup of hd/2 threads per head vector
 __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict__ k, const float * __restrict__ v, int64_t qs, int64_t ks, int64_t vs,
                           const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head_,
-                          uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc, const int32_t * __restrict__ dyn) {
+                          uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc, const int32_t * __restrict__ dyn, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int kv_head = dyn ? dyn[0] : kv_head_;
     const int t = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;           // i: pair index
     const int n_embd = n_head * hd, n_gqa = n_head_kv * hd;
@@ -501,7 +508,7 @@ extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float
     const pi_rope_table * t = (const pi_rope_table *) table_;
     if (t->head_dim != hd) { pi_set_error("pi_op_rope_kv_store: table head_dim %d != %d", t->head_dim, hd); return -1; }
     hipLaunchKernelGGL(k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
-                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc, dyn_dev);
+                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc, dyn_dev, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -509,32 +516,35 @@ extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float
 // =================================================================================================================
 // activations through the fp16 tables (ggml.c:1433-1441, 1490-1498), ggml_mul, ggml_add
 // =================================================================================================================
-__global__ void k_silu_mul(const float * __restrict__ g, const float * __restrict__ u, float * __restrict__ o, int64_t n, const uint16_t * __restrict__ tab) {
+__global__ void k_silu_mul(const float * __restrict__ g, const float * __restrict__ u, float * __restrict__ o, int64_t n, const uint16_t * __restrict__ tab, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = pi_h2f(tab[pi_f2h(g[i])]) * u[i];
 }
-__global__ void k_gelu(const float * __restrict__ x, float * __restrict__ o, int64_t n, const uint16_t * __restrict__ tab) {
+__global__ void k_gelu(const float * __restrict__ x, float * __restrict__ o, int64_t n, const uint16_t * __restrict__ tab, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = pi_h2f(tab[pi_f2h(x[i])]);
 }
-__global__ void k_add(const float * __restrict__ a, const float * __restrict__ b, float * __restrict__ o, int64_t n) {
+__global__ void k_add(const float * __restrict__ a, const float * __restrict__ b, float * __restrict__ o, int64_t n, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = a[i] + b[i];
 }
 
 extern "C" int pi_op_silu_mul(const float * g, const float * u, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, g, u, o, n, pi_get_tables().silu_f16);
+    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, g, u, o, n, pi_get_tables().silu_f16, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 extern "C" int pi_op_gelu(const float * x, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_gelu, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, o, n, pi_get_tables().gelu_f16);
+    hipLaunchKernelGGL(k_gelu, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, o, n, pi_get_tables().gelu_f16, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 extern "C" int pi_op_add(const float * a, const float * b, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_add, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a, b, o, n);
+    hipLaunchKernelGGL(k_add, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a, b, o, n, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 
@@ -548,7 +558,8 @@ extern "C" int pi_op_add(const float * a, const float * b, float * o, int64_t n,
 #define TOPK_NCH 32
 // (both stages read their values once into registers; the k selection rounds then run on registers and LDS only)
 #define TOPK_VPT 8                                                     // values per thread held in registers by stage 1 (slices up to 2048)
-__global__ void __launch_bounds__(256) k_topk1(const float * __restrict__ logits, int n_vocab, int k, int32_t * __restrict__ cid, float * __restrict__ cval, float * __restrict__ cmax, float * __restrict__ csum) {
+__global__ void __launch_bounds__(256) k_topk1(const float * __restrict__ logits, int n_vocab, int k, int32_t * __restrict__ cid, float * __restrict__ cval, float * __restrict__ cmax, float * __restrict__ csum, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     __shared__ float sv[2][4]; __shared__ int si[2][4];
     const int t = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (n_vocab + TOPK_NCH - 1) / TOPK_NCH, lo = ch * per, hi = min(n_vocab, lo + per);
@@ -602,7 +613,8 @@ __global__ void __launch_bounds__(256) k_topk1(const float * __restrict__ logits
     if (tid == 0) { cmax[t * TOPK_NCH + ch] = first; csum[t * TOPK_NCH + ch] = (sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3]); }
 }
 __global__ void __launch_bounds__(64) k_topk2(int k, const int32_t * __restrict__ cid, const float * __restrict__ cval, const float * __restrict__ cmax, const float * __restrict__ csum,
-                                               int32_t * __restrict__ ids, float * __restrict__ vals, float * __restrict__ sumexp) {
+                                               int32_t * __restrict__ ids, float * __restrict__ vals, float * __restrict__ sumexp, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
     const int t = blockIdx.x, lane = threadIdx.x;
     const int n = TOPK_NCH * k;                                        // <= 256: four candidates per lane
     float cv[4]; int ci[4];
@@ -640,7 +652,7 @@ extern "C" int pi_op_topk(const float * logits, int n_vocab, int n_tok, int k, i
     if (!scratch) { pi_set_error("pi_op_topk: scratch is NULL (needs pi_op_topk_scratch_bytes(n_tok) bytes)"); return -1; }
     int32_t * cid = (int32_t *) scratch; float * cval = (float *) (cid + (size_t) n_tok * TOPK_NCH * k);
     float * cmax = cval + (size_t) n_tok * TOPK_NCH * k, * csum = cmax + (size_t) n_tok * TOPK_NCH;
-    hipLaunchKernelGGL(k_topk1, dim3(n_tok, TOPK_NCH), dim3(256), 0, (hipStream_t) stream, logits, n_vocab, k, cid, cval, cmax, csum);
-    hipLaunchKernelGGL(k_topk2, dim3(n_tok), dim3(64), 0, (hipStream_t) stream, k, cid, cval, cmax, csum, ids, vals, sumexp);
+    hipLaunchKernelGGL(k_topk1, dim3(n_tok, TOPK_NCH), dim3(256), 0, (hipStream_t) stream, logits, n_vocab, k, cid, cval, cmax, csum, pi_abort_word());
+    hipLaunchKernelGGL(k_topk2, dim3(n_tok), dim3(64), 0, (hipStream_t) stream, k, cid, cval, cmax, csum, ids, vals, sumexp, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }

@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
     // the wave index is made a scalar: with it in a VGPR, g.seg[si] turns into per-lane global loads of the kernel arguments — two
     // dependent memory round trips before the first weight load of every wave
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (pi_aborted(g.abort_w)) return;
     float * xs = (float *) lds + (size_t) wave * L::FLOATS;
     const int q = lane >> 2, c = lane & 3;                                   // producer role: quad q, accumulator lanes 2c, 2c+1
     const int s = lane >> 3, k = lane & 7;                                   // chain role: pair slot s, accumulator lane k
@@ -464,6 +465,7 @@ template <int TYPE, int NT, int G>
 __global__ void __launch_bounds__(1024) k_mmvq_q0r(const mmvq_args g) {
     const mmvq_seg & sg = g.seg[0];
     __shared__ float hand[NT][64];
+    if (pi_aborted(g.abort_w)) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int r = lane >> 3, k = lane & 7;
     const int64_t row = (int64_t) blockIdx.x * 8 + r;
@@ -547,6 +549,7 @@ template <int TYPE, int NT>
 __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     const mmvq_seg & sg = g.seg[0];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (pi_aborted(g.abort_w)) return;
     // LDS tile: qs [NT][TILE groups][128] | d [NT][TILE][4] f16
     uint8_t * l_qs = lds;
     uint16_t * l_d = (uint16_t *) (lds + (size_t) NT * MMVQ_TILE * 128);
@@ -634,6 +637,7 @@ __global__ void __launch_bounds__(256) k_mmvq_leg(const mmvq_args g) {
     constexpr int DSTR = Y81 ? 16 : 8;                                       // bytes of activation scales per group: 4 floats or 4 f16
     const mmvq_seg & sg = g.seg[0];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (pi_aborted(g.abort_w)) return;
     uint8_t * l_qs = lds;                                                    // qs [NT][TILE groups][128] | d [NT][TILE][DSTR] | s [NT][TILE][16]
     uint8_t * l_d = lds + (size_t) NT * MMVQ_TILE * 128;
     float * l_s = (float *) (l_d + (size_t) NT * MMVQ_TILE * DSTR);
@@ -948,7 +952,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         L.g.K = (int) K; L.g.nb = (int) nbq;
         L.g.pos = rope ? rope->pos : nullptr; L.g.rope_cs = rope ? rope->cs : nullptr; L.g.dyn = rope ? rope->dyn : nullptr;
         L.g.kv_head = rope ? rope->kv_head : 0; L.g.hd = rope ? rope->hd : 2; L.g.tok0 = t0;
-        L.g.frag = nullptr; L.g.aux = nullptr; L.g.nt = nt;
+        L.g.frag = nullptr; L.g.aux = nullptr; L.g.nt = nt; L.g.abort_w = pi_abort_word();
         L.rope = rope != nullptr;
         for (int i = 0; i < n_w; i++) {
             const pi_weight * w = ws[i];

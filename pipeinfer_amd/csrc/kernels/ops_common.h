@@ -38,6 +38,8 @@ struct pi_weight {
 };
 
 void pi_set_error(const char * fmt, ...);
+// abort word the calling thread's launches (and captures) hand to their kernels (pi_set_abort_word; nullptr: no check)
+const int32_t * pi_abort_word();
 const pi_tables & pi_get_tables();
 
 #define PI_CHECK_HIP(expr)                                                                   \

@@ -72,6 +72,14 @@ static __device__ __forceinline__ float pi_wave_max(float v) {
     return v;
 }
 
+// ---- device-visible abort word of a run (runtime.hip: pi_op_abort_begin / pi_op_abort_cancel) ----------------------------------------
+// The reference's workers poll the cancel channel between every two graph nodes (ggml.c:15748-15811, llama.cpp:5665-5687); here every hot-path
+// kernel of a context reads that context's abort word — (run id << 1 | aborted), rewritten by device-scope atomics only — and returns when bit 0
+// is set.  The load bypasses L1 (sc1, agent scope: what a poll of another agent's atomic needs) and is issued first; kernels that stream
+// weights look at the value only after their first loads are in flight (vmcnt retires in order, so the wait costs them nothing).
+static __device__ __forceinline__ int pi_abort_peek(const int32_t * w) { return w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
+static __device__ __forceinline__ bool pi_aborted(const int32_t * w) { return (pi_abort_peek(w) & 1) != 0; }
+
 // signed 4 x int8 dot product accumulate: v_dot4c_i32_i8
 static __device__ __forceinline__ int pi_dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 

@@ -104,6 +104,30 @@ extern "C" int pi_memset(void * dst, int v, size_t n, void * stream) { PI_CHECK_
 extern "C" int pi_device_sync(void) { PI_CHECK_HIP(hipDeviceSynchronize()); return 0; }
 extern "C" int pi_stream_sync(void * stream) { PI_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream)); return 0; }
 
+// ---- abort word of a run (pi_device.h: pi_aborted) --------------------------------------------------------------------------------
+static thread_local const int32_t * g_abort_word = nullptr;
+const int32_t * pi_abort_word() { return g_abort_word; }
+extern "C" void pi_set_abort_word(const int32_t * word_dev) { g_abort_word = word_dev; }
+// device-scope atomics only: the exchange at a run's start and the compare-and-swap of a cancel never tear, whichever stream runs first
+__global__ void k_abort_begin(int32_t * word, int32_t run_id, const int32_t * host_flag) {
+    const int32_t f = host_flag ? __hip_atomic_load(host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+    __hip_atomic_exchange(word, (run_id << 1) | (f != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_abort_cancel(int32_t * word, int32_t run_id) {
+    int32_t expect = run_id << 1;
+    __hip_atomic_compare_exchange_strong(word, &expect, (run_id << 1) | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" int pi_op_abort_begin(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, void * stream) {
+    hipLaunchKernelGGL(k_abort_begin, dim3(1), dim3(1), 0, (hipStream_t) stream, word_dev, run_id & 0x3fffffff, host_flag);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * stream) {
+    hipLaunchKernelGGL(k_abort_cancel, dim3(1), dim3(1), 0, (hipStream_t) stream, word_dev, run_id & 0x3fffffff);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- weight upload + re-layout ------------------------------------------------------------------------------------
 // one thread per source block; bytes are moved into the k-major layouts of ops_common.h
 __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t nblocks, int bsize, int qs_off) {

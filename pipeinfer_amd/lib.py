@@ -80,6 +80,9 @@ def _declare(lib):
     lib.pi_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     lib.pi_memset.argtypes = [vp, i32, sz, vp]
     lib.pi_stream_sync.argtypes = [vp]
+    lib.pi_set_abort_word.argtypes = [vp]; lib.pi_set_abort_word.restype = None
+    lib.pi_op_abort_begin.argtypes = [vp, i32, vp, vp]
+    lib.pi_op_abort_cancel.argtypes = [vp, i32, vp]
     lib.pi_kernel_timing.argtypes = [i32, i32]
     lib.pi_kernel_timing_report.argtypes = [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.pi_weight_upload.restype = vp

@@ -257,7 +257,12 @@ def bench_main(args, rank, world):
             os.close(keep)
     lib = L.load()
     n_dev = max(1, lib.pi_device_count())
-    local = int(os.environ.get("LOCAL_RANK", str(rank))) % n_dev
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    shared_gpu = world > n_dev
+    if shared_gpu and os.environ.get("PIPEINFER_ALLOW_SHARED_GPU") != "1":
+        # one rank per GPU is the contract; doubling ranks up on a device silently would turn a scaling run into something else
+        raise SystemExit(f"[bench rank {rank}] {world} ranks but only {n_dev} GPU(s) visible: refusing to share devices (PIPEINFER_ALLOW_SHARED_GPU=1 overrides, tests only)")
+    local %= n_dev
     L.check(lib.pi_device_init(local), "pi_device_init")
     # the default workload of N > 1 is BASELINE configs[2] (70B target); PIPEINFER_KEEP_WORKLOAD=1 keeps an explicit --workload 7b
     tspec, tft, dspec, dft = B.WORKLOADS[args.workload]
@@ -307,7 +312,7 @@ def bench_main(args, rank, world):
     if rank != 0:
         st = tp.serve(ctx=backend.ctx)
         stats = backend.stats()
-        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"]], dtype=torch.float64)    # single-token calls
+        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"], float(st["runs"])], dtype=torch.float64)    # single-token calls
         dist.gather(t, None, dst=0)
         dist.barrier()
         tp.close()
@@ -345,8 +350,8 @@ def bench_main(args, rank, world):
     tp.shutdown()
     tp_device_mode = tp.device_mode
     head_stats = tp.stats()
-    gathered = [torch.zeros(8, dtype=torch.float64) for _ in range(world)]
-    dist.gather(torch.zeros(8, dtype=torch.float64), gathered, dst=0)
+    gathered = [torch.zeros(9, dtype=torch.float64) for _ in range(world)]
+    dist.gather(torch.zeros(9, dtype=torch.float64), gathered, dst=0)
     dist.barrier()
     tp.close()
     if not os.environ.get("PIPEINFER_KEEP_STAGE_FILES"):
@@ -361,7 +366,7 @@ def bench_main(args, rank, world):
     stage_stats = [{"rank": r, "layers": list(ranges[r - 1]), "calls": int(gathered[r][1]), "gpu_ms_per_call": round(float(gathered[r][0]) / max(1.0, float(gathered[r][1])), 4),
                     "GBps": round(float(gathered[r][2]) / max(1e-9, float(gathered[r][0]) * 1e-3) / 1e9, 1),
                     "runs_skipped": int(gathered[r][3]), "runs_cut_short": int(gathered[r][4]), "wait_for_input_ms": round(float(gathered[r][5]), 1),
-                    "compute_ms": round(float(gathered[r][6]), 1), "hop_ms": round(float(gathered[r][7]), 1)} for r in range(1, world)]
+                    "compute_ms": round(float(gathered[r][6]), 1), "hop_ms": round(float(gathered[r][7]), 1), "runs": int(gathered[r][8])} for r in range(1, world)]
     slow = max(stage_stats, key=lambda s: s["gpu_ms_per_call"])
     # dominant kernel = the single-token Q4_K mat-vec of every stage; its HBM traffic comes from the committed single-GPU PMC pass of the same
     # kernel sources (the per-launch traffic of a mat-vec does not depend on which stage launches it)
@@ -370,7 +375,11 @@ def bench_main(args, rank, world):
     out = {"metric": B.METRIC if args.workload == "70b" else f"accepted tokens/sec + acceptance rate, {tspec} {tft} target / {dspec} draft", "value": main_sum["tokens_per_s"], "unit": "tokens/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_total / args.steps, 2), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "int8 x int4/6 dot, fp32 accumulate (f16 KV)", "data": "synthetic",
-           "config": {"workload": f"{tspec} {tft} target layer-split over {n_stage} GPU(s) + {dspec} {dft} draft on GPU0; stage hop = " + ("peer store into the next stage's HBM ring (hipIpc over xGMI)" if tp_device_mode else "host-staged rings in shared memory"), "schedule": sched,
+           # how a stage boundary is crossed: "peer" = the producing stage stores into a ring in the consuming stage's HBM (hipIpc mapping, xGMI), "host" = rings in shared host memory
+           "transport": "peer" if tp_device_mode else "host", "devices_shared": bool(shared_gpu),
+           "hop_ms": {str(s_["rank"]): s_["hop_ms"] for s_ in stage_stats}, "hop_us_per_run": {str(s_["rank"]): round(1e3 * s_["hop_ms"] / max(1, s_["runs"]), 2) for s_ in stage_stats},
+           "wait_for_input_ms": {str(s_["rank"]): s_["wait_for_input_ms"] for s_ in stage_stats},
+           "config": {"workload": f"{tspec} {tft} target layer-split over {n_stage} GPU(s) + {dspec} {dft} draft on GPU0", "schedule": sched,
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel, "p_accept": args.p_accept,
                       "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "layer_ranges": [list(r) for r in ranges],
                       "layer_split": "reference ggml_mpi_split_range, equal weights" if ref_split else "balanced by work (lm_head charged to the last stage)",

@@ -544,3 +544,26 @@ def test_cancel_of_a_run_in_flight_stops_it_at_a_segment_boundary(LL):
     assert np.array_equal(l1.view(np.uint32), r1.view(np.uint32))
     print("segments skipped by cancels:", skipped, "of", 20 * 3)
     c.free(); ref.free(); m.free()
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 3 ...` exactly as the round driver invokes it — no torchrun around it, no RANK / WORLD_SIZE in the environment
+    (the reference starts every rank from one command: ggml-mpi.c:58-61, speculative.cpp:116-139).  The parent spawns the ranks as children before
+    any GPU call and forwards rank 0's single JSON line.  Three ranks share this one GPU, which needs the explicit override; without it the job refuses."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=root, OMP_NUM_THREADS="2", PIPEINFER_CACHE=str(tmp_path / "models"))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=dict(env, PIPEINFER_ALLOW_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["value"] > 0 and out["lossless_vs_target_only"] is True
+    assert out["transport"] in ("peer", "host") and out["devices_shared"] is True
+    assert set(out["hop_ms"]) == {"1", "2"} and set(out["wait_for_input_ms"]) == {"1", "2"}
+    print("bench --gpus 3 (one shared GPU):", {k: out[k] for k in ("value", "transport", "hop_ms", "hop_us_per_run", "wait_for_input_ms")})
+    # more ranks than devices without the override: refused loudly, non-zero exit, no result line
+    r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode != 0 and "refusing to share devices" in r2.stderr and not r2.stdout.strip()

@@ -430,3 +430,51 @@ def test_qkv_rope_epilogue_equals_separate_launches(gpu, types, hd, n_head, n_he
     lib.pi_rope_table_free(table)
     for w in ws:
         lib.pi_weight_free(w)
+
+
+def test_abort_word_stops_kernels_of_the_cancelled_run_only(gpu):
+    """Kernel-granular early cancellation (reference: the abort callback polled between graph nodes, ggml.c:15748-15811, llama.cpp:5665-5687): every hot-path
+    kernel launched under pi_set_abort_word reads (run id << 1 | aborted) on entry.  pi_op_abort_cancel is a compare-and-swap on the run id: it stops the run that
+    is executing, never another one; a run that is not aborted computes the oracle's bits."""
+    from pipeinfer_amd import lib as L
+    lib, U = gpu
+    t, k, rows, n_tok = O.Q4_K, 4096, 256, 2
+    rng = np.random.default_rng(5)
+    blocks = synth.random_blocks(t, rows * k, rng, 0.05).reshape(rows, -1)
+    act = rng.standard_normal((n_tok, k)).astype(np.float32)
+    want = O.Impl("oracle").mul_mat(t, blocks, k, rows, act)
+    w = upload_weight(lib, t, rows, k, blocks)
+    word = U.Dev(np.zeros(4, np.int32))
+    xd = U.Dev(act)
+    sentinel = np.full((n_tok, rows), 12345.0, np.float32)
+
+    def run(expect_computed, before):
+        """quantise + mat-vec + a norm under the abort word, after `before` has set the word up; the outputs either stay the sentinel or are the oracle's"""
+        q8 = U.Dev(nbytes=lib.pi_q8_nbytes(O.Q8_K, k, n_tok)); out = U.Dev(sentinel); y = U.Dev(np.full((n_tok, k), 777.0, np.float32))
+        before()
+        lib.pi_set_abort_word(word.ptr)
+        try:
+            L.check(lib.pi_op_quantize(O.Q8_K, xd.ptr, k, n_tok, q8.ptr, None))
+            L.check(lib.pi_op_mul_mat(w, q8.ptr, n_tok, out.ptr, None, None))
+            L.check(lib.pi_op_norm(xd.ptr, None, None, y.ptr, k, n_tok, 1e-5, 1, None))
+        finally:
+            lib.pi_set_abort_word(None)
+        got, gy = out.get(np.float32, (n_tok, rows)), y.get(np.float32, (n_tok, k))
+        if expect_computed:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and not np.any(gy == 777.0)
+        else:
+            assert np.array_equal(got, sentinel) and np.all(gy == 777.0), "kernels of an aborted run must return before they write anything"
+
+    flag = np.zeros(1, np.int32)                                        # (the engine keeps these flags in pinned host memory; NULL = no flag to pick up)
+    run(True, lambda: L.check(lib.pi_op_abort_begin(word.ptr, 7, None, None)))
+    assert word.get(np.int32)[0] == 7 << 1
+    run(True, lambda: L.check(lib.pi_op_abort_cancel(word.ptr, 6, None)))                       # a cancel for ANOTHER run (one that is not executing) changes nothing
+    assert word.get(np.int32)[0] == 7 << 1
+    run(False, lambda: L.check(lib.pi_op_abort_cancel(word.ptr, 7, None)))                      # the executing run: stopped
+    assert word.get(np.int32)[0] == (7 << 1) | 1
+    run(False, lambda: None)                                                                    # ... and stays stopped: every later kernel of it returns on entry
+    run(True, lambda: L.check(lib.pi_op_abort_begin(word.ptr, 8, None, None)))                  # the next run starts clean
+    run(True, lambda: L.check(lib.pi_op_abort_cancel(word.ptr, 7, None)))                       # a late cancel of the old run cannot touch it
+    assert word.get(np.int32)[0] == 8 << 1
+    lib.pi_weight_free(w)
+    del flag
