@@ -138,7 +138,7 @@ def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_promp
     n_layer = synth.SPECS[tspec][1]
     if n_layer <= 32:
         spt, done, kind = _time_cpu_model(tgt_path, n_tokens, 16, cores, 25.0)
-        return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "kind": kind,
+        return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "threads": cores, "host_cores": os.cpu_count(), "kind": kind,
                 "sample": f"target-only greedy decode of {done} tokens after a 16-token prompt, same synthetic GGUF, n_threads={cores}"}
     p4 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 4))
     p8 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 8))
@@ -147,8 +147,9 @@ def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_promp
     per_layer = max(1e-9, (t8 - t4) / 4.0)
     head = max(0.0, t4 - 4.0 * per_layer)
     spt = head + n_layer * per_layer
-    return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "kind": kind,
-            "sample": f"target-only greedy decode, reference kernels on {cores} threads: {d4}+{d8} tokens on 4- and 8-layer copies of the {n_layer}-layer model (tensor types of "
+    # cores = threads = what the leg actually used (ggml's spin-waiting pool stops scaling near 32 threads); host_cores = what the GPU box's host has
+    return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "threads": cores, "host_cores": os.cpu_count(), "kind": kind,
+            "sample": f"target-only greedy decode, reference kernels on {cores} of the host's {os.cpu_count()} cores: {d4}+{d8} tokens on 4- and 8-layer copies of the {n_layer}-layer model (tensor types of "
                       f"layers 8..15, embedding + lm_head included) -> {per_layer * 1e3:.2f} ms per layer + {head * 1e3:.2f} ms head, extrapolated linearly to {n_layer} layers "
                       f"= {spt * 1e3:.0f} ms per token"}
 
@@ -376,6 +377,7 @@ def main():
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel,
                       "p_accept": args.p_accept, "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy",
                       "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}, draft wrong on {args.draft_miss:.0%} of the vocabulary",
+                      "engine": {"kernel_abort_word": os.environ.get("PI_NO_ABORT_WORD") is None, "target_layers_per_segment": seg_layers},
                       "driver_additions": {"adaptive_window": args.adaptive_window, "adaptive_pause": args.adaptive_pause, "min_spec_iters": args.min_spec_iters, "max_inflight": args.max_inflight}},
            "acceptance": {k: v for k, v in main_sum.items() if k != "tokens_per_s"},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff, "other_schedules": other,

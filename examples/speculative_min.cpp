@@ -12,9 +12,19 @@
 #include "llama.h"
 #include "pipeinfer.h"
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+
+// the boundary is a struct layout as much as a set of names: llama_batch is passed BY VALUE (llama.h:142-162; 80 bytes on x86-64 = int32 + pad + 6 pointers + 5 int32,
+// SURVEY 8b), llama_token_data is 12 bytes (llama.h:116-120) — a caller compiled against the reference's header must find the same offsets here
+static_assert(sizeof(llama_batch) == 80, "llama_batch layout differs from the reference (llama.h:142-162)");
+static_assert(offsetof(llama_batch, n_tokens) == 0 && offsetof(llama_batch, token) == 8 && offsetof(llama_batch, embd) == 16 && offsetof(llama_batch, pos) == 24 &&
+              offsetof(llama_batch, n_seq_id) == 32 && offsetof(llama_batch, seq_id) == 40 && offsetof(llama_batch, logits) == 48 && offsetof(llama_batch, all_pos_0) == 56 &&
+              offsetof(llama_batch, all_pos_1) == 60 && offsetof(llama_batch, all_seq_id) == 64 && offsetof(llama_batch, batch_id) == 68 && offsetof(llama_batch, max_n_seq) == 72,
+              "llama_batch field offsets differ from the reference (llama.h:142-162)");
+static_assert(sizeof(llama_token_data) == 12 && offsetof(llama_token_data, logit) == 4 && offsetof(llama_token_data, p) == 8, "llama_token_data layout (llama.h:116-120)");
 
 static void batch_add(llama_batch & b, llama_token id, llama_pos pos, llama_seq_id seq, bool logits) {
     b.token[b.n_tokens] = id; b.pos[b.n_tokens] = pos; b.n_seq_id[b.n_tokens] = 1; b.seq_id[b.n_tokens][0] = seq; b.logits[b.n_tokens] = logits;

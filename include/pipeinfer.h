@@ -84,8 +84,12 @@ struct pipeinfer_transport_params {
     int32_t timeout_ms;          /* set-up and result waits (0: 120 s) */
 };
 struct pipeinfer_transport_stats {
-    uint64_t runs, skipped, cut_short, cancel_notes;   /* stage: computed / forwarded as skipped / stopped between segments / notes seen; head: started / skipped / - / notes written */
-    double   wait_in_ms, compute_ms, send_ms;          /* stage: waiting for a header, inside the backend, in the hop to the next stage */
+    uint64_t runs, skipped, cut_short, cancel_notes;   /* stage: computed / forwarded as skipped (cut_short included) / stopped inside the run / notes seen; head: started / came back skipped / - / notes written */
+    double   wait_in_ms, compute_ms, send_ms;          /* stage: waiting for a header, inside the backend, between the end of a run and its header being published downstream (host side of the hop) */
+    uint64_t received;                                 /* stage: headers taken from the incoming ring == runs + skipped; head: results consumed (== started once everything is back) */
+    double   wait_out_ms;                              /* stage: back-pressure — waiting for a free slot in the next stage's ring (or the result ring) before a run */
+    double   hop_gpu_ms;                               /* stage: GPU time of the in-stream store of the activations into the next stage's ring (last stage: of the logits into the result slot) */
+    int32_t  peer_access;                              /* stage: what hipDeviceCanAccessPeer said for (this device -> next stage's device); -1: not asked (same device, host rings, last stage) */
 };
 /* stage compute behind the transport when it is not a llama_context of this library (the CPU tests plug the oracle in here):
  * 0 = computed, 1 = dropped, < 0 error; x_in / x_out are host pointers when the transport runs on host rings */
@@ -105,7 +109,9 @@ LLAMA_API int  pipeinfer_transport_attach_head(pipeinfer_transport * tp, struct 
 LLAMA_API int  pipeinfer_transport_shutdown(pipeinfer_transport * tp);
 LLAMA_API void pipeinfer_transport_get_stats(pipeinfer_transport * tp, struct pipeinfer_transport_stats * out);      /* head-side counters */
 /* ranks >= 1: serves runs until the head shuts the pipeline down.  Compute = pipeinfer_stage_run_abortable on stage_ctx (backend NULL),
- * or the backend's run().  A sender thread overlaps each hop with the next run's compute. */
+ * or the backend's run().  A stage stores its activations, in stream order behind its last kernel, straight into a slot of the NEXT stage's ring (reserved before the
+ * run starts) and then publishes the 32-byte header: one device-to-device copy and one flag per hop, no staging buffer, no sender thread.  A watcher thread follows the cancel
+ * table while a run computes and stops it at the next kernel (pi_op_abort_cancel). */
 LLAMA_API int  pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_context * stage_ctx, const struct pipeinfer_stage_backend * backend, struct pipeinfer_transport_stats * out);
 
 /* Offline quantisation of one run of fp32 values into `type` (ggml type id: 0 f32, 1 f16, 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 10..14 Q2_K..Q6_K) with the
@@ -120,7 +126,7 @@ struct pipeinfer_stats {
     uint64_t n_calls;            /* decode calls issued on this context */
     double   gpu_ms;             /* sum over calls of (done event - start event) on the context's stream */
     uint64_t alg_bytes;          /* algorithmic HBM bytes of those calls (SURVEY 8d formula) */
-    uint64_t weight_bytes;       /* bytes of this stage's weights resident in HBM */
+    uint64_t weight_bytes;       /* bytes of this stage's weights resident in HBM (== ggml_nbytes: what one call streams) */
     uint64_t kv_bytes_per_cell;  /* K+V bytes per cached token for this stage's layers */
     uint64_t n_calls_1;          /* the same three counters restricted to single-token calls (prompt batches excluded) */
     double   gpu_ms_1;
@@ -129,6 +135,7 @@ struct pipeinfer_stats {
     uint64_t n_cancel_runs;      /* runs finished as cancelled (before or after their start) */
     uint64_t n_cancel_runs_started; /* ... of which llama_cancel_run arrived after llama_start_async_decode: their kernels return on entry from then on (abort word) */
     double   cancel_gpu_ms;      /* GPU time (first to last event) those started-then-cancelled runs still took */
+    uint64_t weight_copy_bytes;  /* HBM held by the tile-major copies of the matrix-core kernel (0 for contexts with n_batch <= 2: they are not made) */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
 LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);

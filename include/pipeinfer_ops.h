@@ -62,6 +62,9 @@ PI_API int     pi_kernel_timing_report(int weight_type, int n_tok, double * avg_
 PI_API pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host_blocks, void * stream);
 PI_API void    pi_weight_free(pi_weight * w);
 PI_API size_t  pi_weight_nbytes(const pi_weight * w);  /* HBM bytes == ggml_nbytes of the tensor */
+PI_API size_t  pi_weight_copy_nbytes(const pi_weight * w); /* HBM bytes of the second, tile-major copy the matrix-core kernel reads (0 without one) */
+/* uploads of the calling thread from now on do (1, default) / do not (0) make that copy: a context that never decodes more than two tokens at once has no use for it */
+PI_API void    pi_weight_set_mq_copies(int on);
 PI_API const void * pi_weight_data(const pi_weight * w); /* device address of the (repacked) tensor bytes */
 /* reads [p, p + bytes) once with up to `workgroups` workgroups (0: as many as the bytes need): warms the memory-side Infinity Cache */
 PI_API int     pi_op_prefetch(const void * p, size_t bytes, int workgroups, void * stream);
@@ -110,6 +113,7 @@ PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const f
  * captured HIP graph can be replayed for every call (n_kv then only sizes LDS and the mask row stride). */
 PI_API int pi_op_attention(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
                            int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, const int32_t * dyn_dev, void * stream);
+PI_API int pi_op_mmq_min_tokens(void);                             /* narrowest batch that pi_op_mul_mat sends to the matrix-core kernel (and its tile-major weight copies) */
 PI_API int pi_op_mul_mat_reserve(void);                            /* once per process, outside graph capture: dynamic-LDS limits of the matrix-core kernels */
 PI_API int pi_op_attention_reserve(int head_dim, int n_kv_max);   /* once per context, outside graph capture: LDS limit for long contexts */
 PI_API int pi_op_silu_mul(const float * gate_dev, const float * up_dev, float * out_dev, int64_t n, void * stream);

@@ -71,7 +71,8 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     const pi_hparams & hp = m->hparams;
     if (pi_device_init(m->device) != 0) { err = pi_last_error(); return false; }
     const int64_t t0 = time_us();
-    if (!m->ensure_loaded(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, err)) return false;
+    // a context whose n_batch-bounded widest pass stays below the matrix-core kernel's first width never reads the tile-major copies: do not make them
+    if (!m->ensure_loaded(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, ctx->n_batch >= pi_op_mmq_min_tokens(), err)) return false;
     ctx->t_load_us += time_us() - t0;
     const int nb = ctx->n_batch, n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, n_layer_local = ctx->l1 - ctx->l0;
     {   // the draft context asks for the high-priority queue: its kernels are small and on the critical path of speculation, the
@@ -295,9 +296,9 @@ static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, 
 // PI_NO_ABORT_WORD=1 (A/B measurements, tests): kernels are launched without an abort word, cancels then act between segments only
 static bool abort_checks_on() { static const bool on = getenv("PI_NO_ABORT_WORD") == nullptr; return on; }
 // ahead of a run's kernels, in stream order: the abort word takes the run's identity (and a cancel that has arrived already)
-static bool launch_abort_begin(llama_context * ctx, const pi_run * run) {
+static bool launch_abort_begin(llama_context * ctx, int32_t run_id) {
     if (!ctx->abort_dev) return true;
-    if (pi_op_abort_begin(ctx->abort_dev, run->run_id, ctx->abort_host + (run->run_id & 255), ctx->stream) != 0) { ctx->last_error = std::string("pi_op_abort_begin: ") + pi_last_error(); return false; }
+    if (pi_op_abort_begin(ctx->abort_dev, run_id, ctx->abort_host + (run_id & 255), ctx->stream) != 0) { ctx->last_error = std::string("pi_op_abort_begin: ") + pi_last_error(); return false; }
     return true;
 }
 // segment `seg` of the forward pass: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device memory that
@@ -402,7 +403,7 @@ static void feed_run(llama_context * ctx, pi_run * run) {
             if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
             yield_to_urgent(ctx);
             if (run->cancel_req.load()) break;                                  // llama_cancel_run arrived while the run was in flight
-            ok = launch_abort_begin(ctx, run);
+            ok = launch_abort_begin(ctx, run->run_id);
             if (ok) ok = launch_segment(ctx, run->n_tokens, kv_head, seg, &run->sink);
             if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
         }
@@ -516,7 +517,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         return run;
     }
     if (!run->canceled) {                                                     // a cancelled run still occupies its cells and completes "empty" (llama.cpp:5627-5716)
-        ok = launch_abort_begin(ctx, run);
+        ok = launch_abort_begin(ctx, run->run_id);
         if (ok) ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
         if (ok) ok = launch_outputs(ctx, run);
         run->launched = ok;
@@ -537,6 +538,24 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     ctx->inflight.push_back(run);
     rc = 0;
     return run;
+}
+
+void context_cancel_run(llama_context * ctx, pi_run * r) {
+    if (r->cancel_req.load()) return;
+    // Not handed to the GPU yet: the feeder drops it whole.  Handed over (partly): the kernels of THIS run return on entry from now on — the flag is picked up by the
+    // run's next pi_op_abort_begin, the compare-and-swap hits the run if it is the one executing (kernel granularity, like the reference's poll between graph nodes:
+    // ggml.c:15748-15811); a segmented context also stops launching its remaining segments.
+    r->cancel_req.store(true);
+    if (ctx->abort_host) ctx->abort_host[r->run_id & 255] = 1;
+    if (ctx->abort_dev && ctx->ctl_stream && r->state.load() != 0 && pi_op_abort_cancel(ctx->abort_dev, r->run_id, ctx->ctl_stream) != 0)
+        fprintf(stderr, "llama_cancel_run: %s\n", pi_last_error());
+}
+
+void stage_abort_current(llama_context * ctx) {
+    const int32_t rid = ctx->stage_run_id.load();
+    if (rid == 0 || !ctx->abort_host || !ctx->abort_dev || !ctx->ctl_stream || ctx->abort_host[rid & 255]) return;
+    ctx->abort_host[rid & 255] = 1;                                            // picked up by the run's next pi_op_abort_begin ...
+    (void) pi_op_abort_cancel(ctx->abort_dev, rid, ctx->ctl_stream);           // ... and hits the kernels already enqueued (only if that run is still the one executing)
 }
 
 bool context_poll_oldest(llama_context * ctx) {
@@ -564,12 +583,16 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     if (n_tokens <= 0 || n_tokens > ctx->n_batch || meta_bytes < (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4) { ctx->last_error = "stage_run: bad metadata block"; return -1; }
     if (!ctx->is_first && !x_in) { ctx->last_error = "stage_run: activations missing"; return -1; }
     hipStream_t s = ctx->stream;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr, ec = nullptr;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1); (void) hipEventCreate(&ec);
     (void) hipEventRecord(e0, s);
+    // the run's identity on the device: its kernels carry the context's abort word, so a cancel that reaches this process while the stage is inside the run
+    // (stage_abort_current, called by the transport's watcher) stops it at the next KERNEL, not at the next segment (llama.cpp:5665-5687 polls between graph nodes)
+    const int32_t rid = (++ctx->run_counter) & 0x3fffffff;
+    if (ctx->abort_host) ctx->abort_host[rid & 255] = 0;
+    ctx->stage_run_id.store(rid);
     // With an abort callback and a segmented context (pipeinfer_context_set_segments) the calling thread plays the feeder: segments go
-    // out at most two ahead of the GPU and the callback is asked before each — a run cancelled by the head while this stage computes it
-    // stops at the next segment boundary (the reference's workers poll for the cancel message between graph nodes, llama.cpp:5665-5687).
+    // out at most two ahead of the GPU and the callback is asked before each — the unlaunched rest of a cancelled run is never enqueued.
     bool ok = true, cut = false;
     const int nseg = n_segments(ctx);
     if (should_abort && nseg > 1) {
@@ -580,14 +603,18 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
         for (; ok && seg < nseg; seg++) {
             if (seg >= 2) (void) hipEventSynchronize(ctx->seg_events[seg & 1]);
             if (seg > 0 && should_abort(abort_user)) { cut = true; break; }
-            ok = launch_segment(ctx, n_tokens, kv_head, seg, nullptr);
+            ok = launch_abort_begin(ctx, rid);
+            if (ok) ok = launch_segment(ctx, n_tokens, kv_head, seg, nullptr);
             if (ok) ok = hipEventRecord(ctx->seg_events[seg & 1], s) == hipSuccess;
         }
         ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
     } else {
-        ok = launch_forward(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in, nullptr);
+        ok = launch_abort_begin(ctx, rid);
+        if (ok) ok = launch_forward(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in, nullptr);
     }
     const size_t nv = ctx->model->hparams.n_vocab;
+    (void) hipEventRecord(ec, s);
+    // the hop: the activations are stored by THIS stream straight into the consumer's ring slot (x_out: a peer mapping of the next stage's HBM, or host memory)
     if (ok && !cut && !ctx->is_last) ok = hipMemcpyAsync(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;
     if (ok && !cut && ctx->is_last)
         ok = hipMemcpyAsync(logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -596,9 +623,13 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
              hipMemcpyAsync(topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
     (void) hipEventRecord(e1, s);
     if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
+    ctx->stage_run_id.store(0);
+    // cancelled while its (last) kernels were enqueued: they returned on entry, what the copies above moved is not a result
+    if (ok && !cut && ((ctx->abort_host && ctx->abort_host[rid & 255]) || (should_abort && should_abort(abort_user)))) cut = true;
     float ms = 0.0f;
     if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n_tokens == 1 && !cut) ctx->stat_gpu_ms_1 += ms; }
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (ok && !cut && hipEventElapsedTime(&ms, ec, e1) == hipSuccess) ctx->stat_hop_ms += ms;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipEventDestroy(ec);
     if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "stage_run failed"; return -1; }
     if (cut) return 1;
     const int32_t * h_dyn = (const int32_t *) meta + 2 * n_tokens;

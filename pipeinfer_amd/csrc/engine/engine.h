@@ -55,10 +55,12 @@ struct llama_model {
     std::vector<pi_layer> layers;
     std::vector<void *> f32_allocs;
     size_t hbm_bytes = 0;                     // bytes resident in HBM for this process's stage(s)
+    size_t hbm_copy_bytes = 0;                // ... plus the tile-major copies the matrix-core kernel reads (pi_weight::mq)
 
     ~llama_model();
     // uploads (once) token_embd if first, layers [l0,l1), final norm + output if last
-    bool ensure_loaded(int l0, int l1, bool first, bool last, std::string & err);
+    // want_mq: also make the tile-major copies of the K-quant matrices (contexts whose widest pass reaches the matrix-core kernel)
+    bool ensure_loaded(int l0, int l1, bool first, bool last, bool want_mq, std::string & err);
     size_t stage_weight_bytes(int l0, int l1, bool first, bool last, int n_tok) const;
 };
 
@@ -127,6 +129,8 @@ struct llama_context {
     // stream order, by pi_op_abort_begin (which also picks up a cancel that arrived before: abort_host[id & 255], pinned); llama_cancel_run of a run already
     // handed to the GPU sets that flag and enqueues pi_op_abort_cancel on ctl_stream — a compare-and-swap that only hits while that very run is executing.
     int32_t * abort_dev = nullptr; int32_t * abort_host = nullptr; hipStream_t ctl_stream = nullptr; int32_t run_counter = 0;
+    std::atomic<int32_t> stage_run_id{0};    // pipeline stages (stage_run): id of the run being computed, 0 between runs (read by the transport's cancel watcher)
+    double stat_hop_ms = 0.0;                // pipeline stages: GPU time of the in-stream store of the activations into the next stage's ring
     uint64_t stat_cancel_runs = 0, stat_cancel_runs_started = 0; double stat_cancel_gpu_ms = 0.0;     // cancelled runs: all / handed to the GPU before the cancel / GPU time they still took
     bool prepared = false, prepare_failed = false;      // device state fully allocated / an attempt failed half-way (never retried)
     int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr; void * topk_scratch_dev = nullptr;
@@ -156,10 +160,12 @@ bool context_prepare(llama_context * ctx, std::string & err);          // upload
 pi_run * context_start(llama_context * ctx, const llama_batch & batch, int & rc);   // rc: 0 ok, 1 no slot, <0 error
 int  context_finish(llama_context * ctx, pi_run * run);
 bool context_poll_oldest(llama_context * ctx);
+void context_cancel_run(llama_context * ctx, pi_run * run);              // stops a started run: unlaunched segments are dropped, kernels already enqueued return on entry (abort word)
 void urgent_drop_all(llama_context * ctx);                                  // the context gives up its claim on the device arbiter (destructor, priority change)
 bool context_wait(llama_context * ctx, pi_run * run);                    // blocks until the run's results are in host memory
 int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
                int (*should_abort)(void *) = nullptr, void * abort_user = nullptr);        // 0 done, 1 cut short by should_abort, < 0 error
+void stage_abort_current(llama_context * ctx);                             // any thread: the run stage_run is computing right now returns from every kernel on entry from now on
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

@@ -84,16 +84,7 @@ extern "C" bool llama_mpi_iprobe(struct llama_context * ctx) { return pi::contex
 extern "C" void llama_cancel_run(struct llama_context * ctx, int32_t * canceled, int count) {
     for (int i = 0; i < count; i++) {
         ctx->canceled_batches.insert(canceled[i]);                                                     // llama.cpp:9981-9993
-        for (pi_run * r : ctx->inflight) {
-            if (r->batch_id != canceled[i] || r->cancel_req.load()) continue;
-            // already started.  Not handed to the GPU yet: the feeder drops it whole.  Handed over (partly): the kernels of THIS run return on entry from now on — the flag
-            // is picked up by the run's next pi_op_abort_begin, the compare-and-swap hits the run if it is the one executing (kernel granularity, like the reference's poll
-            // between graph nodes: ggml.c:15748-15811); a segmented context also stops launching its remaining segments.
-            r->cancel_req.store(true);
-            if (ctx->abort_host) ctx->abort_host[r->run_id & 255] = 1;
-            if (ctx->abort_dev && ctx->ctl_stream && r->state.load() != 0 && pi_op_abort_cancel(ctx->abort_dev, r->run_id, ctx->ctl_stream) != 0)
-                fprintf(stderr, "llama_cancel_run: %s\n", pi_last_error());
-        }
+        for (pi_run * r : ctx->inflight) if (r->batch_id == canceled[i]) pi::context_cancel_run(ctx, r);      // already started: stops at kernel granularity (context.cpp)
         if (ctx->remote && ctx->remote_ops.cancel) ctx->remote_ops.cancel(ctx->remote_ops.user, canceled[i]);
     }
 }
@@ -337,6 +328,7 @@ extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer
     out->kv_bytes_per_cell = (uint64_t) 4 * ctx->model->hparams.n_embd_gqa() * (uint64_t) (ctx->l1 - ctx->l0);
     out->n_segments = ctx->stat_segments; out->n_segments_skipped = ctx->stat_segments_skipped;
     out->n_cancel_runs = ctx->stat_cancel_runs; out->n_cancel_runs_started = ctx->stat_cancel_runs_started; out->cancel_gpu_ms = ctx->stat_cancel_gpu_ms;
+    out->weight_copy_bytes = ctx->model->hbm_copy_bytes;
 }
 extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; }
 

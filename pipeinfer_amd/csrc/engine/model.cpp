@@ -30,6 +30,7 @@ static pi_weight * upload_matrix(llama_model & m, const std::string & name, int6
     pi_weight * w = pi_weight_upload(t->type, ne0, ne1, t->data, nullptr);
     if (!w) { err = std::string("upload of ") + name + " failed: " + pi_last_error(); return nullptr; }
     m.hbm_bytes += pi_weight_nbytes(w);
+    m.hbm_copy_bytes += pi_weight_copy_nbytes(w);
     return w;
 }
 
@@ -44,10 +45,14 @@ static float * upload_f32(llama_model & m, const std::string & name, int64_t n, 
     return d;
 }
 
-bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, std::string & err) {
+bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want_mq, std::string & err) {
     const pi_hparams & hp = hparams;
     const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff;
+    struct mq_scope { ~mq_scope() { pi_weight_set_mq_copies(1); } } restore;      // (the setting is the calling thread's)
+    pi_weight_set_mq_copies(0);                                                  // the embedding table is only ever gathered from (get_rows): no matrix-core copy
     if (first && !tok_embd) { if (!(tok_embd = upload_matrix(*this, "token_embd.weight", n_embd, hp.n_vocab, err))) return false; }
+    // tile-major copies (+78 % HBM on a Q4_K_M model) only where a pass can be wide enough to use them
+    pi_weight_set_mq_copies(want_mq ? 1 : 0);
     for (int il = l0; il < l1; il++) {
         pi_layer & L = layers[il];
         if (L.loaded) continue;

@@ -9,7 +9,8 @@
 //   * ACTIVATIONS [n_tokens][n_embd] fp32 are stored by the producing stage straight into a ring in the consuming stage's HBM
 //     (hipIpc memory handle opened once; one device-to-device copy over xGMI per hop on the producer's copy stream).  The consumer
 //     never posts a receive: slot k of its ring is free as soon as it has consumed header k, so the next run's activations arrive
-//     while it still computes the current one, and a sender thread per stage overlaps the hop with the next run's compute;
+//     while it still computes the current one.  The producer reserves the slot before it starts the run and its compute stream stores the
+//     activations there right behind its last kernel — "direct peer store + flag" (SURVEY 2.4): no staging buffer, no sender thread;
 //   * LOGITS + the device top-8 of the last stage go into a result ring in the shared segment (D2H straight into the slot);
 //   * CANCEL notes are entries of one shared append-only table — no message per stage; a stage looks at it before a run and,
 //     through pipeinfer_stage_run_abortable, between the segments of the run it is computing.
@@ -54,6 +55,7 @@ struct stage_block {                             // index = rank
     ring_ctl in;                                 // producer: rank - 1 (the head for rank 1); consumer: rank
     msg_hdr slots[TP_IN1_SLOTS];                 // ranks >= 2 use the first TP_X_SLOTS
     std::atomic<uint32_t> ipc_ready, probe_written, joined, setup_done;
+    std::atomic<int32_t> device;                 // HIP device ordinal of the rank's process (-1: none)
     char ipc_handle[64];                         // hipIpcMemHandle_t
 };
 struct shm_layout {
@@ -84,6 +86,7 @@ struct pipeinfer_transport {
     float * peer_ring = nullptr;                 // device mode: the next stage's ring, mapped through hipIpc
     hipStream_t copy_stream = nullptr;
     bool res_registered = false;
+    int peer_access = -1;                        // hipDeviceCanAccessPeer(this device, next stage's device); -1: not asked
     // head side
     int32_t gen = 0;
     uint64_t started = 0, consumed = 0;
@@ -196,6 +199,22 @@ void setup_device_rings(pipeinfer_transport * tp) {
     if (r >= 1 && r + 1 < W) {                                                  // map the next stage's ring and write the probe block
         if (!tp->wait_for([&] { return L->st[r + 1].ipc_ready.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) L->device_fail.store(1);
         if (!L->device_fail.load()) {
+            // say what the hardware offers for this pair before relying on it (the lazy flag of hipIpcOpenMemHandle below would enable it silently — or not)
+            const int nd = L->st[r + 1].device.load();
+            if (nd >= 0 && nd != tp->device) {
+                int can = 0;
+                e = hipDeviceCanAccessPeer(&can, tp->device, nd);
+                tp->peer_access = e == hipSuccess ? can : 0;
+                hipError_t pe = hipSuccess;
+                if (tp->peer_access) { pe = hipDeviceEnablePeerAccess(nd, 0); if (pe == hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); pe = hipSuccess; } }
+                fprintf(stderr, "[pipeinfer transport, rank %d] device %d -> device %d (rank %d): hipDeviceCanAccessPeer = %d, hipDeviceEnablePeerAccess: %s\n", r, tp->device, nd, r + 1,
+                        tp->peer_access, tp->peer_access ? hipGetErrorString(pe) : "not attempted");
+                if (!tp->peer_access || pe != hipSuccess) { fprintf(stderr, "[pipeinfer transport, rank %d] no peer access to the next stage's device: activations will be staged through host memory\n", r); L->device_fail.store(1); }
+            } else if (nd == tp->device) {
+                fprintf(stderr, "[pipeinfer transport, rank %d] the next stage (rank %d) shares device %d: the hop is a copy inside one HBM\n", r, r + 1, nd);
+            }
+        }
+        if (!L->device_fail.load()) {
             hipIpcMemHandle_t h; memcpy(&h, L->st[r + 1].ipc_handle, sizeof h);
             if ((e = hipIpcOpenMemHandle((void **) &tp->peer_ring, h, hipIpcMemLazyEnablePeerAccess)) != hipSuccess) { bad("hipIpcOpenMemHandle", e); tp->peer_ring = nullptr; }
             else {
@@ -256,6 +275,7 @@ int head_wait(void * user, int32_t run_seq, float * logits, int32_t * ids, float
     } else tp->head_stats.skipped++;
     L->res.tail.store(t + 1, std::memory_order_release);
     tp->consumed++;
+    tp->head_stats.received = tp->consumed;
     return computed ? 1 : 0;
 }
 void head_cancel(void * user, int32_t batch_id) {
@@ -287,6 +307,7 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
     if (!map_segment(tp, *P)) { pipeinfer_transport_close(tp); return nullptr; }
     shm_layout * L = tp->L;
     if (P->device < 0 || getenv("PIPEINFER_TRANSPORT_HOST")) L->device_fail.store(1);   // a rank without a GPU (or the test switch): host rings for everybody
+    L->st[tp->rank].device.store(P->device);
     L->st[tp->rank].joined.store(1, std::memory_order_release);
     for (int r = 0; r < tp->world; r++)
         if (!tp->wait_for([&] { return L->st[r].joined.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never joined the transport"); pipeinfer_transport_close(tp); return nullptr; }
@@ -349,103 +370,102 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
     pipeinfer_transport_stats st{};
     if (dev && hipSetDevice(tp->device) != hipSuccess) { tp->fail("hipSetDevice failed"); return -1; }
 
-    // outgoing activations: two local buffers, so that the hop of run k overlaps the compute of run k + 1
-    float * x_out[2] = { nullptr, nullptr };
-    const size_t xb = L->x_slot_bytes;
-    if (!is_last) for (int i = 0; i < 2; i++) {
-        if (dev) { if (hipMalloc((void **) &x_out[i], xb) != hipSuccess) { tp->fail("hipMalloc of the outgoing activation buffer failed"); return -1; } }
-        else x_out[i] = (float *) malloc(xb);
+    st.peer_access = tp->peer_access;
+    // host rings (no GPU in this process, or no peer mapping): a stage context still computes on its device and its stream copies straight into / out of the host slots
+    // (hipMemcpyDefault); slots are page-locked once so that those copies are asynchronous
+    bool x_registered = false;
+    if (ctx && !dev && tp->world > 2) {
+        if (hipHostRegister(tp->base + L->off_x, L->x_slot_bytes * TP_X_SLOTS * (size_t) (tp->world - 2), hipHostRegisterDefault) == hipSuccess) x_registered = true; else (void) hipGetLastError();
     }
-    struct out_msg { msg_hdr h; int buf; };
-    std::mutex mu; std::condition_variable cv;
-    std::deque<out_msg> outq; int buf_busy[2] = { 0, 0 }; bool sender_failed = false;
-    std::thread sender;
-    if (!is_last) sender = std::thread([&] {
-        if (dev) (void) hipSetDevice(tp->device);
-        ring_ctl & nx = L->st[r + 1].in;
-        while (true) {
-            out_msg m;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !outq.empty(); }); m = outq.front(); outq.pop_front(); }
-            const uint64_t h = nx.head.load(std::memory_order_relaxed);
-            const int64_t t0 = now_us();
-            if (!tp->wait_for([&] { return h - nx.tail.load(std::memory_order_acquire) < (uint64_t) TP_X_SLOTS; }, -1)) { std::lock_guard<std::mutex> lk(mu); sender_failed = true; cv.notify_all(); return; }
-            if (m.h.kind == KIND_RUN && !(m.h.flags & F_SKIPPED)) {
-                const size_t bytes = (size_t) m.h.n_tokens * tp->n_embd * 4;
-                bool ok = true;
-                if (dev) ok = hipMemcpyAsync((uint8_t *) tp->peer_ring + (h % TP_X_SLOTS) * xb, x_out[m.buf], bytes, hipMemcpyDeviceToDevice, tp->copy_stream) == hipSuccess && hipStreamSynchronize(tp->copy_stream) == hipSuccess;
-                else memcpy(tp->host_x_slot(r + 1, h), x_out[m.buf], bytes);
-                if (!ok) { tp->fail("peer store of the activations failed"); std::lock_guard<std::mutex> lk(mu); sender_failed = true; cv.notify_all(); return; }
-            }
-            if (m.buf >= 0) { std::lock_guard<std::mutex> lk(mu); buf_busy[m.buf] = 0; cv.notify_all(); }
-            L->st[r + 1].slots[h % TP_X_SLOTS] = m.h;
-            nx.head.store(h + 1, std::memory_order_release);                    // the header is published after its activations have landed
-            { std::lock_guard<std::mutex> lk(mu); st.send_ms += (now_us() - t0) / 1e3; }
-            if (m.h.kind == KIND_SHUTDOWN) return;
+    const size_t xb = L->x_slot_bytes;
+
+    // kernel-granular cancel: while a run computes, a watcher follows the cancel table and stops it through the run's device-side abort word
+    std::atomic<uint64_t> watch_key{~0ull}; std::atomic<bool> watch_stop{false};
+    std::thread watcher;
+    if (ctx) watcher = std::thread([&] {
+        if (tp->device >= 0) (void) hipSetDevice(tp->device);
+        uint64_t cursor = 0; std::unordered_set<uint64_t> seen;
+        while (!watch_stop.load(std::memory_order_relaxed)) {
+            const uint64_t n = L->n_cancel.load(std::memory_order_acquire);
+            for (; cursor < n; cursor++) seen.insert(L->cancel[cursor % TP_CANCEL_CAP].load(std::memory_order_relaxed));
+            const uint64_t key = watch_key.load(std::memory_order_acquire);
+            if (key != ~0ull && seen.count(key)) pi::stage_abort_current(ctx);
+            std::this_thread::sleep_for(std::chrono::microseconds(key != ~0ull ? 30 : 200));
         }
     });
 
     ring_ctl & in = L->st[r].in;
     const int cap = tp->in_cap(r);
-    int rc_all = 0, jbuf = 0;
+    int rc_all = 0;
+    // publishes header m downstream (next stage's ring slot h, or the result ring): the activations / logits it announces have landed (the stream was synchronised)
+    auto publish = [&](const msg_hdr & m, uint64_t h, uint8_t * rs) {
+        if (is_last) { *(msg_hdr *) rs = m; L->res.head.store(h + 1, std::memory_order_release); }
+        else { L->st[r + 1].slots[h % TP_X_SLOTS] = m; L->st[r + 1].in.head.store(h + 1, std::memory_order_release); }
+    };
     while (true) {
         const uint64_t t = in.tail.load(std::memory_order_relaxed);
         int64_t t0 = now_us();
         if (!tp->wait_for([&] { return in.head.load(std::memory_order_acquire) > t; }, -1)) { rc_all = -1; break; }
         st.wait_in_ms += (now_us() - t0) / 1e3;
         msg_hdr m = L->st[r].slots[t % cap];
+        // reserve the outgoing slot BEFORE the run: the stage's own stream stores into it, and slot k of a consumer is free once it has consumed header k
+        uint8_t * rs = nullptr; uint64_t oh = 0;
+        t0 = now_us();
+        if (is_last) {
+            if (m.kind != KIND_SHUTDOWN) {
+                oh = L->res.head.load(std::memory_order_relaxed);
+                if (!tp->wait_for([&] { return oh - L->res.tail.load(std::memory_order_acquire) < (uint64_t) TP_RES_SLOTS; }, -1)) { rc_all = -1; break; }
+                rs = tp->res_slot(oh);
+            }
+        } else {
+            ring_ctl & nx = L->st[r + 1].in;
+            oh = nx.head.load(std::memory_order_relaxed);
+            if (!tp->wait_for([&] { return oh - nx.tail.load(std::memory_order_acquire) < (uint64_t) TP_X_SLOTS; }, -1)) { rc_all = -1; break; }
+        }
+        st.wait_out_ms += (now_us() - t0) / 1e3;
         if (m.kind == KIND_SHUTDOWN) {
             in.tail.store(t + 1, std::memory_order_release);
-            if (!is_last) { std::lock_guard<std::mutex> lk(mu); outq.push_back({ m, -1 }); cv.notify_all(); }
+            if (!is_last) publish(m, oh, nullptr);
             break;
         }
+        st.received++;
         const int n = m.n_tokens;
         const size_t words = (size_t) (tp->n_ctx + 31) / 32, meta_bytes = (size_t) n * 8 + 16 + (size_t) n * words * 4;
         bool skipped = (m.flags & F_SKIPPED) != 0;
         if (!skipped && tp->is_cancelled(m.gen, m.batch_id)) skipped = true;    // the head cancelled it before this stage started on it
-        uint8_t * rs = nullptr; uint64_t rh = 0;
-        if (is_last) {
-            rh = L->res.head.load(std::memory_order_relaxed);
-            if (!tp->wait_for([&] { return rh - L->res.tail.load(std::memory_order_acquire) < (uint64_t) TP_RES_SLOTS; }, -1)) { rc_all = -1; break; }
-            rs = tp->res_slot(rh);
-        }
-        int buf = -1;
         if (!skipped) {
-            if (!is_last) {
-                buf = jbuf & 1;
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !buf_busy[buf] || sender_failed; });
-                if (sender_failed) { rc_all = -1; break; }
-                buf_busy[buf] = 1;
-            }
             const float * x_in = is_first ? nullptr : (dev ? (const float *) ((uint8_t *) tp->my_ring + (t % TP_X_SLOTS) * xb) : tp->host_x_slot(r, t));
-            float * xo = is_last ? nullptr : x_out[buf];
+            float * xo = is_last ? nullptr : (dev ? (float *) ((uint8_t *) tp->peer_ring + (oh % TP_X_SLOTS) * xb) : tp->host_x_slot(r + 1, oh));
             tp->cur_key = ((uint64_t) (uint32_t) m.gen << 32) | (uint32_t) m.batch_id;
+            watch_key.store(tp->cur_key, std::memory_order_release);
             t0 = now_us();
             int rc;
+            const double hop0 = ctx ? ctx->stat_hop_ms : 0.0;
             if (backend) rc = backend->run(backend->user, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr);
             else rc = pi::stage_run(ctx, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr, abort_probe, tp);
             st.compute_ms += (now_us() - t0) / 1e3;
+            if (ctx) st.hop_gpu_ms += ctx->stat_hop_ms - hop0;
+            watch_key.store(~0ull, std::memory_order_release);
             tp->cur_key = ~0ull;
             if (rc < 0) { tp->fail(std::string("stage run failed: ") + (ctx ? pipeinfer_context_error(ctx) : "backend error")); rc_all = -1; break; }
-            if (rc == 1) { skipped = true; st.cut_short++; if (buf >= 0) { std::lock_guard<std::mutex> lk(mu); buf_busy[buf] = 0; } buf = -1; }
-            else { st.runs++; if (!is_last) jbuf++; }
+            if (rc == 1) { skipped = true; st.cut_short++; }
+            else st.runs++;
         }
         if (skipped) st.skipped++;
+        t0 = now_us();
         in.tail.store(t + 1, std::memory_order_release);                        // the incoming activation slot is free again
         m.flags = skipped ? F_SKIPPED : 0;
-        if (is_last) {
-            *(msg_hdr *) rs = m;
-            L->res.head.store(rh + 1, std::memory_order_release);
-        } else {
-            std::lock_guard<std::mutex> lk(mu);
-            outq.push_back({ m, buf }); cv.notify_all();
-        }
+        publish(m, oh, rs);                                                     // what the header announces has landed: stage_run returns with its stream idle
+        st.send_ms += (now_us() - t0) / 1e3;
     }
-    if (sender.joinable()) {
-        if (rc_all != 0) { std::lock_guard<std::mutex> lk(mu); msg_hdr bye{}; bye.kind = KIND_SHUTDOWN; outq.push_back({ bye, -1 }); cv.notify_all(); }
-        sender.join();
+    if (rc_all != 0 && !is_last) {                                              // tell the stages behind this one: nothing else will come
+        ring_ctl & nx = L->st[r + 1].in;
+        const uint64_t h = nx.head.load(std::memory_order_relaxed);
+        if (h - nx.tail.load(std::memory_order_acquire) < (uint64_t) TP_X_SLOTS) { msg_hdr bye{}; bye.kind = KIND_SHUTDOWN; publish(bye, h, nullptr); }
     }
-    for (int i = 0; i < 2; i++) if (x_out[i]) { if (dev) (void) hipFree(x_out[i]); else free(x_out[i]); }
+    watch_stop.store(true);
+    if (watcher.joinable()) watcher.join();
+    if (x_registered) (void) hipHostUnregister(tp->base + L->off_x);
     st.cancel_notes = tp->cancel_cursor;
     if (out) *out = st;
     return rc_all;

@@ -49,6 +49,7 @@ int pi_mmq_min_nt() {
     static const int v = [] { const char * e = getenv("PI_MMQ_MIN_NT"); const int n = e ? atoi(e) : 3; return n < 2 ? 2 : n; }();
     return v;
 }
+extern "C" int pi_op_mmq_min_tokens(void) { return pi_mmq_min_nt(); }
 bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
 // accumulator lane and only wins from 5 tokens (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),

@@ -35,6 +35,7 @@ struct pi_weight {
     // 16 blocks are contiguous (tools_dev/pattern.hip).  [row group of 16][block][PI_MQ_TILE (Q4_K) / PI_MQ_TILE_Q5 (Q5_K) bytes]; scales / mins unpacked per lane, quants re-ordered (layout in runtime.hip)
     const uint8_t * mq;
     void *   mq_base;
+    size_t   mq_nbytes;    // HBM bytes of that copy (0 without one)
 };
 
 void pi_set_error(const char * fmt, ...);

@@ -128,6 +128,7 @@ extern "C" int pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * str
     return 0;
 }
 
+static thread_local bool g_mq_copies = true;      // pi_weight_set_mq_copies: whether uploads of this thread also make the tile-major copy of the matrix-core kernel
 // ---- weight upload + re-layout ------------------------------------------------------------------------------------
 // one thread per source block; bytes are moved into the k-major layouts of ops_common.h
 __global__ void k_repack_k45(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t nblocks, int bsize, int qs_off) {
@@ -344,16 +345,24 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
         } else if (type == PI_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
         else                 hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
     }
-    w->mq = nullptr; w->mq_base = nullptr;
+    w->mq = nullptr; w->mq_base = nullptr; w->mq_nbytes = 0;
     static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
-    if (mq_on && (type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) {
+    if (mq_on && g_mq_copies && (type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) {
         const int64_t n_rg = (ne1 + 15) / 16;
         const size_t tile_sz = type == PI_Q6_K ? PI_MQ_TILE_Q6 : type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
-        if (hipMalloc(&w->mq_base, (size_t) n_rg * w->nb * tile_sz + 512) != hipSuccess) { (void) hipFree(staging); return fail("hipMalloc of the tile-major copy failed"); }
-        w->mq = (const uint8_t *) w->mq_base;
-        const dim3 mgrid((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads));
-        if (type == PI_Q6_K) hipLaunchKernelGGL(k_repack_mq_q6_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
-        else hipLaunchKernelGGL(k_repack_mq_q45_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb, type == PI_Q5_K ? 1 : 0);
+        const size_t mq_bytes = (size_t) n_rg * w->nb * tile_sz + 512;
+        if (hipMalloc(&w->mq_base, mq_bytes) != hipSuccess) {
+            // the copy only serves the matrix-core kernel; without it mul_mat takes the (bit-identical) VALU kernel for every width: a model that fits without the copies must still load
+            (void) hipGetLastError();
+            w->mq_base = nullptr;
+            static bool said = false;
+            if (!said) { said = true; fprintf(stderr, "pi_weight_upload: no HBM left for the tile-major copies of the matrix-core kernel (%zu bytes asked): batches fall back to the VALU kernel\n", mq_bytes); }
+        } else {
+            w->mq = (const uint8_t *) w->mq_base; w->mq_nbytes = mq_bytes;
+            const dim3 mgrid((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads));
+            if (type == PI_Q6_K) hipLaunchKernelGGL(k_repack_mq_q6_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
+            else hipLaunchKernelGGL(k_repack_mq_q45_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb, type == PI_Q5_K ? 1 : 0);
+        }
     }
     const hipError_t e = hipStreamSynchronize(stream);
     (void) hipFree(staging);
@@ -363,6 +372,8 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
 
 extern "C" void pi_weight_free(pi_weight * w) { if (w) { (void) hipFree(w->base); if (w->mq_base) (void) hipFree(w->mq_base); delete w; } }
 extern "C" size_t pi_weight_nbytes(const pi_weight * w) { return w->nbytes; }
+extern "C" size_t pi_weight_copy_nbytes(const pi_weight * w) { return w ? w->mq_nbytes : 0; }
+extern "C" void pi_weight_set_mq_copies(int on) { g_mq_copies = on != 0; }
 
 // ---- Infinity-Cache warm-up: read [p, p + bytes) once so that the bytes sit in the 256 MB memory-side cache when the mat-vec that owns them starts.
 // Runs on a side stream next to the latency-bound launches of a decode layer (norm / quantise / attention keep one to 64 CUs busy and leave HBM idle).

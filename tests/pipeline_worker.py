@@ -129,6 +129,7 @@ def main():
         else:
             comp = CheckedOracle(tgt) if rank == 2 else Relay(n_embd)
         st = tp.serve(backend=comp.run)
+        dist.gather_object(st, None, dst=0)                 # the stage's counters go into the verdict: conservation is asserted by the test
         dist.barrier()
         tp.close()
         print("stage", rank, "served", st, file=sys.stderr)
@@ -145,9 +146,12 @@ def main():
         local.attach(cd)
         out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec, verbose=int(os.environ.get("V", "0")))
         verdict["trials"].append({"out": [int(x) for x in out[:24]], "want": want, "n_runs_spec": res["n_runs_spec"], "n_runs_canceled": res["n_runs_canceled"],
-                                  "n_accept_clean": res["n_accept_clean"], **{k: tp.stats()[k] for k in ("runs", "skipped", "cancel_notes")}})
+                                  "n_accept_clean": res["n_accept_clean"], **{k: tp.stats()[k] for k in ("runs", "skipped", "cancel_notes", "received")}})
         ct.free(); cd.free()
     tp.shutdown()
+    stages = [None] * world
+    dist.gather_object(None, stages, dst=0)
+    verdict["stages"] = stages[1:]
     dist.barrier()
     tp.close()
     with open(out_path, "w") as f:

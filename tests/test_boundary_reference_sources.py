@@ -41,6 +41,23 @@ def test_reference_driver_compiles_and_links_against_the_boundary():
         assert p.returncode != 0 or "no HIP device" in (p.stderr + p.stdout)
 
 
+def test_boundary_struct_layouts_are_compile_time_checked():
+    """examples/speculative_min.cpp carries static_asserts on sizeof / offsetof of llama_batch (passed by value: llama.h:142-162) and llama_token_data: they hold
+    against include/llama.h, and — where the reference's sources exist — the very same asserts hold against the reference's own llama.h"""
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    src = os.path.join(ROOT, "examples", "speculative_min.cpp")
+    text = open(src).read()
+    assert "static_assert(sizeof(llama_batch) == 80" in text and "offsetof(llama_batch, batch_id) == 68" in text
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), src], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if os.path.isdir(REF):
+        asserts = text[text.index("static_assert(sizeof(llama_batch)"):text.index("static void batch_add")]
+        probe = "#include <cstddef>\n" + asserts
+        r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I" + REF, "-include", os.path.join(REF, "llama.h"), "-x", "c++", "-"], input=probe, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+
 @need_ref
 def test_reference_sampling_known_answers_run_against_our_samplers(tmp_path):
     exe = str(tmp_path / "test-sampling")

@@ -4,6 +4,7 @@
   * greedy continuation == the reference's (the lossless-speculation ground truth)
   * the PipeInfer driver's accepted tokens == that same greedy continuation, for several draft models and settings
 Tolerance on logits: 1e-3 absolute (BASELINE.json north_star); measured spread is printed."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -567,3 +568,38 @@ def test_bench_starts_its_own_ranks(tmp_path):
     # more ranks than devices without the override: refused loudly, non-zero exit, no result line
     r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r2.returncode != 0 and "refusing to share devices" in r2.stderr and not r2.stdout.strip()
+
+
+@pytest.mark.parametrize("segments", [0, 1])
+def test_cancel_after_the_start_stops_the_run_at_kernel_granularity(LL, segments):
+    """llama_cancel_run after llama_start_async_decode with the device abort word (llama.cpp:9981-9993; the reference's workers poll between graph nodes, ggml.c:15748-15811):
+    the cancelled run's kernels return on entry from then on, whether the context launches whole runs itself (segments = 0) or through its feeder; the run finishes "empty" (no
+    top-k rows may be sampled from it), the counters see it, a cancel for a run that has already finished changes nothing, and later runs equal a fresh context bit for bit."""
+    stem = "tiny_llama_b_q4_k_m"
+    m = LL.Model(os.path.join(GOLD, stem + ".gguf"))
+    c, ref = LL.Context(m, n_ctx=256, n_batch=64), LL.Context(m, n_ctx=256, n_batch=64)
+    if segments:
+        c.set_segments(segments)
+    prompt = [5, 9, 13, 200, 77, 31, 8, 19]
+    l0 = c.decode(prompt, list(range(8)), [[0]] * 8); r0 = ref.decode(prompt, list(range(8)), [[0]] * 8)
+    assert np.array_equal(l0.view(np.uint32), r0.view(np.uint32))
+    c.reset_stats()
+    ids, lg, sm = (C.c_int32 * 8)(), (C.c_float * 8)(), C.c_float()
+    for trial in range(12):
+        t = c.start([42, 43, 44, 45], [8, 9, 10, 11], [[1]] * 4, batch_id=100 + trial)      # a speculative batch in partition 1
+        c.cancel([100 + trial])
+        assert c.lib.llama_finish_async_decode(c.h, t[1].c, t[0]) == 1
+        assert c.lib.pipeinfer_get_topk(c.h, 0, ids, lg, C.byref(sm)) != 0, "a cancelled run has no rows to sample"
+        c.seq_rm(1, 8, -1)                                                                 # the driver frees the partition's cells
+        # an uncancelled run right behind it computes the reference's bits (the abort word was re-armed by its own pi_op_abort_begin) ...
+        a = c.decode([42 + trial], [8], [[2]]); b = ref.decode([42 + trial], [8], [[2]])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), trial
+        c.cancel([100 + trial])                                                            # ... and a late, repeated cancel of the finished run touches nothing
+        a = c.decode([7 + trial], [9], [[2]]); b = ref.decode([7 + trial], [9], [[2]])
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), trial
+        c.seq_rm(2, 8, -1); ref.seq_rm(2, 8, -1)
+    st = c.stats()
+    assert st["n_cancel_runs"] == 12 and st["n_cancel_runs_started"] == 12, st
+    print(f"segments={segments}: 12 runs cancelled after their start took {st['cancel_gpu_ms']:.3f} ms of GPU time in all; segments dropped by the feeder: {st['n_segments_skipped']}")
+    c.free(); ref.free(); m.free()
+

@@ -324,6 +324,18 @@ def test_topk(gpu, n_vocab):
         want = np.exp((logits[t] - logits[t].max()).astype(np.float64)).sum()
         assert abs(gs[t] - want) / want < 1e-5
     assert gi[1, 0] == 7 and gi[1, 1] == 100
+    # ... and against the oracle's restatement of llama_sample_softmax (llama.cpp:7019-7046: sorted by logit, p = expf(l - max) / sum over the FULL vocabulary in fp32) and of
+    # llama_sample_token_greedy (:7496-7510: the first maximum): ids and logits exactly; probabilities to 1e-5 relative — the reference adds its 32 000 exponentials in
+    # sorted order in fp32, the device in chunk order (the driver compares p with the thresholds p_accept / p_split only)
+    o = O.oracle()
+    for t in range(3):
+        oi, ol, op = np.zeros(8, np.int32), np.zeros(8, np.float32), np.zeros(8, np.float32)
+        row = np.ascontiguousarray(logits[t])
+        o.o_softmax_topk(row.ctypes.data, n_vocab, 8, oi.ctypes.data, ol.ctypes.data, op.ctypes.data)
+        assert list(gi[t]) == list(oi) and np.array_equal(gv[t], ol)
+        assert gi[t, 0] == o.o_argmax(row.ctypes.data, n_vocab)
+        p_dev = np.exp(gv[t] - gv[t, 0]) / gs[t]
+        assert np.all(np.abs(p_dev - op) <= 1e-5 * op + 1e-12), (p_dev, op)
 
 
 @pytest.mark.parametrize("vdt,n", [(O.Q8_K, 256), (O.Q8_K, 4096), (O.Q8_K, 8192), (O.Q8_K, 11008), (O.Q8_0, 4544), (O.Q8_0, 256), (O.Q8_0, 18176)])

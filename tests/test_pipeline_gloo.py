@@ -41,7 +41,17 @@ def test_head_and_stage_over_gloo_are_lossless(tmp_path, tgt, dft, seed, world):
     for t in v["trials"]:
         assert t["out"] == t["want"], t
         assert t["runs"] > 0 and t["skipped"] <= t["runs"]                   # counters are cumulative over the three generations
+        assert t["received"] == t["runs"], t                                   # conservation at the head: every started run came back (computed or as a skipped header)
     last = v["trials"][-1]
+    assert len(v["stages"]) == world - 1
+    for st in v["stages"]:
+        # conservation at every stage: each run the head started passed through it exactly once, as a computed run or as a skipped header (a run cut short inside the
+        # stage counts as skipped); nothing lost, nothing duplicated
+        assert st["received"] == last["runs"] and st["runs"] + st["skipped"] == st["received"] and st["cut_short"] <= st["skipped"], (st, last)
+    # what the head saw come back as skipped is what the LAST stage forwarded as skipped (a skip propagates down the pipeline, never up)
+    assert last["skipped"] == v["stages"][-1]["skipped"], (last, v["stages"])
+    for a, b in zip(v["stages"], v["stages"][1:]):
+        assert a["skipped"] <= b["skipped"]
     assert last["cancel_notes"] <= sum(t["n_runs_canceled"] for t in v["trials"])   # one shared note per cancelled run; only speculative runs are cancelled on the wire (speculative.cpp:1211)
     if tgt != dft:
         assert last["cancel_notes"] > 0
@@ -49,3 +59,17 @@ def test_head_and_stage_over_gloo_are_lossless(tmp_path, tgt, dft, seed, world):
     assert any(t["n_runs_spec"] > 0 for t in v["trials"])
     if tgt == dft:
         assert any(t["n_accept_clean"] > 0 for t in v["trials"])
+
+
+def test_bench_spawns_its_ranks_and_refuses_to_share_a_device():
+    """`python bench.py --gpus 2` with no launcher around it and no RANK / WORLD_SIZE in the environment (how the round driver calls it): the parent process starts the
+    ranks itself as children (torch.distributed.run) — here, without a GPU, both ranks then refuse loudly to double up on one device, the parent forwards the failure as
+    a non-zero exit code and prints no result line.  (The same command on a GPU box, three ranks sharing the one GPU by explicit override: tests/test_gpu_engine.py.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PIPEINFER_ALLOW_SHARED_GPU")}
+    env.update(PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "refusing to share devices" in r.stderr, r.stderr[-2000:]
+    assert "[bench rank 0]" in r.stderr and "[bench rank 1]" in r.stderr           # two ranks were really started
+    assert not r.stdout.strip()
