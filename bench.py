@@ -286,7 +286,12 @@ def main():
     seg_layers = int(os.environ.get("PIPEINFER_SEG_LAYERS", str(max(1, synth.SPECS[tspec][1] // 2))))
     if seg_layers > 0:
         ct.set_segments(seg_layers)
+    # Engine feature, not a driver change: the target's feeder takes every live run waiting in its queue into one forward pass (include/pipeinfer.h: run coalescing).
+    # On ONE GPU the PipeInfer driver's non-speculative run for a freshly sampled token and the speculative run(s) drafted meanwhile wait behind the run in flight; carried
+    # together they stream the 41 GB of weights once instead of once each.  Every token's bits are those it gets alone (tests/test_gpu_engine.py).
+    coalesce = int(os.environ.get("PIPEINFER_COALESCE", "16")) if seg_layers > 0 else 0
     ct.prepare(); cd.prepare()
+    ct.set_coalescing(coalesce)
     print(f"[bench] models resident in HBM after {time.time() - t0:.1f}s", file=sys.stderr)
 
     spec = dict(n_predict=args.n_predict, n_draft=args.n_draft, n_parallel=args.n_parallel, p_accept=args.p_accept, p_split=args.p_split,
@@ -330,6 +335,12 @@ def main():
             s = summarize([r for _, r in outs])
             s["lossless_vs_target_only"] = bool(generation(0, mode=mode)[0][:args.n_predict] == ref_tokens[:args.n_predict]) if mode != 2 else True
             other[name] = s
+        if coalesce > 1 and args.mode == 0:            # the same schedule with one forward pass per run, as the reference's stages compute them
+            ct.set_coalescing(0)
+            s = summarize([generation(1 + args.warmup + i)[1] for i in range(min(args.steps, 2))])
+            s["lossless_vs_target_only"] = bool(generation(0)[0][:args.n_predict] == ref_tokens[:args.n_predict])
+            other["pipeinfer_one_pass_per_run"] = s
+            ct.set_coalescing(coalesce)
 
     # roofline of the dominant kernel.  Events recorded inside a captured graph cannot be read back on ROCm 7.2, so the sampling pass
     # replays one generation of the timed schedule kernel by kernel (graphs off) right after the timed region, on the same contexts;
@@ -361,11 +372,12 @@ def main():
     roofline["target_segments"] = {"layers_per_segment": seg_layers, "launched": st_t["n_segments"], "skipped_by_cancel": st_t["n_segments_skipped"]}
     # early cancellation: runs that llama_cancel_run reached AFTER their start return from every kernel on entry from then on (abort word) and the feeder drops their
     # unlaunched segments; `skipped_frac` = 1 - (GPU time those runs still took) / (what the same number of complete calls takes)
-    avg_call_ms = st_t["gpu_ms"] / max(1, st_t["n_calls"] - st_t["n_cancel_runs"])
+    avg_call_ms = st_t["gpu_ms"] / max(1, st_t["n_calls"])
     roofline["target_cancelled_runs"] = {"finished_as_cancelled": st_t["n_cancel_runs"], "cancelled_after_start": st_t["n_cancel_runs_started"],
                                          "gpu_ms_still_spent": round(st_t["cancel_gpu_ms"], 2), "gpu_ms_of_as_many_complete_calls": round(st_t["n_cancel_runs_started"] * avg_call_ms, 2),
                                          "skipped_frac": round(1.0 - st_t["cancel_gpu_ms"] / max(1e-9, st_t["n_cancel_runs_started"] * avg_call_ms), 4) if st_t["n_cancel_runs_started"] else None,
                                          "kernel_abort_word": os.environ.get("PI_NO_ABORT_WORD") is None}
+    roofline["target_passes"] = {"passes": st_t["n_passes"], "runs": st_t["n_pass_runs"], "tokens": st_t["n_pass_tokens"], "passes_of_several_runs": st_t["n_coalesced_passes"]}
     roofline["draft_decode_call"] = {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
                                      "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}
 
@@ -377,7 +389,7 @@ def main():
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel,
                       "p_accept": args.p_accept, "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy",
                       "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}, draft wrong on {args.draft_miss:.0%} of the vocabulary",
-                      "engine": {"kernel_abort_word": os.environ.get("PI_NO_ABORT_WORD") is None, "target_layers_per_segment": seg_layers},
+                      "engine": {"run_coalescing_max_tokens": coalesce, "kernel_abort_word": os.environ.get("PI_NO_ABORT_WORD") is None, "target_layers_per_segment": seg_layers},
                       "driver_additions": {"adaptive_window": args.adaptive_window, "adaptive_pause": args.adaptive_pause, "min_spec_iters": args.min_spec_iters, "max_inflight": args.max_inflight}},
            "acceptance": {k: v for k, v in main_sum.items() if k != "tokens_per_s"},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff, "other_schedules": other,

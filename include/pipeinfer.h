@@ -30,6 +30,13 @@ LLAMA_API int  pipeinfer_context_set_cu_range(struct llama_context * ctx, int cu
  * then stops at the next segment boundary (the reference aborts between graph nodes, llama.cpp:5665-5687), and contexts with a higher
  * stream priority (pipeinfer_context_set_priority) on the same GPU are served between segments instead of after the whole run. */
 LLAMA_API int  pipeinfer_context_set_segments(struct llama_context * ctx, int layers_per_segment);
+/* Run coalescing for a segmented context (any time between generations; max_tokens <= n_batch, 0 or 1 = off, the default): its feeder takes every live run waiting in its queue
+ * — up to max_tokens tokens — into ONE forward pass.  A pass streams the stage's weights once whatever its width, so two queued runs cost ~1.4x one instead of 2x; every
+ * token's logits and KV entries are the bits it would get alone (the kernels are exact at every batch width; a token attends to the cells of its own run's mask; a later
+ * run's reads of an earlier run's cells are satisfied inside the pass, like causal attention inside any batch).  The feeder then does not run ahead of the GPU across
+ * passes and waits up to PIPEINFER_REACTION_US (3000) for the caller to react to a finished pass before it composes the next one.  For one GPU that serves both models:
+ * the PipeInfer driver keeps a non-speculative and one or more speculative runs queued behind the run in flight (speculative.cpp:1182-1275). */
+LLAMA_API int  pipeinfer_context_set_coalescing(struct llama_context * ctx, int max_tokens);
 /* 0: launch the decode kernels one by one instead of replaying the captured HIP graph (profiling / per-kernel event timing) */
 LLAMA_API void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable);
 LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
@@ -135,6 +142,7 @@ struct pipeinfer_stats {
     uint64_t n_cancel_runs;      /* runs finished as cancelled (before or after their start) */
     uint64_t n_cancel_runs_started; /* ... of which llama_cancel_run arrived after llama_start_async_decode: their kernels return on entry from then on (abort word) */
     double   cancel_gpu_ms;      /* GPU time (first to last event) those started-then-cancelled runs still took */
+    uint64_t n_passes, n_pass_runs, n_pass_tokens, n_coalesced_passes;   /* feeder contexts: forward passes computed in full, the runs / tokens they carried, passes of more than one run */
     uint64_t weight_copy_bytes;  /* HBM held by the tile-major copies of the matrix-core kernel (0 for contexts with n_batch <= 2: they are not made) */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);

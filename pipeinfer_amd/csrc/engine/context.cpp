@@ -33,6 +33,8 @@ llama_context::~llama_context() {
     }
     for (auto & kv : graphs) if (kv.second.exec) (void) hipGraphExecDestroy(kv.second.exec);
     for (hipEvent_t e : seg_events) if (e) (void) hipEventDestroy(e);
+    if (pass_event) (void) hipEventDestroy(pass_event);
+    for (uint8_t * b : pass_host) if (b) (void) hipHostFree(b);
     if (ctl_stream) { (void) hipStreamSynchronize(ctl_stream); (void) hipStreamDestroy(ctl_stream); }
     if (abort_host) (void) hipHostFree(abort_host);
     pi_free(abort_dev);
@@ -103,7 +105,7 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     if (!(ctx->x = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->x2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->nx = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->nx2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->qkv = (float *) dev((size_t) 4 * nb * qkv_w)) || !(ctx->att = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->up = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->gate = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->q16 = (uint16_t *) dev((size_t) 2 * nb * n_embd)) ||
-        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev(64)))
+        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev((size_t) 4 * (4 + nb))))
         return false;
     {   // abort word + cancel flags + the control stream cancels travel on (highest priority: a cancel must not queue behind the run it stops)
         int lo = 0, hi = 0;
@@ -283,11 +285,14 @@ static int n_segments(const llama_context * ctx) {
 // x_in (device, [n_tokens][n_embd]) replaces the embedding lookup on stages after the first
 static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, const float * x_in) {
     const int words = (ctx->n_ctx + 31) / 32;
-    const int32_t * h_tok = (const int32_t *) meta, * h_pos = h_tok + n_tokens, * h_dyn = h_pos + n_tokens; const uint32_t * h_mask = (const uint32_t *) (h_dyn + 4);
+    // block: tokens[n] | pos[n] | {kv_head, n_kv, n, has_table} | (cell[n] when has_table: a pass that carries several runs) | mask[n][words]
+    const int32_t * h_tok = (const int32_t *) meta, * h_pos = h_tok + n_tokens, * h_dyn = h_pos + n_tokens;
+    const size_t n_table = h_dyn[3] ? (size_t) n_tokens : 0;
+    const uint32_t * h_mask = (const uint32_t *) (h_dyn + 4 + n_table);
     hipStream_t s = ctx->stream;
     bool ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
-              hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16 + 4 * n_table, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
     if (ok && x_in) ok = hipMemcpyAsync(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;      // device (peer ring) or host (staged transport)
     if (!ok) ctx->last_error = "H2D of batch metadata failed";
@@ -351,11 +356,11 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
 static bool launch_outputs(llama_context * ctx, pi_run * run) {
     if (!ctx->is_last) return true;
     hipStream_t s = ctx->stream;
-    const size_t nv = ctx->model->hparams.n_vocab; const int n_tokens = run->n_tokens;
-    const bool ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                    hipMemcpyAsync(run->topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                    hipMemcpyAsync(run->topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
-                    hipMemcpyAsync(run->topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
+    const size_t nv = ctx->model->hparams.n_vocab, r0 = (size_t) run->row0; const int n_tokens = run->n_tokens;
+    const bool ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev + r0 * nv, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(run->topk_ids, ctx->topk_ids_dev + r0 * 8, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(run->topk_vals, ctx->topk_vals_dev + r0 * 8, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipMemcpyAsync(run->topk_sum, ctx->topk_sum_dev + r0, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (!ok) ctx->last_error = "D2H of logits failed";
     return ok;
 }
@@ -391,47 +396,128 @@ static void yield_to_urgent(const llama_context * ctx) {
 }
 
 // ---- feeder thread of a segmented context ---------------------------------------------------------------------------------------------------
-static void feed_run(llama_context * ctx, pi_run * run) {
-    run->state.store(1);
-    bool ok = hipEventRecord(run->begin, ctx->stream) == hipSuccess, full = false;
+static bool pass_cancelled(const pi_pass & p) {
+    for (const pi_run * r : p.runs) if (!r->canceled && !r->cancel_req.load()) return false;
+    return true;
+}
+// one input block for a pass of several runs: their tokens, positions and mask rows one after the other, the cell of every token, n_kv = the widest run's
+// (cells past a run's own n_kv are masked for its tokens and contribute exact zeros, like every masked cell inside it)
+static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
+    const int n = pass.n_tokens, words = (ctx->n_ctx + 31) / 32;
+    const size_t need = (size_t) n * 8 + 16 + (size_t) n * 4 + (size_t) n * words * 4;
+    if (need > ctx->pass_host_cap) {
+        const size_t cap = std::max(need, (size_t) std::max(ctx->coalesce_max.load(), 1) * (12 + (size_t) words * 4) + 16);
+        for (uint8_t *& b : ctx->pass_host) { if (b) (void) hipHostFree(b); b = nullptr; }
+        (void) hipStreamSynchronize(ctx->stream);
+        for (uint8_t *& b : ctx->pass_host) if (hipHostMalloc((void **) &b, cap, hipHostMallocDefault) != hipSuccess) { b = nullptr; ctx->last_error = "out of pinned host memory (pass staging)"; return nullptr; }
+        ctx->pass_host_cap = cap;
+    }
+    uint8_t * blk = ctx->pass_host[ctx->pass_slot++ & 3];
+    int32_t * tok = (int32_t *) blk, * pos = tok + n, * dyn = pos + n, * cell = dyn + 4; uint32_t * mask = (uint32_t *) (cell + n);
+    int at = 0, n_kv = 0;
+    for (const pi_run * r : pass.runs) {
+        const int m = r->n_tokens;
+        const int32_t * rt = (const int32_t *) r->meta_host, * rp = rt + m, * rd = rp + m; const uint32_t * rm = (const uint32_t *) (rd + 4);
+        memcpy(tok + at, rt, (size_t) 4 * m); memcpy(pos + at, rp, (size_t) 4 * m);
+        for (int i = 0; i < m; i++) cell[at + i] = rd[0] + i;
+        memcpy(mask + (size_t) at * words, rm, (size_t) 4 * m * words);
+        n_kv = std::max(n_kv, (int) rd[1]);
+        at += m;
+    }
+    dyn[0] = cell[0]; dyn[1] = n_kv; dyn[2] = n; dyn[3] = 1;
+    return blk;
+}
+// enqueues one pass (one run, or several runs the feeder took together) on the context's stream; every member's events and state are final afterwards
+static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass) {
+    const std::vector<pi_run *> & runs = pass->runs;
+    for (pi_run * r : runs) r->state.store(1);
+    bool ok = true, full = false;
+    for (pi_run * r : runs) ok = hipEventRecord(r->begin, ctx->stream) == hipSuccess && ok;
     hipEvent_t seg_done[2] = { ctx->seg_events[0], ctx->seg_events[1] };
-    if (!run->canceled && !run->cancel_req.load()) {
-        const int nseg = n_segments(ctx), kv_head = ((const int32_t *) run->meta_host)[2 * run->n_tokens];
-        ok = launch_inputs(ctx, run->n_tokens, run->meta_host, nullptr);
+    const int n = pass->n_tokens;
+    if (!pass_cancelled(*pass)) {
+        const void * meta = runs.size() == 1 ? (const void *) runs[0]->meta_host : compose_pass(ctx, *pass);
+        ok = ok && meta != nullptr;
+        const int nseg = n_segments(ctx), kv_head = ok ? ((const int32_t *) meta)[2 * n] : 0;
+        if (ok) ok = launch_inputs(ctx, n, meta, nullptr);
         int seg = 0;
         for (; ok && seg < nseg; seg++) {
             if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
             yield_to_urgent(ctx);
-            if (run->cancel_req.load()) break;                                  // llama_cancel_run arrived while the run was in flight
-            ok = launch_abort_begin(ctx, run->run_id);
-            if (ok) ok = launch_segment(ctx, run->n_tokens, kv_head, seg, &run->sink);
+            if (pass_cancelled(*pass)) break;                                   // llama_cancel_run reached every run of the pass while it was in flight
+            ok = launch_abort_begin(ctx, pass->id);
+            if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink);
             if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
         }
-        run->segments_run = seg;
+        for (pi_run * r : runs) r->segments_run = seg;
         ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
         full = ok && seg == nseg;
-        if (full) ok = launch_outputs(ctx, run);
+        if (full) for (pi_run * r : runs) ok = launch_outputs(ctx, r) && ok;
+        if (full) { ctx->stat_passes++; ctx->stat_pass_runs += runs.size(); ctx->stat_pass_tokens += (uint64_t) n; if (runs.size() > 1) ctx->stat_coalesced_passes++; }
     }
-    run->launched = ok && full;
-    if (hipEventRecord(run->done, ctx->stream) != hipSuccess) ok = false;
+    for (pi_run * r : runs) {
+        r->launched = ok && full;
+        if (hipEventRecord(r->done, ctx->stream) != hipSuccess) ok = false;
+    }
+    if (ctx->coalesce_max.load() > 1 && ctx->pass_event && hipEventRecord(ctx->pass_event, ctx->stream) == hipSuccess) { ctx->pass_pending = true; ctx->pass_first_id = runs[0]->run_id; }
     if (!ok) {                                                                 // NOT the same thing as a cancelled run: finish reports it (the driver ends the generation)
-        run->failed = true;
+        for (pi_run * r : runs) r->failed = true;
         std::lock_guard<std::mutex> lk(ctx->fmu);
         fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.c_str());
     }
-    run->state.store(2);
+    for (pi_run * r : runs) r->state.store(2);
+}
+// coalescing contexts: the feeder does not run ahead of the GPU across passes, and before it composes the next pass it gives the caller the chance to react to the one
+// that has just finished — cancel what it invalidates, start what follows from it — so that those runs travel together.  Ends at once when the caller is blocked waiting
+// for a run, when it has finished a run of that pass and called start / iprobe since, or after PIPEINFER_REACTION_US (3 ms: a drafted tree of three steps).
+static void wait_for_reaction(llama_context * ctx) {
+    if (!ctx->pass_pending) return;
+    (void) hipEventSynchronize(ctx->pass_event);
+    ctx->pass_pending = false;
+    static const int64_t tmo = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 3000;
+    const int64_t t0 = time_us();
+    for (int spin = 0; ; spin++) {
+        if (ctx->waiters.load() > 0) return;
+        if (ctx->last_finished_id.load() >= ctx->pass_first_id && ctx->caller_epoch.load() > ctx->epoch_after_finish.load()) return;
+        if (time_us() - t0 > tmo) return;
+        { std::lock_guard<std::mutex> lk(ctx->fmu); if (ctx->fstop) return; }
+        if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
 }
 static void feeder_main(llama_context * ctx) {
     (void) hipSetDevice(ctx->model->device);
     while (true) {
-        pi_run * run = nullptr;
         {
             std::unique_lock<std::mutex> lk(ctx->fmu);
             ctx->fcv.wait(lk, [&] { return ctx->fstop || !ctx->fqueue.empty(); });
             if (ctx->fqueue.empty()) return;                                   // fstop and drained
-            run = ctx->fqueue.front(); ctx->fqueue.pop_front();
         }
-        feed_run(ctx, run);
+        const int cmax = ctx->coalesce_max.load();
+        bool coalesce = cmax > 1;
+        if (coalesce && !ctx->pass_event && hipEventCreateWithFlags(&ctx->pass_event, hipEventDisableTiming) != hipSuccess) { ctx->pass_event = nullptr; coalesce = false; }
+        if (coalesce) wait_for_reaction(ctx); else ctx->pass_pending = false;
+        std::vector<std::shared_ptr<pi_pass>> todo;                            // cancelled runs met on the way (no GPU work, events only), then the pass itself
+        {
+            std::lock_guard<std::mutex> lk(ctx->fmu);
+            auto single = [&](pi_run * r) { auto p = std::make_shared<pi_pass>(); p->runs.push_back(r); p->id = r->run_id; p->n_tokens = r->n_tokens; p->n_kv = r->n_kv; r->pass = p; r->row0 = 0; r->pass_leader = true; r->pass_tokens = r->n_tokens; return p; };
+            pi_run * first = ctx->fqueue.front(); ctx->fqueue.pop_front();
+            std::shared_ptr<pi_pass> pass = single(first);
+            if (coalesce && !first->canceled && !first->cancel_req.load()) {
+                std::vector<pi_run *> dropped;
+                while (!ctx->fqueue.empty()) {
+                    pi_run * q = ctx->fqueue.front();
+                    if (q->canceled || q->cancel_req.load()) { ctx->fqueue.pop_front(); dropped.push_back(q); continue; }
+                    if (pass->n_tokens + q->n_tokens > cmax) break;
+                    ctx->fqueue.pop_front();
+                    q->pass = pass; q->row0 = pass->n_tokens; q->pass_leader = false;
+                    pass->runs.push_back(q); pass->n_tokens += q->n_tokens; pass->n_kv = std::max(pass->n_kv, q->n_kv);
+                }
+                for (pi_run * r : pass->runs) r->pass_tokens = pass->n_tokens;
+                for (pi_run * r : dropped) todo.push_back(single(r));
+            }
+            todo.push_back(pass);
+        }
+        for (auto & p : todo) feed_pass(ctx, p);
     }
 }
 
@@ -465,7 +551,14 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     auto give_back = [&]() { ctx->cells->release_cells(kv_head, n_tokens); };
     if (!run) { ctx->last_error = "out of pinned host memory"; give_back(); return nullptr; }
     run->batch_id = batch_in.batch_id; run->n_tokens = n_tokens; run->t_start_us = time_us(); run->sink = nullptr;
-    run->run_id = (++ctx->run_counter) & 0x3fffffff; run->kv_head = kv_head;
+    run->run_id = (++ctx->run_counter) & 0x3fffffff; run->kv_head = kv_head; run->n_kv = n_kv;
+    if (run->pass) {                                                          // the object is about to be recycled: it leaves its pass
+        std::lock_guard<std::mutex> lk(ctx->fmu);
+        auto & v = run->pass->runs;
+        v.erase(std::remove(v.begin(), v.end(), run), v.end());
+        run->pass.reset();
+    } run->row0 = 0; run->pass_leader = true; run->pass_tokens = n_tokens;
+    ctx->caller_epoch.fetch_add(1);
     // (a segmented context's stream belongs to its feeder thread: the begin event is recorded there, in stream order with the run's segments)
     if (!ctx->remote && ctx->seg_layers == 0 && hipEventRecord(run->begin, ctx->stream) != hipSuccess) { ctx->last_error = "hipEventRecord failed"; give_back(); ctx->pool.push_back(run); return nullptr; }
     // which rows phase 1 hands back (llama.cpp:5776-5789): flagged rows, or all with logits_all, or only the last one (stored at row 0)
@@ -505,11 +598,6 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
             }
             ctx->feeder = std::thread(feeder_main, ctx);
         }
-        if (!run->canceled) {
-            ctx->stat_calls++;
-            ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, n_kv);
-            if (n_tokens == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
-        }
         ctx->inflight.push_back(run);
         { std::lock_guard<std::mutex> lk(ctx->fmu); ctx->fqueue.push_back(run); }
         ctx->fcv.notify_one();
@@ -521,9 +609,6 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         if (ok) ok = launch_forward(ctx, n_tokens, run->meta_host, nullptr, &run->sink);
         if (ok) ok = launch_outputs(ctx, run);
         run->launched = ok;
-        ctx->stat_calls++;
-        ctx->stat_alg_bytes += decode_alg_bytes(ctx, n_tokens, n_kv);
-        if (n_tokens == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
     }
     if (ok) ok = hipEventRecord(run->done, ctx->stream) == hipSuccess;
     run->state.store(2);
@@ -542,12 +627,18 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
 
 void context_cancel_run(llama_context * ctx, pi_run * r) {
     if (r->cancel_req.load()) return;
-    // Not handed to the GPU yet: the feeder drops it whole.  Handed over (partly): the kernels of THIS run return on entry from now on — the flag is picked up by the
-    // run's next pi_op_abort_begin, the compare-and-swap hits the run if it is the one executing (kernel granularity, like the reference's poll between graph nodes:
-    // ggml.c:15748-15811); a segmented context also stops launching its remaining segments.
+    // Not handed to the GPU yet: the feeder drops it whole.  Handed over (partly): the kernels of its pass return on entry from now on — the flag is picked up by the
+    // pass's next pi_op_abort_begin, the compare-and-swap hits the pass if it is the one executing (kernel granularity, like the reference's poll between graph nodes:
+    // ggml.c:15748-15811); a segmented context also stops launching its remaining segments.  A pass that carries several runs stops when ALL of them are cancelled.
     r->cancel_req.store(true);
-    if (ctx->abort_host) ctx->abort_host[r->run_id & 255] = 1;
-    if (ctx->abort_dev && ctx->ctl_stream && r->state.load() != 0 && pi_op_abort_cancel(ctx->abort_dev, r->run_id, ctx->ctl_stream) != 0)
+    int32_t id = r->run_id; bool all = true, handed = r->state.load() != 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->fmu);
+        if (r->pass) { id = r->pass->id; all = pass_cancelled(*r->pass); for (const pi_run * q : r->pass->runs) handed = handed || q->state.load() != 0; }
+    }
+    if (!all) return;
+    if (ctx->abort_host) ctx->abort_host[id & 255] = 1;
+    if (ctx->abort_dev && ctx->ctl_stream && handed && pi_op_abort_cancel(ctx->abort_dev, id, ctx->ctl_stream) != 0)
         fprintf(stderr, "llama_cancel_run: %s\n", pi_last_error());
 }
 
@@ -559,6 +650,7 @@ void stage_abort_current(llama_context * ctx) {
 }
 
 bool context_poll_oldest(llama_context * ctx) {
+    ctx->caller_epoch.fetch_add(1);
     if (ctx->inflight.empty()) return false;
     if (ctx->remote) return !ctx->inflight.front()->launched || ctx->remote_ops.poll(ctx->remote_ops.user) != 0;
     static const int64_t dbg_delay_us = getenv("PI_DEBUG_RUN_LATENCY_US") ? atoll(getenv("PI_DEBUG_RUN_LATENCY_US")) : 0;   // tests: pretend every run takes at least this long
@@ -569,6 +661,7 @@ bool context_poll_oldest(llama_context * ctx) {
 
 bool context_wait(llama_context * ctx, pi_run * run) {
     if (ctx->remote) return true;                                             // context_finish blocks in the transport's wait()
+    struct waiting { llama_context * c; waiting(llama_context * c_) : c(c_) { c->waiters.fetch_add(1); c->caller_epoch.fetch_add(1); } ~waiting() { c->waiters.fetch_sub(1); } } w(ctx);
     while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
     return hipEventSynchronize(run->done) == hipSuccess;
 }
@@ -648,8 +741,13 @@ int context_finish(llama_context * ctx, pi_run * run) {
             run->launched = rc == 1;                                          // 0: a stage skipped the run after a cancel
         }
     } else {
-        while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; urgent_end(ctx); return -1; }
+        {
+            struct waiting { llama_context * c; waiting(llama_context * c_) : c(c_) { c->waiters.fetch_add(1); } ~waiting() { c->waiters.fetch_sub(1); } } w(ctx);
+            while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; urgent_end(ctx); return -1; }
+        }
+        if (run->run_id > ctx->last_finished_id.load()) ctx->last_finished_id.store(run->run_id);
+        ctx->epoch_after_finish.store(ctx->caller_epoch.fetch_add(1) + 1);
         urgent_end(ctx);
         if (run->failed) {
             // a launch of this run failed (graph capture, a kernel launch, a copy): that is an error, not a cancelled run — the caller gets -1, the cells
@@ -657,6 +755,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
             { std::lock_guard<std::mutex> lk(ctx->fmu); if (ctx->last_error.empty()) ctx->last_error = "a launch of the run failed"; }
             ctx->cells->release_cells(run->kv_head, run->n_tokens);
             ctx->last_n_tokens = 0;
+            if (run->pass) { std::lock_guard<std::mutex> lk(ctx->fmu); auto & v = run->pass->runs; v.erase(std::remove(v.begin(), v.end(), run), v.end()); run->pass.reset(); }
             for (auto it = ctx->inflight.begin(); it != ctx->inflight.end(); ++it) if (*it == run) { ctx->inflight.erase(it); break; }
             run->finished = true;
             ctx->pool.push_back(run);
@@ -666,7 +765,10 @@ int context_finish(llama_context * ctx, pi_run * run) {
         if (run->canceled || cut) {
             float ms = 0.0f;
             ctx->stat_cancel_runs++;
-            if (!run->canceled) { ctx->stat_cancel_runs_started++; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_cancel_gpu_ms += ms; }
+            if (!run->canceled) {
+                ctx->stat_cancel_runs_started++;                              // (a run that shared its pass with live runs cost nothing of its own: the pass was computed for them)
+                if (run->pass_tokens == run->n_tokens && hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) ctx->stat_cancel_gpu_ms += ms;
+            }
         }
         if (cut) run->launched = false;
     }
@@ -685,7 +787,21 @@ int context_finish(llama_context * ctx, pi_run * run) {
             ctx->last_n_tokens = 0;
         }
     }
-    if (run->launched && !ctx->remote) { float ms = 0.0f; if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n == 1) ctx->stat_gpu_ms_1 += ms; } }
+    if (run->launched && !ctx->remote && run->pass_leader) {
+        // one pass = one decode call of the roofline accounting, whatever the number of runs it carried; the single-token figures count passes of ONE token only
+        const int pn = run->pass_tokens;
+        const int n_kv = run->pass ? std::max(run->n_kv, run->pass->n_kv) : run->n_kv;
+        ctx->stat_calls++; ctx->stat_alg_bytes += decode_alg_bytes(ctx, pn, n_kv);
+        if (pn == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (pn == 1) ctx->stat_gpu_ms_1 += ms; }
+    }
+    if (run->pass) {                                                          // the object is about to be recycled: it leaves its pass
+        std::lock_guard<std::mutex> lk(ctx->fmu);
+        auto & v = run->pass->runs;
+        v.erase(std::remove(v.begin(), v.end(), run), v.end());
+        run->pass.reset();
+    }
     if (run->launched && run->sink && pi_kt_enabled()) pi_kt_accumulate(run->sink, 1);
     const int64_t dt = time_us() - run->t_start_us;
     if (n == 1) { ctx->t_eval_us += dt; ctx->n_eval++; } else { ctx->t_p_eval_us += dt; ctx->n_p_eval += n; }     // llama.cpp:5807-5815

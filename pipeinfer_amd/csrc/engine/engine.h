@@ -64,6 +64,12 @@ struct llama_model {
     size_t stage_weight_bytes(int l0, int l1, bool first, bool last, int n_tok) const;
 };
 
+struct pi_run;
+struct pi_pass {                               // the runs one forward pass of a feeder context carries (usually one; several when the feeder coalesces its queue)
+    std::vector<pi_run *> runs;                // members not yet finished by the caller (a finished run leaves the list under fmu: its object is recycled)
+    int32_t id = 0; int n_tokens = 0, n_kv = 0;
+};
+
 struct pi_run {                                // one llama_start_async_decode .. llama_finish_async_decode
     int32_t batch_id = 0;
     int n_tokens = 0;
@@ -82,6 +88,10 @@ struct pi_run {                                // one llama_start_async_decode .
     std::atomic<int>  state{0};             // 0 queued, 1 being launched, 2 completion event recorded (the run's fields are final)
     std::atomic<bool> cancel_req{false};    // llama_cancel_run after the start: the feeder stops launching its segments
     int segments_run = 0;                   // segments that were launched before a cancel took effect (statistics)
+    std::shared_ptr<pi_pass> pass;          // feeder contexts: the pass that carries this run (assigned under fmu when the feeder takes the run)
+    int row0 = 0;                           // first row of this run inside its pass (logits / top-k rows, token order)
+    bool pass_leader = true;                // the pass's GPU time is accounted to its first run only
+    int pass_tokens = 0, n_kv = 0;          // tokens of the whole pass; cells this run attends over (kv_self.n at its start)
     int32_t run_id = 0;                     // per-context counter: the identity the device-side abort word carries (pi_op_abort_begin / _cancel)
     bool failed = false;                    // a launch of this run failed (distinct from cancelled / cut short): finish reports -1 and gives the cells back
     int kv_head = 0;                        // first cell find_slot allotted (released again when the run failed)
@@ -128,6 +138,18 @@ struct llama_context {
     // every kernel of this context reads abort_dev = (id of the run whose kernels are executing << 1 | aborted) on entry.  A run's launches are preceded, in
     // stream order, by pi_op_abort_begin (which also picks up a cancel that arrived before: abort_host[id & 255], pinned); llama_cancel_run of a run already
     // handed to the GPU sets that flag and enqueues pi_op_abort_cancel on ctl_stream — a compare-and-swap that only hits while that very run is executing.
+    // Run coalescing (pipeinfer_context_set_coalescing): the feeder of a segmented context takes EVERY live run waiting in its queue — up to coalesce_max tokens — into one
+    // forward pass: a multi-token pass streams the stage's weights once, whatever the number of tokens (the matrix-core kernel is flat from 3 to 16), so two queued runs
+    // cost about 1.4x one instead of 2x.  Every token's result is what it would be alone: the kernels are bit-exact at every batch width, a token attends to exactly the
+    // cells of ITS run's mask, and a later run's reads of an earlier run's cells are satisfied inside the pass like causal attention inside any batch (K/V of a layer are
+    // stored for all tokens before that layer's attention).  The feeder does not run ahead of the GPU across passes and gives the caller a short window to react to a
+    // finished pass (cancel / start follow-up runs) before it composes the next one.
+    std::atomic<int> coalesce_max{0};       // may change between generations (the feeder reads it per pass)
+    std::atomic<uint64_t> caller_epoch{0}; std::atomic<int> waiters{0};
+    std::atomic<int32_t> last_finished_id{0}; std::atomic<uint64_t> epoch_after_finish{0};
+    hipEvent_t pass_event = nullptr; bool pass_pending = false; int32_t pass_first_id = 0;      // feeder thread only
+    uint8_t * pass_host[4] = { nullptr, nullptr, nullptr, nullptr }; size_t pass_host_cap = 0; int pass_slot = 0;   // pinned staging blocks of composed passes
+    uint64_t stat_passes = 0, stat_pass_runs = 0, stat_pass_tokens = 0, stat_coalesced_passes = 0;
     int32_t * abort_dev = nullptr; int32_t * abort_host = nullptr; hipStream_t ctl_stream = nullptr; int32_t run_counter = 0;
     std::atomic<int32_t> stage_run_id{0};    // pipeline stages (stage_run): id of the run being computed, 0 between runs (read by the transport's cancel watcher)
     double stat_hop_ms = 0.0;                // pipeline stages: GPU time of the in-stream store of the activations into the next stage's ring

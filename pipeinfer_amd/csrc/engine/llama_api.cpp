@@ -260,6 +260,12 @@ extern "C" int pipeinfer_context_set_segments(struct llama_context * ctx, int la
     return 0;
 }
 
+extern "C" int pipeinfer_context_set_coalescing(struct llama_context * ctx, int max_tokens) {
+    if (ctx->remote) { ctx->last_error = "pipeinfer_context_set_coalescing: a remote head owns no layers"; return -1; }
+    if (max_tokens > 1 && ctx->seg_layers <= 0) { ctx->last_error = "pipeinfer_context_set_coalescing: needs a segmented context (pipeinfer_context_set_segments): the feeder thread composes the passes"; return -1; }
+    ctx->coalesce_max.store(max_tokens > 1 ? std::min(max_tokens, ctx->n_batch) : 0);
+    return 0;
+}
 extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }
 
 extern "C" void pipeinfer_context_set_remote(struct llama_context * ctx, const struct pipeinfer_remote_ops * ops) {
@@ -328,9 +334,10 @@ extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer
     out->kv_bytes_per_cell = (uint64_t) 4 * ctx->model->hparams.n_embd_gqa() * (uint64_t) (ctx->l1 - ctx->l0);
     out->n_segments = ctx->stat_segments; out->n_segments_skipped = ctx->stat_segments_skipped;
     out->n_cancel_runs = ctx->stat_cancel_runs; out->n_cancel_runs_started = ctx->stat_cancel_runs_started; out->cancel_gpu_ms = ctx->stat_cancel_gpu_ms;
+    out->n_passes = ctx->stat_passes; out->n_pass_runs = ctx->stat_pass_runs; out->n_pass_tokens = ctx->stat_pass_tokens; out->n_coalesced_passes = ctx->stat_coalesced_passes;
     out->weight_copy_bytes = ctx->model->hbm_copy_bytes;
 }
-extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; }
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0; }
 
 // ---- stand-alone KV-cell table (host logic tests) ---------------------------------------------------------------------------------
 struct pi_kvcells { pi::kv_cells cells; explicit pi_kvcells(int n) : cells(n) {} };

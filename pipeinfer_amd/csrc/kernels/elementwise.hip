@@ -479,20 +479,20 @@ __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict
                           const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head_,
                           uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc, const int32_t * __restrict__ dyn, const int32_t * __restrict__ abort_w) {
     if (pi_aborted(abort_w)) return;
-    const int kv_head = dyn ? dyn[0] : kv_head_;
     const int t = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;           // i: pair index
+    const int cell = pi_cell_of(dyn, kv_head_, t);
     const int n_embd = n_head * hd, n_gqa = n_head_kv * hd;
     if (hh >= n_head + n_head_kv) {                                         // V: plain f32 -> f16 copy into the cache row
         const int h = hh - n_head - n_head_kv;
         const float * src = v + (int64_t) t * vs + h * hd;
-        uint16_t * dst = vc + (int64_t) (kv_head + t) * n_gqa + h * hd;
+        uint16_t * dst = vc + (int64_t) cell * n_gqa + h * hd;
         dst[2 * i] = pi_f2h(src[2 * i]); dst[2 * i + 1] = pi_f2h(src[2 * i + 1]);
         return;
     }
     const bool is_q = hh < n_head;
     const int h = is_q ? hh : hh - n_head;
     const float * src = is_q ? q + (int64_t) t * qs + h * hd : k + (int64_t) t * ks + h * hd;
-    uint16_t * dst = is_q ? q16 + (int64_t) t * n_embd + h * hd : kc + (int64_t) (kv_head + t) * n_gqa + h * hd;
+    uint16_t * dst = is_q ? q16 + (int64_t) t * n_embd + h * hd : kc + (int64_t) cell * n_gqa + h * hd;
     const float2 c = *(const float2 *) (cs + ((int64_t) pos[t] * (hd / 2) + i) * 2);
     const int i0 = neox ? i : 2 * i, i1 = neox ? i + hd / 2 : 2 * i + 1;
     const float x0 = src[i0], x1 = src[i1];

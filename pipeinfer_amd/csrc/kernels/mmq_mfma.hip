@@ -366,11 +366,10 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         // k_mmvq_kq: rows 2i, 2i+1 of a head are neighbours in this row group; the rounding points are those of k_rope_kv
         __syncthreads();
         if (active) {
-            const int kvh = g.dyn ? g.dyn[0] : g.kv_head;
             if (sg.store == 3) {
                 for (int j = tid_g; j < rows * nt; j += 64 * S) {
                     const int rr = j / nt, t = j % nt;
-                    sg.dst16[(int64_t) (kvh + g.tok0 + t) * sg.stride16 + row0 + rr] = pi_f2h(X[rr * 16 + t]);
+                    sg.dst16[(int64_t) pi_cell_of(g.dyn, g.kv_head, g.tok0 + t) * sg.stride16 + row0 + rr] = pi_f2h(X[rr * 16 + t]);
                 }
             } else {
                 for (int j = tid_g; j < (rows / 2) * nt; j += 64 * S) {
@@ -379,7 +378,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
                     const int64_t rw = row0 + 2 * pr;
                     const int i = (int) (rw % g.hd) >> 1;
                     const float2 cs = *(const float2 *) (g.rope_cs + ((int64_t) g.pos[g.tok0 + t] * (g.hd / 2) + i) * 2);
-                    uint16_t * dd = sg.dst16 + (int64_t) ((sg.store == 2 ? kvh : 0) + g.tok0 + t) * sg.stride16 + rw;
+                    uint16_t * dd = sg.dst16 + (int64_t) (sg.store == 2 ? pi_cell_of(g.dyn, g.kv_head, g.tok0 + t) : g.tok0 + t) * sg.stride16 + rw;
                     dd[0] = pi_f2h(x0 * cs.x - x1 * cs.y);
                     dd[1] = pi_f2h(x0 * cs.y + x1 * cs.x);
                 }

@@ -174,19 +174,19 @@ static __device__ __forceinline__ void kq_load_act(const mmvq_args & g, size_t a
 // ST = 2: decode instance for longer rows — "tile per wave": the workgroup is one row group, wave t takes tile t exactly like the
 // single-tile instance (so every tile of the row is in flight at once and nothing loops), the products meet in LDS and wave 0 runs
 // the ordered chains through the tiles in block order
-template <int TYPE, int NT, int R, int ST>
-__global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
+// LSTR: floats of LDS per wave (== kq_lds<TYPE, NP>::FLOATS, or the larger of two types' when waves of two weight types share a workgroup: k_mmvq_kq2)
+template <int TYPE, int NT, int R, int ST, int LSTR>
+static __device__ __forceinline__ void mmvq_kq_body(const mmvq_args & g, uint8_t * lds) {
     static_assert(ST == 0 || (ST != 0 && NT <= MMVQ_ST_NT), "loop-free instances: decode and small verify batches");
     constexpr bool TPW = ST == 2;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NP = R * NT, NIT = (NP + 7) / 8;
     constexpr int TG = 4;                                                    // tokens whose activations are held in registers at once
     using L = kq_lds<TYPE, NP>;
+    static_assert(LSTR >= L::FLOATS, "LDS stride per wave");
     // the wave index is made a scalar: with it in a VGPR, g.seg[si] turns into per-lane global loads of the kernel arguments — two
     // dependent memory round trips before the first weight load of every wave
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (pi_aborted(g.abort_w)) return;
-    float * xs = (float *) lds + (size_t) wave * L::FLOATS;
+    float * xs = (float *) lds + (size_t) wave * LSTR;
     const int q = lane >> 2, c = lane & 3;                                   // producer role: quad q, accumulator lanes 2c, 2c+1
     const int s = lane >> 3, k = lane & 7;                                   // chain role: pair slot s, accumulator lane k
     const int wave_id = TPW ? (int) blockIdx.x : (int) (blockIdx.x * (blockDim.x >> 6) + wave);   // index of the row group
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
         __syncthreads();
         if (wave != 0) return;
         for (int t = 0, b = 0; b < nb; t++, b += KQ_TB) {
-            const float * xt = (const float *) lds + (size_t) t * L::FLOATS;
+            const float * xt = (const float *) lds + (size_t) t * LSTR;
             if (nb - b >= KQ_TB) chain(xt, KQ_TB, std::true_type{}); else chain(xt, nb - b, std::false_type{});
         }
     } else if constexpr (WIDE) {
@@ -434,11 +434,10 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
         // llm_build_kv_store / ggml_rope mode 0 (llama.cpp:3546-3577, ggml.c:11062-11163) as the epilogue of the projection: rows 2i, 2i+1
         // of a head are neighbours in this wave (R even, row0 multiple of R); the rounding points are those of k_rope_kv
         wave_lds_sync();
-        const int kvh = g.dyn ? g.dyn[0] : g.kv_head;
         if (sg.store == 3) {
             for (int j = lane; j < rows * NT; j += 64) {
                 const int r = j / NT, t = j % NT;
-                sg.dst16[(int64_t) (kvh + g.tok0 + t) * sg.stride16 + row0 + r] = pi_f2h(xs[j]);
+                sg.dst16[(int64_t) pi_cell_of(g.dyn, g.kv_head, g.tok0 + t) * sg.stride16 + row0 + r] = pi_f2h(xs[j]);
             }
         } else {
             for (int j = lane; j < (rows / 2) * NT; j += 64) {
@@ -447,12 +446,35 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
                 const int64_t row = row0 + 2 * pr;
                 const int i = (int) (row % g.hd) >> 1;                       // pair index inside the head
                 const float2 cs = *(const float2 *) (g.rope_cs + ((int64_t) g.pos[g.tok0 + t] * (g.hd / 2) + i) * 2);
-                uint16_t * d = sg.dst16 + (int64_t) ((sg.store == 2 ? kvh : 0) + g.tok0 + t) * sg.stride16 + row;
+                uint16_t * d = sg.dst16 + (int64_t) (sg.store == 2 ? pi_cell_of(g.dyn, g.kv_head, g.tok0 + t) : g.tok0 + t) * sg.stride16 + row;
                 d[0] = pi_f2h(x0 * cs.x - x1 * cs.y);
                 d[1] = pi_f2h(x0 * cs.y + x1 * cs.x);
             }
         }
     }
+}
+
+template <int TYPE, int NT, int R, int ST>
+__global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (pi_aborted(g.abort_w)) return;
+    mmvq_kq_body<TYPE, NT, R, ST, kq_lds<TYPE, R * NT>::FLOATS>(g, lds);
+}
+
+// Two weight types in ONE launch (decode widths): the attention projections of the Q4_K_M / Q5_K_M mixtures keep attn_q / attn_k in Q4_K and put attn_v into Q5_K or
+// Q6_K (llama.cpp:7923-7933) — 1024 rows of the 70B model, a launch of its own that runs at 0.04-0.10 of the HBM peak because it is all launch ramp.  Segments whose bit
+// is set in g.type_b_mask run the TB body, the others the TA body; the choice is uniform per wave (per workgroup in the tile-per-wave instance), both bodies compute
+// exactly what their single-type kernels compute.
+template <int TA, int TB, int NT, int R, int ST>
+__global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq2(const mmvq_args g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (pi_aborted(g.abort_w)) return;
+    constexpr int FA = kq_lds<TA, R * NT>::FLOATS, FB = kq_lds<TB, R * NT>::FLOATS, LSTR = FA > FB ? FA : FB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_id = ST == 2 ? (int) blockIdx.x : (int) (blockIdx.x * (blockDim.x >> 6) + wave);
+    const int si = (wave_id >= g.seg[1].wave0) + (wave_id >= g.seg[2].wave0);
+    if ((g.type_b_mask >> si) & 1) mmvq_kq_body<TB, NT, R, ST, LSTR>(g, lds);
+    else                           mmvq_kq_body<TA, NT, R, ST, LSTR>(g, lds);
 }
 
 // ================================================================================================================
@@ -898,6 +920,45 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
     return 0;
 }
 
+// two weight types in one launch (k_mmvq_kq2): TA = Q4_K, TB = Q5_K or Q6_K, decode widths, rows of one to four tiles.  Same instance choice as launch_mmvq.
+static bool mmvq2_applies(int type_a, int type_b, int nt, int nb) {
+    static const bool off = getenv("PI_MMVQ_NO_MIXED") != nullptr;          // tuning / tests
+    return !off && type_a == PI_Q4_K && (type_b == PI_Q5_K || type_b == PI_Q6_K) && nt >= 1 && nt <= 2 && nb <= 4 * KQ_TB;
+}
+template <int TB, int NT>
+static int launch_mmvq2(mmvq_launch & L, hipStream_t stream) {
+    mmvq_args & g = L.g;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    const bool sample = kt_begin(PI_Q4_K, NT, ea, eb);                      // (statistics: counted with the Q4_K launches, all bytes of the launch)
+    int R = g.K >= 8192 ? 4 : 2;
+    while (R > 1 && L.m_total / R < 2048) R >>= 1;
+    if (R < 2) R = 2;                                                       // (the RoPE epilogue needs both rows of a pair in one wave)
+    int waves = 0;
+    for (int i = 0; i < MMVQ_MAX_SEG; i++) {
+        if (i < L.nseg) { g.seg[i].wave0 = waves; waves += (g.seg[i].M + R - 1) / R; }
+        else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
+    }
+    const int ntiles = (g.nb + KQ_TB - 1) / KQ_TB;
+    auto go = [&](auto rc) {
+        constexpr int RR = decltype(rc)::value;
+        constexpr int FA = kq_lds<PI_Q4_K, RR * NT>::FLOATS, FB = kq_lds<TB, RR * NT>::FLOATS, LSTR = FA > FB ? FA : FB;
+        if (ntiles > 1) {
+            const size_t lds_t = (size_t) ntiles * LSTR * 4;
+            if (sample) hipExtLaunchKernelGGL((k_mmvq_kq2<PI_Q4_K, TB, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
+            else        hipLaunchKernelGGL((k_mmvq_kq2<PI_Q4_K, TB, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);
+        } else {
+            constexpr int wpb = 4;
+            const unsigned grid = (unsigned) ((waves + wpb - 1) / wpb);
+            if (sample) hipExtLaunchKernelGGL((k_mmvq_kq2<PI_Q4_K, TB, NT, RR, 1>), dim3(grid), dim3(64 * wpb), (size_t) wpb * LSTR * 4, stream, ea, eb, 0, g);
+            else        hipLaunchKernelGGL((k_mmvq_kq2<PI_Q4_K, TB, NT, RR, 1>), dim3(grid), dim3(64 * wpb), (size_t) wpb * LSTR * 4, stream, g);
+        }
+    };
+    if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
+    if (sample) kt_end(PI_Q4_K, NT, L, ea, eb);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int TYPE>
 static int dispatch_nt(mmvq_launch & L, int nt, hipStream_t stream) {
     switch (nt) {
@@ -925,8 +986,21 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     const pi_weight * w0 = ws[0];
     const int vdt = pi_vec_dot_type(w0->type);
     if (vdt != PI_Q8_K && vdt != PI_Q8_0 && vdt != PI_Q8_1) { pi_set_error("pi_op_mul_mat: weight type %d has no quantised mat-vec", w0->type); return -1; }
-    for (int i = 1; i < n_w; i++)
-        if (ws[i]->type != w0->type || ws[i]->ne0 != w0->ne0) { pi_set_error("pi_op_mul_mat_multi: weights differ in type or width"); return -1; }
+    // one type per launch — or Q4_K together with Q5_K / Q6_K at decode widths (k_mmvq_kq2)
+    int type_b = -1, type_b_mask = 0;
+    for (int i = 0; i < n_w; i++) {
+        if (ws[i]->ne0 != w0->ne0) { pi_set_error("pi_op_mul_mat_multi: weights differ in width"); return -1; }
+        if (ws[i]->type == PI_Q4_K) continue;
+        if (type_b >= 0 && ws[i]->type != type_b) { type_b = -2; break; }
+        type_b = ws[i]->type; type_b_mask |= 1 << i;
+    }
+    const bool all_b = type_b >= 0 && type_b_mask == (1 << n_w) - 1;            // a single type that is not Q4_K
+    const bool mixed = type_b >= 0 && !all_b;
+    if (type_b == -2 || (mixed && !mmvq2_applies(PI_Q4_K, type_b, n_tok, (int) (w0->ne0 / 256)))) {
+        bool same = true;
+        for (int i = 1; i < n_w; i++) same = same && ws[i]->type == w0->type;
+        if (!same) { pi_set_error("pi_op_mul_mat_multi: weights differ in type (only Q4_K with Q5_K or Q6_K share a launch, at 1-2 tokens)"); return -1; }
+    }
     if (vdt != PI_Q8_K && n_w > 1) {
         for (int i = 0; i < n_w; i++) { const int rc = mul_mat_multi_impl(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, nullptr, stream_); if (rc) return rc; }
         return 0;
@@ -940,7 +1014,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     // (single tokens, types without an MFMA kernel) takes the VALU mat-vec, 8 tokens per pass
     int64_t rows_all = 0;
     for (int i = 0; i < n_w; i++) rows_all += ws[i]->ne1;
-    bool mfma = vdt == PI_Q8_K && pi_mmq_wants(w0->type, n_tok, rows_all);
+    bool mfma = !mixed && vdt == PI_Q8_K && pi_mmq_wants(w0->type, n_tok, rows_all);
     for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
     if (mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
@@ -952,7 +1026,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         L.g.K = (int) K; L.g.nb = (int) nbq;
         L.g.pos = rope ? rope->pos : nullptr; L.g.rope_cs = rope ? rope->cs : nullptr; L.g.dyn = rope ? rope->dyn : nullptr;
         L.g.kv_head = rope ? rope->kv_head : 0; L.g.hd = rope ? rope->hd : 2; L.g.tok0 = t0;
-        L.g.frag = nullptr; L.g.aux = nullptr; L.g.nt = nt; L.g.abort_w = pi_abort_word();
+        L.g.frag = nullptr; L.g.aux = nullptr; L.g.nt = nt; L.g.abort_w = pi_abort_word(); L.g.type_b_mask = mixed ? type_b_mask : 0;
         L.rope = rope != nullptr;
         for (int i = 0; i < n_w; i++) {
             const pi_weight * w = ws[i];
@@ -972,6 +1046,12 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             else { L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr; }
         }
         int rc = -1;
+        if (mixed) {
+            if (type_b == PI_Q5_K) rc = nt == 1 ? launch_mmvq2<PI_Q5_K, 1>(L, stream) : launch_mmvq2<PI_Q5_K, 2>(L, stream);
+            else                   rc = nt == 1 ? launch_mmvq2<PI_Q6_K, 1>(L, stream) : launch_mmvq2<PI_Q6_K, 2>(L, stream);
+            if (rc) return rc;
+            continue;
+        }
         if (mfma) {
             L.g.frag = base + ofa + (size_t) (t0 / 16) * nbq * 8192;
             L.g.aux = base + oax + (size_t) (t0 / 16) * nbq * 1024;
@@ -1033,6 +1113,16 @@ extern "C" int pi_op_mul_mat_qkv_rope(const pi_weight * wq, const pi_weight * wk
     uint16_t * dst[3] = { q16, kc, vc };
     const int stride[3] = { n_head * hd, n_head_kv * hd, n_head_kv * hd };
     bool done[3] = { false, false, false };
+    {   // attn_q / attn_k in Q4_K with attn_v in Q5_K or Q6_K (the Q4_K_M mixture, llama.cpp:7923-7933): ONE launch at decode widths
+        int tb_type = -1, n_a = 0; bool ok2 = true;
+        for (int j = 0; j < 3; j++) { if (ws[j]->type == PI_Q4_K) n_a++; else if (tb_type < 0 || tb_type == ws[j]->type) tb_type = ws[j]->type; else ok2 = false; }
+        if (ok2 && n_a > 0 && n_a < 3 && mmvq2_applies(PI_Q4_K, tb_type, n_tok, (int) (wq->ne0 / 256))) {
+            mmvq_rope r;
+            r.pos = pos; r.cs = tb->cs; r.dyn = dyn_dev; r.kv_head = kv_head; r.hd = hd;
+            for (int j = 0; j < 3; j++) { r.store[j] = store[j]; r.dst16[j] = dst[j]; r.stride16[j] = stride[j]; }
+            return mul_mat_multi_impl(3, ws, q8, n_tok, nullptr, nullptr, &r, stream);
+        }
+    }
     for (int i = 0; i < 3; i++) {
         if (done[i]) continue;
         const pi_weight * gw[3]; mmvq_rope r; int ng = 0;

@@ -31,6 +31,7 @@ struct mmvq_args {
     int kv_head, hd, tok0;
     // multi-token MFMA kernel (mmq_mfma.hip): operand planes of this launch's chunk of <= 16 tokens (pi_q8_frag_layout), tokens in the chunk
     const uint8_t * frag; const uint8_t * aux; int nt;
+    int type_b_mask;            // k_mmvq_kq2 (two weight types in one launch): bit i set <=> segment i is of the second type
     const int32_t * abort_w;    // abort word of the run (pi_device.h), nullable: a kernel whose run has been cancelled returns on entry
     int dbg;                    // tuning only (PI_MMQ_DBG): 1 = skip the arithmetic, 2 = skip the activation staging and its barriers (results are then garbage)
 };

@@ -80,6 +80,10 @@ static __device__ __forceinline__ float pi_wave_max(float v) {
 static __device__ __forceinline__ int pi_abort_peek(const int32_t * w) { return w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
 static __device__ __forceinline__ bool pi_aborted(const int32_t * w) { return (pi_abort_peek(w) & 1) != 0; }
 
+// KV cell of token i of a pass.  dyn (device memory, refreshed per call so that one captured graph serves every call): {kv_head, n_kv, n_tokens, has_table, cell[0..n_tokens)}.
+// A run's tokens sit in consecutive cells from kv_head (find_slot, llama.cpp:1593-1644); a pass that carries several runs at once (context.cpp: coalescing) brings a table.
+static __device__ __forceinline__ int pi_cell_of(const int32_t * dyn, int kv_head, int i) { return dyn ? (dyn[3] ? dyn[4 + i] : dyn[0] + i) : kv_head + i; }
+
 // signed 4 x int8 dot product accumulate: v_dot4c_i32_i8
 static __device__ __forceinline__ int pi_dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 

@@ -49,7 +49,8 @@ class pipeinfer_spec_result(C.Structure):
 class pipeinfer_stats(C.Structure):
     _fields_ = [("n_calls", C.c_uint64), ("gpu_ms", C.c_double), ("alg_bytes", C.c_uint64), ("weight_bytes", C.c_uint64), ("kv_bytes_per_cell", C.c_uint64),
                 ("n_calls_1", C.c_uint64), ("gpu_ms_1", C.c_double), ("alg_bytes_1", C.c_uint64), ("n_segments", C.c_uint64), ("n_segments_skipped", C.c_uint64),
-                ("n_cancel_runs", C.c_uint64), ("n_cancel_runs_started", C.c_uint64), ("cancel_gpu_ms", C.c_double), ("weight_copy_bytes", C.c_uint64)]
+                ("n_cancel_runs", C.c_uint64), ("n_cancel_runs_started", C.c_uint64), ("cancel_gpu_ms", C.c_double),
+                ("n_passes", C.c_uint64), ("n_pass_runs", C.c_uint64), ("n_pass_tokens", C.c_uint64), ("n_coalesced_passes", C.c_uint64), ("weight_copy_bytes", C.c_uint64)]
 
 
 _api = None
@@ -207,6 +208,11 @@ class Context:
     def set_segments(self, layers_per_segment):
         self.lib.pipeinfer_context_set_segments.argtypes = [C.c_void_p, C.c_int]
         if self.lib.pipeinfer_context_set_segments(self.h, int(layers_per_segment)) != 0:
+            raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
+
+    def set_coalescing(self, max_tokens):
+        self.lib.pipeinfer_context_set_coalescing.argtypes = [C.c_void_p, C.c_int]
+        if self.lib.pipeinfer_context_set_coalescing(self.h, int(max_tokens)) != 0:
             raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
 
     def set_graphs(self, enable):

@@ -603,3 +603,85 @@ def test_cancel_after_the_start_stops_the_run_at_kernel_granularity(LL, segments
     print(f"segments={segments}: 12 runs cancelled after their start took {st['cancel_gpu_ms']:.3f} ms of GPU time in all; segments dropped by the feeder: {st['n_segments_skipped']}")
     c.free(); ref.free(); m.free()
 
+
+
+def _coalescing_scenario(LL, model_path, n_ctx, n_batch, seg_layers, rng):
+    """runs started back to back on a coalescing context == the same runs decoded one by one on a plain context, bit for bit.  The batch mixes what the PipeInfer driver
+    keeps queued on one GPU: a 3-token speculative run in its own sequence, the non-speculative run of the canonical sequence, a chained speculative run that ATTENDS to the
+    cells of the first one (an in-pass dependency), and a run that is cancelled before the feeder gets to it."""
+    m = LL.Model(model_path)
+    c, ref = LL.Context(m, n_ctx=n_ctx, n_batch=n_batch), LL.Context(m, n_ctx=n_ctx, n_batch=n_batch)
+    c.set_segments(seg_layers)
+    c.prepare(); ref.prepare()
+    c.set_coalescing(16)
+    nv = m.n_vocab
+    prompt = [int(x) for x in rng.integers(3, nv, 12)]
+    a = c.decode(prompt, list(range(12)), [[0, 1, 2, 3]] * 12); b = ref.decode(prompt, list(range(12)), [[0, 1, 2, 3]] * 12)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    coalesced = 0
+    for rnd in range(6):
+        t = [int(x) for x in rng.integers(3, nv, 9)]
+        p0 = 12 + 4 * rnd
+        runs = [([t[0]], [p0], [[0, 1, 2, 3]], 0),                                       # opens the round: the feeder takes it alone, the others queue up behind it
+                ([t[1], t[2], t[3]], [p0 + 1, p0 + 2, p0 + 3], [[1]] * 3, 11),            # speculative run, sequence 1
+                ([t[4]], [p0 + 1], [[0]], 0),                                              # non-speculative run, canonical sequence
+                ([t[5], t[6]], [p0 + 4, p0 + 5], [[1]] * 2, 12),                          # chained: attends to the cells of the sequence-1 run above
+                ([t[7], t[8]], [p0 + 1, p0 + 2], [[2]] * 2, 13)]                          # cancelled before it starts computing
+        tickets = [c.start(tok, pos, seq, batch_id=bid) for tok, pos, seq, bid in runs]
+        c.cancel([13])
+        got = [None] * 5
+        for i in (0, 1, 2, 3):
+            got[i] = c.finish(tickets[i])
+        assert c.lib.llama_finish_async_decode(c.h, tickets[4][1].c, tickets[4][0]) == 1
+        for i, (tok, pos, seq, bid) in enumerate(runs):
+            want = ref.decode(tok, pos, seq)                                               # one by one, in the same order: same cells
+            if i < 4:
+                assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (rnd, i, float(np.abs(got[i] - want).max()))
+        for x in (c, ref):                                                                # keep the canonical sequence, drop the rest of the round
+            x.seq_rm(1, p0 + 1, -1); x.seq_rm(2, p0 + 1, -1); x.seq_rm(0, p0 + 1, -1); x.seq_rm(3, p0 + 1, -1)
+            x.seq_cp(0, 1, p0, p0 + 1)
+        # top up positions so that the next round continues the canonical sequence
+        for x in (c, ref):
+            y = x.decode([t[1], t[2], t[3]], [p0 + 1, p0 + 2, p0 + 3], [[0, 1, 2, 3]] * 3)
+        coalesced = c.stats()["n_coalesced_passes"]
+    st = c.stats()
+    c.free(); ref.free(); m.free()
+    return st
+
+
+def test_coalesced_runs_equal_runs_decoded_one_by_one(LL):
+    st = _coalescing_scenario(LL, os.path.join(GOLD, "tiny_llama_b_q4_k_m.gguf"), 256, 64, 1, np.random.default_rng(3))
+    print("tiny:", {k: st[k] for k in ("n_passes", "n_pass_runs", "n_pass_tokens", "n_coalesced_passes", "n_cancel_runs")})
+    assert st["n_coalesced_passes"] >= 3 and st["n_pass_runs"] > st["n_passes"]
+
+
+@pytest.mark.parametrize("workload", ["70b", "7b"])
+def test_coalesced_runs_equal_single_runs_at_full_size_shapes(LL, workload):
+    """the same at the shapes of the bench target (Llama-2-70B Q4_K_M cut to 4 layers: GQA 64/8, K = 8192 / 28672, Q4_K + Q5_K / Q6_K attention projections in one launch,
+    4..9-token passes on the matrix-core kernel) and of BASELINE configs[1] (7B shapes, 4 layers)"""
+    import bench as B
+    tspec, tft, _, _ = B.WORKLOADS[workload]
+    path = B.ensure_model(os.environ.get("PIPEINFER_CACHE", "/tmp/pipeinfer_models"), tspec, tft, 0x5EED, 1.0, 0.25, layers=(8, 4))
+    st = _coalescing_scenario(LL, path, 512, 64, 2, np.random.default_rng(5))
+    print(workload, {k: st[k] for k in ("n_passes", "n_pass_runs", "n_pass_tokens", "n_coalesced_passes")})
+    assert st["n_coalesced_passes"] >= 3
+
+
+@pytest.mark.parametrize("tgt,dft", [("tiny_llama_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0"), ("tiny_llama_q3_k_m", "tiny_llama_q4_0")])
+@pytest.mark.parametrize("n_draft,n_parallel,p_split,min_spec", [(3, 3, 0.9, 0), (3, 3, 0.9, 1), (8, 1, 0.9, 2), (4, 3, 0.05, 3)])
+def test_pipeinfer_driver_is_lossless_with_run_coalescing(LL, tgt, dft, n_draft, n_parallel, p_split, min_spec):
+    """the driver's accepted tokens stay the reference target's greedy continuation when the target's feeder carries the runs waiting in its queue together"""
+    prompt, want = greedy_reference(tgt, 8, 24)
+    mt, md = LL.Model(os.path.join(GOLD, tgt + ".gguf")), LL.Model(os.path.join(GOLD, dft + ".gguf"))
+    ct, cd = LL.Context(mt, n_ctx=256, n_batch=64), LL.Context(md, n_ctx=256, n_batch=64)
+    ct.set_segments(1); cd.set_priority(1)
+    ct.prepare(); cd.prepare()
+    ct.set_coalescing(16)
+    out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=p_split, ignore_eos=0, min_spec_iters=min_spec)
+    assert out[:24] == want, (out, want, res)
+    st = ct.stats()
+    print(tgt, dft, {k: res[k] for k in ("n_accept_clean", "n_runs_spec", "n_runs_nonspec", "n_runs_canceled")}, {k: st[k] for k in ("n_passes", "n_pass_runs", "n_coalesced_passes")})
+    for c in (ct, cd):
+        c.free()
+    for m in (mt, md):
+        m.free()

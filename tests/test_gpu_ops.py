@@ -325,8 +325,9 @@ def test_topk(gpu, n_vocab):
         assert abs(gs[t] - want) / want < 1e-5
     assert gi[1, 0] == 7 and gi[1, 1] == 100
     # ... and against the oracle's restatement of llama_sample_softmax (llama.cpp:7019-7046: sorted by logit, p = expf(l - max) / sum over the FULL vocabulary in fp32) and of
-    # llama_sample_token_greedy (:7496-7510: the first maximum): ids and logits exactly; probabilities to 1e-5 relative — the reference adds its 32 000 exponentials in
-    # sorted order in fp32, the device in chunk order (the driver compares p with the thresholds p_accept / p_split only)
+    # llama_sample_token_greedy (:7496-7510: the first maximum): ids and logits exactly; probabilities to 2e-4 relative — the reference adds its 32 000 / 65 024 exponentials
+    # one after the other in fp32 (sorted order; measured 7e-5 off the exact sum at 32 000 terms), the device adds them pairwise per chunk (the driver only compares p with
+    # the thresholds p_accept / p_split)
     o = O.oracle()
     for t in range(3):
         oi, ol, op = np.zeros(8, np.int32), np.zeros(8, np.float32), np.zeros(8, np.float32)
@@ -335,7 +336,7 @@ def test_topk(gpu, n_vocab):
         assert list(gi[t]) == list(oi) and np.array_equal(gv[t], ol)
         assert gi[t, 0] == o.o_argmax(row.ctypes.data, n_vocab)
         p_dev = np.exp(gv[t] - gv[t, 0]) / gs[t]
-        assert np.all(np.abs(p_dev - op) <= 1e-5 * op + 1e-12), (p_dev, op)
+        assert np.all(np.abs(p_dev - op) <= 2e-4 * op + 1e-12), (p_dev, op)
 
 
 @pytest.mark.parametrize("vdt,n", [(O.Q8_K, 256), (O.Q8_K, 4096), (O.Q8_K, 8192), (O.Q8_K, 11008), (O.Q8_0, 4544), (O.Q8_0, 256), (O.Q8_0, 18176)])
@@ -434,6 +435,57 @@ def test_qkv_rope_epilogue_equals_separate_launches(gpu, types, hd, n_head, n_he
             L.check(lib.pi_op_mul_mat_qkv_rope(ws[0], ws[1], ws[2], q8.ptr, n_tok, pd.ptr, table, hd, n_head, n_head_kv, -1, dyn.ptr, q16.ptr, kc.ptr, vc.ptr, None))
         else:
             L.check(lib.pi_op_rope_kv_store(qf.ptr, kf.ptr, vf.ptr, n_embd, n_gqa, n_gqa, pd.ptr, table, 0, hd, n_head, n_head_kv, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
+        lib.pi_device_sync()
+        res.append((q16.get(np.uint16), kc.get(np.uint16), vc.get(np.uint16)))
+    for a, b, name in zip(res[0], res[1], "qkv"):
+        assert np.array_equal(a, b), name
+    assert res[0][1].any() and res[0][2].any()
+    lib.pi_rope_table_free(table)
+    for w in ws:
+        lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("types", [(O.Q4_K, O.Q4_K, O.Q5_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q4_K, O.Q6_K, O.Q6_K), (O.Q5_K, O.Q4_K, O.Q4_K)])
+@pytest.mark.parametrize("k,n_tok", [(2048, 1), (4096, 1), (4096, 2), (8192, 1), (8192, 2), (5120, 1), (16384, 2)])
+def test_two_weight_types_share_one_launch(gpu, types, k, n_tok):
+    """attn_q / attn_k in Q4_K with attn_v in Q5_K or Q6_K — the Q4_K_M mixture (llama.cpp:7923-7933) — go out as ONE launch at decode widths (k_mmvq_kq2: the segment's
+    type is chosen per wave / per workgroup); the bits are those of the oracle's vec_dot per matrix, RoPE and the cache writes those of the separate operators.
+    Rows of one tile (K <= 4096), of two to four tiles (the tile-per-wave instance) and a ragged last tile (K = 5120)."""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    rng = np.random.default_rng(k + n_tok)
+    hd, n_head, n_head_kv, n_ctx, kv_head = 128, 6, 2, 24, 7
+    n_embd, n_gqa = n_head * hd, n_head_kv * hd
+    ws, blocks = [], []
+    for t, m in zip(types, (n_embd, n_gqa, n_gqa)):
+        b = synth.random_blocks(t, m * k, rng, 0.05).reshape(m, -1)
+        blocks.append(b)
+        ws.append(upload_weight(lib, t, m, k, b))
+    assert lib.pi_op_mul_mat_qkv_rope_ok(ws[0], ws[1], ws[2], 0, hd) == 1
+    act = rng.standard_normal((n_tok, k)).astype(np.float32)
+    pos = rng.integers(0, 200, n_tok).astype(np.int32)
+    table = lib.pi_rope_table_create(256, hd, 10000.0, 1.0, 0)
+    xd, pd = U.Dev(act), U.Dev(pos)
+    q8 = U.Dev(nbytes=lib.pi_q8_nbytes(O.Q8_K, k, n_tok))
+    L.check(lib.pi_op_quantize(O.Q8_K, xd.ptr, k, n_tok, q8.ptr, None))
+    # (1) plain multi launch with fp32 outputs: every matrix equals the oracle bit for bit
+    outs = [U.Dev(nbytes=4 * n_tok * m) for m in (n_embd, n_gqa, n_gqa)]
+    wl = (C.c_void_p * 3)(*ws); ol = (C.c_void_p * 3)(*[o.ptr for o in outs])
+    L.check(lib.pi_op_mul_mat_multi(3, wl, q8.ptr, n_tok, ol, None, None))
+    o = O.Impl("oracle")
+    for t, m, b, dv in zip(types, (n_embd, n_gqa, n_gqa), blocks, outs):
+        want = o.mul_mat(t, b, k, m, act)
+        got = dv.get(np.float32, (n_tok, m))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (O.TYPE_NAMES[t], float(np.abs(got - want).max()))
+    # (2) with the RoPE / KV-store epilogue == the separate operators on those fp32 outputs
+    dyn = U.Dev(np.array([kv_head, 32, n_tok, 0], np.int32))
+    res = []
+    for fused in (False, True):
+        q16 = U.Dev(np.zeros(n_tok * n_embd, np.uint16)); kc = U.Dev(np.zeros(n_ctx * n_gqa, np.uint16)); vc = U.Dev(np.zeros(n_ctx * n_gqa, np.uint16))
+        if fused:
+            L.check(lib.pi_op_mul_mat_qkv_rope(ws[0], ws[1], ws[2], q8.ptr, n_tok, pd.ptr, table, hd, n_head, n_head_kv, -1, dyn.ptr, q16.ptr, kc.ptr, vc.ptr, None))
+        else:
+            L.check(lib.pi_op_rope_kv_store(outs[0].ptr, outs[1].ptr, outs[2].ptr, n_embd, n_gqa, n_gqa, pd.ptr, table, 0, hd, n_head, n_head_kv, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
         lib.pi_device_sync()
         res.append((q16.get(np.uint16), kc.get(np.uint16), vc.get(np.uint16)))
     for a, b, name in zip(res[0], res[1], "qkv"):
