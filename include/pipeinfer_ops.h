@@ -113,8 +113,13 @@ PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const f
  * captured HIP graph can be replayed for every call (n_kv then only sizes LDS and the mask row stride). */
 PI_API int pi_op_attention(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
                            int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, const int32_t * dyn_dev, void * stream);
+/* the same for a pass that may carry several runs (per_token_kv != 0): dyn_dev = {kv_head, n_kv of the widest run, n_tok, has_table, cell[n_tok], n_kv[n_tok]}; with
+ * has_table set every token attends over the n_kv of ITS run (kv_self.n at that run's start, llama.cpp:5571) */
+PI_API int pi_op_attention_ex(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
+                              int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, const int32_t * dyn_dev, int per_token_kv, void * stream);
 PI_API int pi_op_mmq_min_tokens(void);                             /* narrowest batch that pi_op_mul_mat sends to the matrix-core kernel (and its tile-major weight copies) */
 PI_API int pi_op_mul_mat_reserve(void);                            /* once per process, outside graph capture: dynamic-LDS limits of the matrix-core kernels */
+PI_API int pi_op_attention_max_cells(void);                       /* longest context the attention kernel serves (one score row per workgroup in LDS): 36 200 cells */
 PI_API int pi_op_attention_reserve(int head_dim, int n_kv_max);   /* once per context, outside graph capture: LDS limit for long contexts */
 PI_API int pi_op_silu_mul(const float * gate_dev, const float * up_dev, float * out_dev, int64_t n, void * stream);
 PI_API int pi_op_gelu(const float * x_dev, float * out_dev, int64_t n, void * stream);

@@ -105,7 +105,7 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     if (!(ctx->x = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->x2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->nx = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->nx2 = (float *) dev((size_t) 4 * nb * n_embd)) || !(ctx->qkv = (float *) dev((size_t) 4 * nb * qkv_w)) || !(ctx->att = (float *) dev((size_t) 4 * nb * n_embd)) ||
         !(ctx->up = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->gate = (float *) dev((size_t) 4 * nb * n_ff)) || !(ctx->q16 = (uint16_t *) dev((size_t) 2 * nb * n_embd)) ||
-        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev((size_t) 4 * (4 + nb))))
+        !(ctx->q8a = dev(q8_bytes)) || !(ctx->q8b = dev(q8_bytes)) || !(ctx->q8c = dev(q8_bytes)) || !(ctx->tokens_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->pos_dev = (int32_t *) dev((size_t) 4 * nb)) || !(ctx->dyn_dev = (int32_t *) dev((size_t) 4 * (4 + 2 * nb))))
         return false;
     {   // abort word + cancel flags + the control stream cancels travel on (highest priority: a cancel must not queue behind the run it stops)
         int lo = 0, hi = 0;
@@ -197,7 +197,7 @@ static bool mul_mat_grouped(int n, const pi_weight * const * ws, const void * co
 }
 
 // layers [la, lb) of this stage; `head`: the embedding lookup goes first, `tail`: final norm + lm_head + top-k go last
-static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int la, int lb, bool head, bool tail) {
+static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int la, int lb, bool head, bool tail, bool multi = false) {
     llama_model * m = ctx->model;
     const pi_hparams & hp = m->hparams;
     const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, hd = hp.head_dim();
@@ -227,7 +227,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
                 trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
                 OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             }
-            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, s));
+            OP_OK(pi_op_attention_ex(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, multi ? 1 : 0, s));
             trace(ctx, "att", il, ctx->att, n_embd, n_tok);
             OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
             OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, x, s));                                                   // ffn_inp = wo.att + inpSA
@@ -255,7 +255,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
             OP_OK(pi_op_rope_kv_store(ctx->qkv, ctx->qkv + n_embd, ctx->qkv + n_embd + n_gqa, qw, qw, qw, ctx->pos_dev, ctx->rope, 1, hd, hp.n_head, hp.n_head_kv,
                                       n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             trace(ctx, "q", il, ctx->qkv, n_embd, n_tok, qw); trace(ctx, "k", il, ctx->qkv + n_embd, n_gqa, n_tok, qw); trace(ctx, "v", il, ctx->qkv + n_embd + n_gqa, n_gqa, n_tok, qw);
-            OP_OK(pi_op_attention(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, s));
+            OP_OK(pi_op_attention_ex(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, multi ? 1 : 0, s));
             trace(ctx, "att", il, ctx->att, n_embd, n_tok);
             OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
             OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, nullptr, s));                                             // ffn_inp = attention output
@@ -285,9 +285,9 @@ static int n_segments(const llama_context * ctx) {
 // x_in (device, [n_tokens][n_embd]) replaces the embedding lookup on stages after the first
 static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, const float * x_in) {
     const int words = (ctx->n_ctx + 31) / 32;
-    // block: tokens[n] | pos[n] | {kv_head, n_kv, n, has_table} | (cell[n] when has_table: a pass that carries several runs) | mask[n][words]
+    // block: tokens[n] | pos[n] | {kv_head, n_kv, n, has_table} | (cell[n], n_kv[n] when has_table: a pass that carries several runs) | mask[n][words]
     const int32_t * h_tok = (const int32_t *) meta, * h_pos = h_tok + n_tokens, * h_dyn = h_pos + n_tokens;
-    const size_t n_table = h_dyn[3] ? (size_t) n_tokens : 0;
+    const size_t n_table = h_dyn[3] ? (size_t) 2 * n_tokens : 0;
     const uint32_t * h_mask = (const uint32_t *) (h_dyn + 4 + n_table);
     hipStream_t s = ctx->stream;
     bool ok = hipMemcpyAsync(ctx->tokens_dev, h_tok, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
@@ -308,7 +308,7 @@ static bool launch_abort_begin(llama_context * ctx, int32_t run_id) {
 }
 // segment `seg` of the forward pass: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device memory that
 // launch_inputs refreshed, so replaying the captured graph IS this call's segment
-static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out) {
+static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out, bool multi = false, bool capture_only = false) {
     const bool tracing = trace_enabled();
     const int nseg = n_segments(ctx);
     const int la = ctx->seg_layers > 0 ? ctx->l0 + seg * ctx->seg_layers : ctx->l0;
@@ -316,7 +316,7 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
     const bool head = seg == 0, tail = seg == nseg - 1;
     hipStream_t s = ctx->stream;
     if (ctx->use_graphs && !tracing) {
-        llama_context::graph_entry & ge = ctx->graphs[std::make_pair(n_tokens, seg)];
+        llama_context::graph_entry & ge = ctx->graphs[std::make_pair(n_tokens, 2 * seg + (multi ? 1 : 0))];     // (passes of several runs: their own graphs — per-token n_kv in the attention launches)
         bool ok = true;
         if (!ge.exec) {
             // One capture at a time in the process, and a few attempts: on this runtime a capture (thread-local mode) is now and then invalidated by what ANOTHER
@@ -333,23 +333,24 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
                     pi_kt_set_sink(&ge.sink);                      // launch counts are part of the graph; they are only read while timing is on
                     if (attempt) { ge.sink.samples.clear(); ge.sink.launches.clear(); }
                     pi_set_abort_word(abort_checks_on() ? ctx->abort_dev : nullptr);      // the captured kernels carry the context's abort word
-                    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+                    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail, multi);
                     pi_set_abort_word(nullptr);
                     pi_kt_set_sink(nullptr);
                     ok = hipStreamEndCapture(s, &graph) == hipSuccess && fwd && graph != nullptr;
                 }
                 if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
                 if (graph) (void) hipGraphDestroy(graph);
-                if (!ok) ge.exec = nullptr;
+                if (!ok) { ge.exec = nullptr; fprintf(stderr, "llama_decode: graph capture of %d token(s), segment %d, attempt %d failed (%s): %s\n", n_tokens, seg, attempt, hipGetErrorString(hipGetLastError()), ctx->last_error.c_str()); }
             }
             if (!ok) ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error;
         }
-        if (ok) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
+        if (ok && !capture_only) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
         if (ok && sink_out && seg == 0) *sink_out = &ge.sink;
         return ok;
     }
+    if (capture_only) return true;
     pi_set_abort_word(abort_checks_on() ? ctx->abort_dev : nullptr);
-    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail);
+    const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail, multi);
     pi_set_abort_word(nullptr);
     return fwd;
 }
@@ -404,22 +405,22 @@ static bool pass_cancelled(const pi_pass & p) {
 // (cells past a run's own n_kv are masked for its tokens and contribute exact zeros, like every masked cell inside it)
 static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
     const int n = pass.n_tokens, words = (ctx->n_ctx + 31) / 32;
-    const size_t need = (size_t) n * 8 + 16 + (size_t) n * 4 + (size_t) n * words * 4;
+    const size_t need = (size_t) n * 8 + 16 + (size_t) n * 8 + (size_t) n * words * 4;
     if (need > ctx->pass_host_cap) {
-        const size_t cap = std::max(need, (size_t) std::max(ctx->coalesce_max.load(), 1) * (12 + (size_t) words * 4) + 16);
+        const size_t cap = std::max(need, (size_t) std::max(ctx->coalesce_max.load(), 1) * (16 + (size_t) words * 4) + 16);
         for (uint8_t *& b : ctx->pass_host) { if (b) (void) hipHostFree(b); b = nullptr; }
         (void) hipStreamSynchronize(ctx->stream);
         for (uint8_t *& b : ctx->pass_host) if (hipHostMalloc((void **) &b, cap, hipHostMallocDefault) != hipSuccess) { b = nullptr; ctx->last_error = "out of pinned host memory (pass staging)"; return nullptr; }
         ctx->pass_host_cap = cap;
     }
     uint8_t * blk = ctx->pass_host[ctx->pass_slot++ & 3];
-    int32_t * tok = (int32_t *) blk, * pos = tok + n, * dyn = pos + n, * cell = dyn + 4; uint32_t * mask = (uint32_t *) (cell + n);
+    int32_t * tok = (int32_t *) blk, * pos = tok + n, * dyn = pos + n, * cell = dyn + 4, * nkv = cell + n; uint32_t * mask = (uint32_t *) (nkv + n);
     int at = 0, n_kv = 0;
     for (const pi_run * r : pass.runs) {
         const int m = r->n_tokens;
         const int32_t * rt = (const int32_t *) r->meta_host, * rp = rt + m, * rd = rp + m; const uint32_t * rm = (const uint32_t *) (rd + 4);
         memcpy(tok + at, rt, (size_t) 4 * m); memcpy(pos + at, rp, (size_t) 4 * m);
-        for (int i = 0; i < m; i++) cell[at + i] = rd[0] + i;
+        for (int i = 0; i < m; i++) { cell[at + i] = rd[0] + i; nkv[at + i] = rd[1]; }
         memcpy(mask + (size_t) at * words, rm, (size_t) 4 * m * words);
         n_kv = std::max(n_kv, (int) rd[1]);
         at += m;
@@ -446,7 +447,7 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
             yield_to_urgent(ctx);
             if (pass_cancelled(*pass)) break;                                   // llama_cancel_run reached every run of the pass while it was in flight
             ok = launch_abort_begin(ctx, pass->id);
-            if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink);
+            if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink, runs.size() > 1);
             if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
         }
         for (pi_run * r : runs) r->segments_run = seg;
@@ -623,6 +624,22 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     ctx->inflight.push_back(run);
     rc = 0;
     return run;
+}
+
+// captures the graphs of every pass width up to max_tokens NOW, on the calling thread, while nothing else uses the context: a graph captured later, by the feeder in the
+// middle of a generation, competes with the caller's own launches (draft runs, cancels) — on this runtime a capture is now and then invalidated by them
+bool context_precapture(llama_context * ctx, int max_tokens) {
+    if (!ctx->prepared || !ctx->use_graphs || trace_enabled() || ctx->remote) return true;
+    { std::lock_guard<std::mutex> lk(ctx->fmu); if (!ctx->fqueue.empty()) return true; }
+    if (!ctx->inflight.empty()) return true;
+    const int nseg = n_segments(ctx);
+    for (int n = 1; n <= std::min(max_tokens, ctx->n_batch); n++)
+        for (int multi = 0; multi < 2; multi++) {
+            if (multi && n < 2) continue;
+            for (int seg = 0; seg < nseg; seg++)
+                if (!launch_segment(ctx, n, 0, seg, nullptr, multi != 0, true)) return false;
+        }
+    return hipStreamSynchronize(ctx->stream) == hipSuccess;
 }
 
 void context_cancel_run(llama_context * ctx, pi_run * r) {

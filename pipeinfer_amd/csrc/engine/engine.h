@@ -182,6 +182,7 @@ bool context_prepare(llama_context * ctx, std::string & err);          // upload
 pi_run * context_start(llama_context * ctx, const llama_batch & batch, int & rc);   // rc: 0 ok, 1 no slot, <0 error
 int  context_finish(llama_context * ctx, pi_run * run);
 bool context_poll_oldest(llama_context * ctx);
+bool context_precapture(llama_context * ctx, int max_tokens);             // captures the graphs of passes of 1..max_tokens tokens now (idle context, calling thread)
 void context_cancel_run(llama_context * ctx, pi_run * run);              // stops a started run: unlaunched segments are dropped, kernels already enqueued return on entry (abort word)
 void urgent_drop_all(llama_context * ctx);                                  // the context gives up its claim on the device arbiter (destructor, priority change)
 bool context_wait(llama_context * ctx, pi_run * run);                    // blocks until the run's results are in host memory

@@ -37,14 +37,11 @@ extern "C" struct llama_context * llama_new_context_with_model(struct llama_mode
     ctx->model = model;
     ctx->cparams = params;
     ctx->n_ctx = params.n_ctx == 0 ? model->hparams.n_ctx_train : (int) params.n_ctx;       // llama.cpp:8726
-    {   // the attention kernel keeps 8 score rows of n_ctx floats (+ the visibility words) in LDS: say so HERE, not at the first decode
-        const size_t att_lds = (size_t) 8 * ((size_t) ctx->n_ctx + ((size_t) ctx->n_ctx + 31) / 32) * sizeof(float);
-        if (att_lds > 156 * 1024) {
-            fprintf(stderr, "llama_new_context_with_model: n_ctx = %d is beyond this engine's attention kernel (score rows in LDS: %zu B > 156 KiB, n_ctx <= 4840)%s\n",
-                    ctx->n_ctx, att_lds, params.n_ctx == 0 ? "; pass an explicit n_ctx (0 selected the model's training context)" : "");
-            delete ctx;
-            return nullptr;
-        }
+    if (ctx->n_ctx > pi_op_attention_max_cells()) {   // the attention kernel keeps a workgroup's score rows in LDS (8 rows up to 4 840 cells ... one row up to 36 200): say so HERE, not at the first decode
+        fprintf(stderr, "llama_new_context_with_model: n_ctx = %d is beyond this engine's attention kernel (one score row of n_ctx floats must fit 146 KiB of LDS: n_ctx <= %d)%s\n",
+                ctx->n_ctx, pi_op_attention_max_cells(), params.n_ctx == 0 ? "; pass an explicit n_ctx (0 selected the model's training context)" : "");
+        delete ctx;
+        return nullptr;
     }
     ctx->n_batch = (int) std::max<uint32_t>(params.n_batch, 1);
     ctx->l0 = 0; ctx->l1 = model->hparams.n_layer; ctx->is_first = ctx->is_last = true;
@@ -264,6 +261,7 @@ extern "C" int pipeinfer_context_set_coalescing(struct llama_context * ctx, int 
     if (ctx->remote) { ctx->last_error = "pipeinfer_context_set_coalescing: a remote head owns no layers"; return -1; }
     if (max_tokens > 1 && ctx->seg_layers <= 0) { ctx->last_error = "pipeinfer_context_set_coalescing: needs a segmented context (pipeinfer_context_set_segments): the feeder thread composes the passes"; return -1; }
     ctx->coalesce_max.store(max_tokens > 1 ? std::min(max_tokens, ctx->n_batch) : 0);
+    if (max_tokens > 1 && !pi::context_precapture(ctx, std::min(max_tokens, ctx->n_batch))) { ctx->coalesce_max.store(0); return -1; }
     return 0;
 }
 extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }

@@ -37,6 +37,7 @@ struct att_args {
     float scale;
     const int32_t * dyn;                                    // optional {kv_head, n_kv} in device memory: lets one captured graph serve every call
     const int32_t * abort_w;                                // abort word of the run (pi_device.h), nullable
+    int per_token;                                          // the pass may carry several runs: dyn = {.., n_kv of the widest, n, has_table, cell[n], n_kv[n]} and a workgroup's rows belong to ONE token
 };
 
 // x[i] + x[i + n] inside a row of 16 lanes (lanes whose partner is outside read 0 and are not used)
@@ -58,9 +59,11 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     if (pi_aborted(ga.abort_w)) return;
     att_args g = ga;
     const int s_stride = ga.n_kv;                           // LDS rows keep the static stride
-    if (ga.dyn) g.n_kv = ga.dyn[1];
     const int hk = blockIdx.x, chunk = blockIdx.y;
     const int r = g.n_head / g.n_head_kv;                   // query heads per kv head (broadcast rule i02 = i12 / r2, ggml.c:9425)
+    // kv_self.n of the run this workgroup's token belongs to (llama.cpp:5571): the reference's vec_dot_f16 sums the last n % 32 cells apart, in double, so every token
+    // must see exactly the n its own run was started with — a pass that carries several runs brings one n per token (the launcher keeps a workgroup inside one token)
+    if (ga.dyn) g.n_kv = (ga.per_token && ga.dyn[3]) ? ga.dyn[4 + ga.dyn[2] + (chunk * RW) / r] : ga.dyn[1];
     const int n_rows_total = g.n_tok * r;
     const int row0 = chunk * RW;
     const int n_rows = min(RW, n_rows_total - row0);
@@ -307,13 +310,19 @@ template <int HD, int RW> static int att_set_lds(size_t lds) {
     PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<HD, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     return 0;
 }
+// LDS a workgroup of rw rows needs for contexts of n_kv cells (score rows + visibility words); the single-row instance also has 8 KiB of static LDS
+static size_t att_lds_bytes(int rw, int n_kv) { return (size_t) rw * ((size_t) n_kv + ((size_t) n_kv + 31) / 32) * sizeof(float); }
+static size_t att_lds_cap(int rw) { return (size_t) (rw == 1 ? 146 : 156) * 1024; }
+// Long contexts: the score rows of a workgroup live in LDS, so the rows per workgroup shrink as the context grows — 8 rows up to 4 840 cells, 4 up to 9 680, 2 up to
+// 19 360, one row up to 36 200 (the reference has no bound, llama.cpp:8729-8748; K/V are then re-read from L2 by more workgroups, nothing else changes).
+extern "C" int pi_op_attention_max_cells(void) { int n = 36200; while (att_lds_bytes(1, n) > att_lds_cap(1)) n--; return n; }
 extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
-    const size_t lds = (size_t) ATT_ROWS * (n_kv_max + (n_kv_max + 31) / 32) * sizeof(float);
-    if (lds > 156 * 1024) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS (> 156 KiB)", n_kv_max, lds); return -1; }
-    if (lds <= 60 * 1024) return 0;
+    if (att_lds_bytes(1, n_kv_max) > att_lds_cap(1)) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS for ONE score row (> 146 KiB): contexts beyond %d cells are not supported", n_kv_max, att_lds_bytes(1, n_kv_max), pi_op_attention_max_cells()); return -1; }
+    if (att_lds_bytes(ATT_ROWS, n_kv_max) <= 60 * 1024) return 0;
     int rc = 0;
-    if (hd == 128) rc = att_set_lds<128, 1>(lds / 8) | att_set_lds<128, 2>(lds / 4) | att_set_lds<128, 4>(lds / 2) | att_set_lds<128, 8>(lds);
-    else           rc = att_set_lds<64, 1>(lds / 8) | att_set_lds<64, 2>(lds / 4) | att_set_lds<64, 4>(lds / 2) | att_set_lds<64, 8>(lds);
+    auto want = [&](int rw) { const size_t b = att_lds_bytes(rw, n_kv_max), cap = att_lds_cap(rw); return b < cap ? b : cap; };
+    if (hd == 128) rc = att_set_lds<128, 1>(want(1)) | att_set_lds<128, 2>(want(2)) | att_set_lds<128, 4>(want(4)) | att_set_lds<128, 8>(want(8));
+    else           rc = att_set_lds<64, 1>(want(1)) | att_set_lds<64, 2>(want(2)) | att_set_lds<64, 4>(want(4)) | att_set_lds<64, 8>(want(8));
     return rc;
 }
 
@@ -331,13 +340,17 @@ static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream)
 
 extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
                                int n_tok, int n_kv, float * out, const int32_t * dyn_dev, void * stream) {
+    return pi_op_attention_ex(q16, kc, vc, mask, hd, n_head, n_head_kv, n_tok, n_kv, out, dyn_dev, 0, stream);
+}
+extern "C" int pi_op_attention_ex(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
+                                  int n_tok, int n_kv, float * out, const int32_t * dyn_dev, int per_token_kv, void * stream) {
     if (n_tok <= 0) return 0;
     att_args g;
     g.q16 = q16; g.kc = kc; g.vc = vc; g.mask = mask; g.out = out;
     g.n_head = n_head; g.n_head_kv = n_head_kv; g.n_tok = n_tok; g.n_kv = n_kv; g.mask_words = (n_kv + 31) / 32;
     g.exp_tab = pi_get_tables().exp_f16;
     g.scale = 1.0f / sqrtf((float) hd);                      // KQ_scale, llama.cpp:5189-5193
-    g.dyn = dyn_dev; g.abort_w = pi_abort_word();
+    g.dyn = dyn_dev; g.abort_w = pi_abort_word(); g.per_token = per_token_kv && dyn_dev ? 1 : 0;
     const int rows = n_tok * (n_head / n_head_kv);
     // rows per workgroup: K/V are re-read (from L2) by every chunk of a kv head, so chunks stay as large as the launch can
     // afford while still putting up to one workgroup on each of the 256 CUs
@@ -346,8 +359,9 @@ extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const 
     while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > wg_max) rw *= 2;
     static const int rw_env = getenv("PI_ATT_RW") ? atoi(getenv("PI_ATT_RW")) : 0;      // tuning / tests
     if (rw_env == 1 || rw_env == 2 || rw_env == 4 || rw_env == 8) rw = rw_env;
-    // (the single-row instance also has 8 KiB of static LDS)
-    if ((size_t) rw * (n_kv + g.mask_words) * sizeof(float) > (size_t) (rw == 1 ? 146 : 156) * 1024) { pi_set_error("pi_op_attention: n_kv=%d needs more than %d KiB of LDS", n_kv, rw == 1 ? 146 : 156); return -1; }
+    if (g.per_token) { const int r = n_head / n_head_kv; while (rw > 1 && r % rw) rw >>= 1; }      // a workgroup's rows stay inside one token (rows are token-major)
+    while (rw > 1 && att_lds_bytes(rw, n_kv) > att_lds_cap(rw)) rw >>= 1;               // long contexts: fewer score rows per workgroup (they live in LDS)
+    if ((size_t) rw * (n_kv + g.mask_words) * sizeof(float) > att_lds_cap(rw)) { pi_set_error("pi_op_attention: n_kv=%d needs more than %d KiB of LDS", n_kv, rw == 1 ? 146 : 156); return -1; }
     if (hd == 128) att_launch<128>(g, rows, rw, (hipStream_t) stream);
     else if (hd == 64) att_launch<64>(g, rows, rw, (hipStream_t) stream);
     else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }

@@ -346,6 +346,17 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
     assert last["skipped"] <= last["cancel_notes"] <= sum(t["n_runs_canceled"] for t in v["trials"])
     assert any(t["n_runs_spec"] > 0 for t in v["trials"])
     assert all(s["device_mode"] == (not host_rings) for s in v["stages"]) and all(s["runs"] > 0 for s in v["stages"])
+    # conservation: every run the head started came back, and passed every stage exactly once (computed, or as a skipped header)
+    assert last["received"] == last["runs"]
+    for s in v["stages"]:
+        assert s["received"] == last["runs"] and s["runs"] + s["skipped"] == s["received"], (s, last)
+    # the hop: one in-stream store into the consumer's ring slot (or the logits into the result slot) + one header; GPU time of the store per run, host time from the end
+    # of a run to its header being visible downstream per run — both far below the 50 us a host-mediated hop costs
+    for s in v["stages"]:
+        hop_gpu_us, hop_host_us = 1e3 * s["hop_gpu_ms"] / s["runs"], 1e3 * s["send_ms"] / s["received"]
+        print(f"stage {s['rank']}: store of the activations / logits {hop_gpu_us:.1f} us of GPU time per run, header published {hop_host_us:.1f} us after the run; waited {s['wait_out_ms']:.2f} ms in all for a free slot downstream")
+        if not host_rings:
+            assert hop_gpu_us < 50.0 and hop_host_us < 50.0, s
 
 
 @pytest.mark.parametrize("tgt,dft,n_layer", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 3), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 2), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0", 2)])

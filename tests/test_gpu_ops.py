@@ -250,7 +250,8 @@ def mask_bits(mask):
 
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok", [(128, 8, 8, 45, 3), (64, 32, 4, 70, 2), (64, 71, 1, 33, 1), (128, 64, 8, 300, 9), (64, 8, 2, 1024, 4),
                                                              (64, 4, 1, 32, 7), (64, 4, 4, 32, 8), (128, 32, 32, 256, 1), (128, 16, 2, 97, 5), (64, 4, 2, 64, 16),
-                                                             (128, 64, 8, 256, 9), (128, 64, 8, 300, 2), (64, 64, 8, 300, 9)])   # many rows: hit f16 ties of the fp32 product
+                                                             (128, 64, 8, 256, 9), (128, 64, 8, 300, 2), (64, 64, 8, 300, 9),    # many rows: hit f16 ties of the fp32 product
+                                                             (64, 64, 8, 6000, 32), (128, 8, 8, 20000, 1), (128, 64, 8, 9000, 3)])  # long contexts: fewer score rows per workgroup (8 -> 4 / 1 / 2 rows in LDS)
 def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
     lib, U = gpu
     from pipeinfer_amd import lib as L

@@ -57,7 +57,7 @@ def main():
         tp.attach_head(ct)
         out, res = LL.speculative(ct, cd, prompt, n_predict=23, n_draft=n_draft, n_parallel=n_parallel, p_accept=0.05, p_split=0.9, ignore_eos=0, min_spec_iters=min_spec)
         verdict["trials"].append({"out": [int(x) for x in out[:24]], "want": want, "n_runs_spec": res["n_runs_spec"], "n_runs_canceled": res["n_runs_canceled"],
-                                  "n_accept_clean": res["n_accept_clean"], **{k: tp.stats()[k] for k in ("runs", "skipped", "cancel_notes")}})
+                                  "n_accept_clean": res["n_accept_clean"], **{k: tp.stats()[k] for k in ("runs", "skipped", "cancel_notes", "received")}})
         ct.free(); cd.free()
     tp.shutdown()
     box = [None] * world
