@@ -79,16 +79,17 @@ def kernel_source_sha():
 def committed_traffic(workload, kernel_key):
     """HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): bench.py cannot
     run the profiler on itself.  The file is only quoted if it was measured on THIS kernel source (sha) and workload."""
+    name = f"r03_pmc_fetch_size_{workload}.json"
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_fetch_size_{workload}.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
-        return None, f"no committed PMC pass for workload {workload}"
+        return None, f"no committed PMC pass for workload {workload} (profiles/{name})"
     if pmc.get("kernel_src_sha16") != kernel_source_sha():
-        return None, f"profiles/r02_pmc_fetch_size_{workload}.json was measured on kernel sources {pmc.get('kernel_src_sha16')}, these are {kernel_source_sha()}: not quoted"
+        return None, f"profiles/{name} was measured on kernel sources {pmc.get('kernel_src_sha16')}, these are {kernel_source_sha()}: not quoted"
     k = pmc.get("kernels", {}).get(kernel_key)
     if not k:
-        return None, f"profiles/r02_pmc_fetch_size_{workload}.json has no entry for {kernel_key}"
-    return k["avg_fetch_bytes_per_launch"], f"profiles/r02_pmc_fetch_size_{workload}.json"
+        return None, f"profiles/{name} has no entry for {kernel_key}"
+    return k["avg_fetch_bytes_per_launch"], f"profiles/{name}"
 
 
 def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):

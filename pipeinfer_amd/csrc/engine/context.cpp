@@ -401,6 +401,34 @@ static bool pass_cancelled(const pi_pass & p) {
     for (const pi_run * r : p.runs) if (!r->canceled && !r->cancel_req.load()) return false;
     return true;
 }
+// May run q join a pass whose members (all started before q) are `members`?  Inside a pass every token's K/V of a layer are stored before that layer's attention, so a
+// member's reads of an EARLIER member's cells see what they would see one run after the other.  What a pass cannot reproduce is a cell that changes hands inside it: q
+// writing a cell that a member also writes, or that a member attends to expecting older content — e.g. the PipeInfer driver frees the cell of a speculative run's first
+// token and hands it to the non-speculative run of the same token while the speculative run is still queued (speculative.cpp:1252-1255, find_slot llama.cpp:1593-1644).
+// One case is exact all the same, and it is that one: the two tokens are the SAME computation — same token id, position, cell, n_kv and visibility row — so they store
+// identical bits, and whoever reads the cell reads those bits whichever store lands last.
+static bool pass_conflict(const llama_context * ctx, const std::vector<pi_run *> & members, const pi_run * q) {
+    const int words = (ctx->n_ctx + 31) / 32;
+    auto tok = [](const pi_run * r) { return (const int32_t *) r->meta_host; };
+    auto msk = [&](const pi_run * r, int t) { return (const uint32_t *) ((const int32_t *) r->meta_host + 2 * r->n_tokens + 4) + (size_t) t * words; };
+    for (int j = 0; j < q->n_tokens; j++) {
+        const int x = q->kv_head + j;
+        bool touched = false, same = false;                                    // a member writes or reads x / a member's token at x is the same computation as q's token j
+        for (const pi_run * m : members) {
+            if (x >= m->kv_head && x < m->kv_head + m->n_tokens) {
+                touched = true;
+                const int i = x - m->kv_head;
+                if (tok(m)[i] == tok(q)[j] && tok(m)[m->n_tokens + i] == tok(q)[q->n_tokens + j] && m->n_kv == q->n_kv && memcmp(msk(m, i), msk(q, j), (size_t) words * 4) == 0) same = true;
+                else return true;                                              // two different tokens written to one cell in one pass
+            } else {
+                for (int i = 0; i < m->n_tokens && !touched; i++) touched = (msk(m, i)[x >> 5] >> (x & 31)) & 1u;
+            }
+        }
+        if (touched && !same) return true;                                     // a member expects older content in x
+    }
+    return false;
+}
+
 // one input block for a pass of several runs: their tokens, positions and mask rows one after the other, the cell of every token, n_kv = the widest run's
 // (cells past a run's own n_kv are masked for its tokens and contribute exact zeros, like every masked cell inside it)
 static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
@@ -508,7 +536,7 @@ static void feeder_main(llama_context * ctx) {
                 while (!ctx->fqueue.empty()) {
                     pi_run * q = ctx->fqueue.front();
                     if (q->canceled || q->cancel_req.load()) { ctx->fqueue.pop_front(); dropped.push_back(q); continue; }
-                    if (pass->n_tokens + q->n_tokens > cmax) break;
+                    if (pass->n_tokens + q->n_tokens > cmax || pass_conflict(ctx, pass->runs, q)) break;
                     ctx->fqueue.pop_front();
                     q->pass = pass; q->row0 = pass->n_tokens; q->pass_leader = false;
                     pass->runs.push_back(q); pass->n_tokens += q->n_tokens; pass->n_kv = std::max(pass->n_kv, q->n_kv);

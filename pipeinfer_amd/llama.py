@@ -99,6 +99,7 @@ def api():
         lib.llama_token_get_text.argtypes = [vp, i32]
         lib.pipeinfer_context_error.restype = C.c_char_p
         lib.pipeinfer_context_error.argtypes = [vp]
+        lib.pipeinfer_run_first_cell.argtypes = [vp]; lib.pipeinfer_run_first_cell.restype = C.c_int32
         lib.pipeinfer_get_topk.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.pipeinfer_get_stats.argtypes = [vp, C.POINTER(pipeinfer_stats)]
         lib.pipeinfer_reset_stats.argtypes = [vp]

@@ -638,13 +638,28 @@ def _coalescing_scenario(LL, model_path, n_ctx, n_batch, seg_layers, rng):
                 ([t[4]], [p0 + 1], [[0]], 0),                                              # non-speculative run, canonical sequence
                 ([t[5], t[6]], [p0 + 4, p0 + 5], [[1]] * 2, 12),                          # chained: attends to the cells of the sequence-1 run above
                 ([t[7], t[8]], [p0 + 1, p0 + 2], [[2]] * 2, 13)]                          # cancelled before it starts computing
-        tickets = [c.start(tok, pos, seq, batch_id=bid) for tok, pos, seq, bid in runs]
+        # A cell that changes hands while its first owner is still queued — what the PipeInfer driver does to the first token of a speculative run when it starts the
+        # non-speculative run of the same position (speculative.cpp:1252-1255): rounds 2, 3 free the first cell of the speculative run before the canonical run is started,
+        # which then takes that very cell.  Round 2 gives it a DIFFERENT token (the runs must not share a pass), round 3 the SAME token (same id, position, cell, n_kv and
+        # visibility: the same computation — they may).  Either way every run's bits are those of the runs decoded one after the other.
+        handover = rnd in (2, 3)
+        if rnd == 3:
+            runs[2] = ([t[1]], [p0 + 1], [[0]], 0)
+        tickets = []
+        for i, (tok, pos, seq, bid) in enumerate(runs):
+            if handover and i == 2:
+                c.seq_rm(1, p0 + 1, p0 + 2)
+            tickets.append(c.start(tok, pos, seq, batch_id=bid))
+        if handover:
+            assert tickets[2][1].c.n_tokens == 1 and c.lib.pipeinfer_run_first_cell(tickets[2][0]) == c.lib.pipeinfer_run_first_cell(tickets[1][0]), "the canonical run was expected to take the freed cell"
         c.cancel([13])
         got = [None] * 5
         for i in (0, 1, 2, 3):
             got[i] = c.finish(tickets[i])
         assert c.lib.llama_finish_async_decode(c.h, tickets[4][1].c, tickets[4][0]) == 1
         for i, (tok, pos, seq, bid) in enumerate(runs):
+            if handover and i == 2:
+                ref.seq_rm(1, p0 + 1, p0 + 2)
             want = ref.decode(tok, pos, seq)                                               # one by one, in the same order: same cells
             if i < 4:
                 assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (rnd, i, float(np.abs(got[i] - want).max()))

@@ -1,5 +1,5 @@
-"""profiles/r02_pmc_fetch_size_<workload>.json from a rocprofv3 --pmc FETCH_SIZE run:
-    python tools_dev/pmc_to_json.py <dir> "<command line that was profiled>" > profiles/r02_pmc_fetch_size_70b.json
+"""profiles/r03_pmc_fetch_size_<workload>.json from a rocprofv3 --pmc FETCH_SIZE run:
+    python tools_dev/pmc_to_json.py <dir> "<command line that was profiled>" > profiles/r03_pmc_fetch_size_70b.json
 bytes = FETCH_SIZE (KiB) * 1024 * 2 (gfx950 correction of MI355X_MICROARCH.md, HBM/rocprofv3 section).
 The file carries the sha of the kernel sources it was measured on (bench.kernel_source_sha): bench.py quotes it only when that matches."""
 import collections
@@ -25,6 +25,10 @@ for name, v in raw.items():
     m = re.match(r"void k_mmvq_kq<(\d+), (\d+), ", name)
     if m and m.group(1) in TYPES:
         keyed[f"{TYPES[m.group(1)]}_nt{m.group(2)}"] += v              # all G / epilogue instances of one (type, tokens per pass)
+        continue
+    m = re.match(r"void k_mmvq_kq2<(\d+), (\d+), (\d+), ", name)     # two weight types in one launch: counted with the first type (Q4_K), like bench.py's launch statistics
+    if m and m.group(1) in TYPES:
+        keyed[f"{TYPES[m.group(1)]}_nt{m.group(3)}"] += v
         continue
     m = re.match(r"void k_mmq_kq<(\d+), ", name)
     if m and m.group(1) in TYPES:
