@@ -280,11 +280,12 @@ def main():
     ct.set_priority(int(os.environ.get("PIPEINFER_TARGET_PRIORITY", "0")))
     # one GPU: the target's stage graphs are launched segment by segment by a feeder thread, so that a cancelled speculative run stops at the
     # next segment boundary and the (high-priority) draft is served between segments instead of behind whole target runs
-    # Segment size = how often the draft gets the GPU.  Measured on the 70B workload (accepted tok/s, speculative runs per generation): 2 layers 28 / 912,
-    # 4: 47 / 463, 8: 66 / 275, 16: 64 / 235, 20: 65 / 198, 40: 73 / 50, 80: 71 / 50, one graph without a feeder: 82 / 0 (the target is always back before the first
-    # drafted token: no speculation at all, the round-1 situation).  The faster the draft is served, the more runs continuous speculation launches ahead
-    # of a verdict, and on ONE GPU every one of them is paid for in full; half a run per segment keeps speculation alive at the lowest cost.
-    seg_layers = int(os.environ.get("PIPEINFER_SEG_LAYERS", str(max(1, synth.SPECS[tspec][1] // 2))))
+    # Segment size = how often the draft gets the GPU (between segments the feeder lets the priority context go first) and how much of a run is enqueued ahead of the GPU.
+    # Round 3 (run coalescing + kernel-granular cancel, 70B workload, accepted tok/s of the PipeInfer schedule / ms per draft step): 40 layers per segment 79.9 / 4.9,
+    # 20: 98.0 / 2.5, 16: 93.2 / 2.2, 10: 85.1 / 2.0 (96.8 with passes capped at 8 tokens), 5: 89.1 / 1.8.  A speculative run of three drafted tokens has to be queued
+    # before the non-speculative run in flight finishes (12 ms): that needs a draft step under 4 ms; serving the draft faster than that only feeds more speculative runs
+    # that continuous speculation cancels again.  Default: a quarter of the layers.  (Round 2, one forward pass per run: 2 layers 28, 8: 66, 40: 73, one graph without a feeder 82.)
+    seg_layers = int(os.environ.get("PIPEINFER_SEG_LAYERS", str(max(1, synth.SPECS[tspec][1] // 4))))
     if seg_layers > 0:
         ct.set_segments(seg_layers)
     # Engine feature, not a driver change: the target's feeder takes every live run waiting in its queue into one forward pass (include/pipeinfer.h: run coalescing).

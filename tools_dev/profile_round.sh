@@ -9,7 +9,7 @@ export PI_NO_GRAPHS=1      # rocprofv3 on this image segfaults inside hipGraphLa
 B=$PWD/bench.py
 cd /tmp
 # 1. per-kernel time of the bench command (cpu_baseline leg off: it is CPU work; the other schedules on: they are part of the default run)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $B --no-cpu-baseline > $out/stats_bench.json 2> $out/stats_bench.err
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $B --no-cpu-baseline --steps 2 --warmup 1 > $out/stats_bench.json 2> $out/stats_bench.err
 echo "stats rc=$?"
 # 1b. the target alone (mode 2), for the per-kernel breakdown of one decode call
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_t -o target -- python3 $B --no-cpu-baseline --no-other-schedules --mode 2 --steps 1 --warmup 0 --n-predict 64 > $out/stats_target.json 2> $out/stats_target.err
