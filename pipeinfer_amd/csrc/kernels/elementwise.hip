@@ -173,29 +173,9 @@ __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__
     const int64_t nb = k >> 8;
     const float4 v = *(const float4 *) (x + (int64_t) t * k + (int64_t) blk * 256 + lane * 4);
     const float xs[4] = { v.x, v.y, v.z, v.w };
-    float amax = 0.0f, mx = 0.0f; int idx = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
-    pi_butterfly<32>([&](auto o) {
-        constexpr int O = decltype(o)::value;
-        const float oa = pi_partner<O>(amax), om = pi_partner<O>(mx); const int oi = pi_partner<O>(idx);
-        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-    });
-    int q[4] = { 0, 0, 0, 0 };
-    float d = 0.0f;
-    if (amax != 0.0f) {
-        const float iscale = -128.f / mx;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const int r = __float2int_rn(iscale * xs[i]); q[i] = r < 127 ? r : 127; }
-        d = 1 / iscale;
-    }
-    const uint32_t packed = (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
-    // k-major: values 4*lane..4*lane+3 are dword (lane & 7) of 32-group (lane >> 3) -> lane k = lane & 7 keeps 8 consecutive dwords
-    ((uint32_t *) (qs + ((int64_t) t * nb + blk) * 256))[(lane & 7) * 8 + (lane >> 3)] = packed;
-    int s = q[0] + q[1] + q[2] + q[3];
-    s += pi_partner<1>(s); s += pi_partner<2>(s);
-    if ((lane & 3) == 0) bsums[((int64_t) t * nb + blk) * 16 + (lane >> 2)] = (int16_t) s;
-    if (lane == 0) dd[(int64_t) t * nb + blk] = d;
+    int q[4], s;
+    const float d = pi_wave_q8K(xs, lane, q, s);
+    pi_wave_q8K_store(q, s, d, lane, (int64_t) t * nb + blk, qs, dd, bsums);
     wave_emit_frags(F, q, s, d, lane, t, blk, nb);
 }
 
@@ -230,29 +210,9 @@ __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__
 // ---- per-256 (Q8_K) / per-8x32 (Q8_0) quantisation of four consecutive values held by each lane of a wave ----------------
 // Same arithmetic as k_quantize_q8_K / k_quantize_q8_0 above; `blk` is the index of the 256-value chunk inside the row.
 static __device__ __forceinline__ void wave_quantize_q8_K(const float xs[4], int lane, int t, int64_t blk, int64_t nb, int8_t * qs, float * dd, int16_t * bsums, const q8k_frags & F) {
-    const int64_t row_blk = (int64_t) t * nb + blk;
-    float amax = 0.0f, mx = 0.0f; int idx = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
-    pi_butterfly<32>([&](auto o) {
-        constexpr int O = decltype(o)::value;
-        const float oa = pi_partner<O>(amax), om = pi_partner<O>(mx); const int oi = pi_partner<O>(idx);
-        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-    });
-    int q[4] = { 0, 0, 0, 0 };
-    float d = 0.0f;
-    if (amax != 0.0f) {
-        const float iscale = -128.f / mx;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const int r = __float2int_rn(iscale * xs[i]); q[i] = r < 127 ? r : 127; }
-        d = 1 / iscale;
-    }
-    ((uint32_t *) (qs + row_blk * 256))[(lane & 7) * 8 + (lane >> 3)] =
-        (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
-    int s = q[0] + q[1] + q[2] + q[3];
-    s += pi_partner<1>(s); s += pi_partner<2>(s);
-    if ((lane & 3) == 0) bsums[row_blk * 16 + (lane >> 2)] = (int16_t) s;
-    if (lane == 0) dd[row_blk] = d;
+    int q[4], s;
+    const float d = pi_wave_q8K(xs, lane, q, s);
+    pi_wave_q8K_store(q, s, d, lane, (int64_t) t * nb + blk, qs, dd, bsums);
     wave_emit_frags(F, q, s, d, lane, t, blk, nb);
 }
 static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int lane, int64_t tok_ng, int64_t e0, uint32_t * qs, uint16_t * dd, float * ss) {

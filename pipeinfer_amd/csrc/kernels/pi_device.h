@@ -87,6 +87,39 @@ static __device__ __forceinline__ int pi_cell_of(const int32_t * dyn, int kv_hea
 // signed 4 x int8 dot product accumulate: v_dot4c_i32_i8
 static __device__ __forceinline__ int pi_dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
 
+// Q8_K quantisation of the 256 values a wave holds (lane l: values 4l .. 4l+3), quantize_row_q8_K (ggml-quants.c:2329-2364): max = the signed value of the FIRST largest
+// |x|, iscale = -128 / max, q = min(127, rne(iscale * x)), d = 1 / iscale.  Returns d; q[] = the lane's four quants; s16 = the sum of the lane's 16-value group (valid in
+// every lane of the quad).  The ONE implementation behind k_quantize_q8_K, k_norm_quant, k_act_quant (elementwise.hip) and the mat-vec prologues (mmvq.hip).
+static __device__ __forceinline__ float pi_wave_q8K(const float xs[4], int lane, int q[4], int & s16) {
+    float amax = 0.0f, mx = 0.0f; int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float a = fabsf(xs[i]); if (a > amax) { amax = a; mx = xs[i]; idx = lane * 4 + i; } }
+    pi_butterfly<32>([&](auto o) {
+        constexpr int O = decltype(o)::value;
+        const float oa = pi_partner<O>(amax), om = pi_partner<O>(mx); const int oi = pi_partner<O>(idx);
+        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
+    });
+    q[0] = q[1] = q[2] = q[3] = 0;
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -128.f / mx;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int r = __float2int_rn(iscale * xs[i]); q[i] = r < 127 ? r : 127; }
+        d = 1 / iscale;
+    }
+    int s = q[0] + q[1] + q[2] + q[3];
+    s += pi_partner<1>(s); s += pi_partner<2>(s);
+    s16 = s;
+    return d;
+}
+// stores the wave's block into Q8_K planes (pi_q8_layout): qs k-major — values 4l..4l+3 are dword (l & 7) of 32-group (l >> 3) —, bsums of the sixteen 16-groups, d
+static __device__ __forceinline__ void pi_wave_q8K_store(const int q[4], int s16, float d, int lane, int64_t row_blk, int8_t * qs, float * dd, int16_t * bsums) {
+    ((uint32_t *) (qs + row_blk * 256))[(lane & 7) * 8 + (lane >> 3)] =
+        (uint32_t) (q[0] & 0xff) | (uint32_t) (q[1] & 0xff) << 8 | (uint32_t) (q[2] & 0xff) << 16 | (uint32_t) (q[3] & 0xff) << 24;
+    if ((lane & 3) == 0) bsums[row_blk * 16 + (lane >> 2)] = (int16_t) s16;
+    if (lane == 0) dd[row_blk] = d;
+}
+
 // fp16 lookup tables of the reference (ggml.c:2190-2201), computed on the host with the host libm and uploaded once
 struct pi_tables {
     const uint16_t * exp_f16;    // f16(expf(x))      indexed by f16 bits of x

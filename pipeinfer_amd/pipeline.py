@@ -313,7 +313,7 @@ def bench_main(args, rank, world):
     if rank != 0:
         st = tp.serve(ctx=backend.ctx)
         stats = backend.stats()
-        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"], float(st["runs"])], dtype=torch.float64)    # single-token calls
+        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"] + st["hop_gpu_ms"], float(st["runs"]), st["wait_out_ms"], float(st["peer_access"])], dtype=torch.float64)    # single-token calls
         dist.gather(t, None, dst=0)
         dist.barrier()
         tp.close()
@@ -351,8 +351,8 @@ def bench_main(args, rank, world):
     tp.shutdown()
     tp_device_mode = tp.device_mode
     head_stats = tp.stats()
-    gathered = [torch.zeros(9, dtype=torch.float64) for _ in range(world)]
-    dist.gather(torch.zeros(9, dtype=torch.float64), gathered, dst=0)
+    gathered = [torch.zeros(11, dtype=torch.float64) for _ in range(world)]
+    dist.gather(torch.zeros(11, dtype=torch.float64), gathered, dst=0)
     dist.barrier()
     tp.close()
     if not os.environ.get("PIPEINFER_KEEP_STAGE_FILES"):
@@ -367,7 +367,8 @@ def bench_main(args, rank, world):
     stage_stats = [{"rank": r, "layers": list(ranges[r - 1]), "calls": int(gathered[r][1]), "gpu_ms_per_call": round(float(gathered[r][0]) / max(1.0, float(gathered[r][1])), 4),
                     "GBps": round(float(gathered[r][2]) / max(1e-9, float(gathered[r][0]) * 1e-3) / 1e9, 1),
                     "runs_skipped": int(gathered[r][3]), "runs_cut_short": int(gathered[r][4]), "wait_for_input_ms": round(float(gathered[r][5]), 1),
-                    "compute_ms": round(float(gathered[r][6]), 1), "hop_ms": round(float(gathered[r][7]), 1), "runs": int(gathered[r][8])} for r in range(1, world)]
+                    "compute_ms": round(float(gathered[r][6]), 1), "hop_ms": round(float(gathered[r][7]), 3), "runs": int(gathered[r][8]),     # hop: GPU time of the in-stream store into the next stage's ring (last stage: logits into the result slot) + host time to publish the header
+                    "wait_for_slot_ms": round(float(gathered[r][9]), 1), "peer_access": int(gathered[r][10])} for r in range(1, world)]
     slow = max(stage_stats, key=lambda s: s["gpu_ms_per_call"])
     # dominant kernel = the single-token Q4_K mat-vec of every stage; its HBM traffic comes from the committed single-GPU PMC pass of the same
     # kernel sources (the per-launch traffic of a mat-vec does not depend on which stage launches it)
