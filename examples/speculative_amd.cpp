@@ -23,7 +23,7 @@
 
 static void usage(const char * a0) {
     fprintf(stderr, "usage: %s -m target.gguf -md draft.gguf (-p text | --prompt-tokens 1,2,3) [-n N] [--draft N] [-np N] [-pa F] [-ps F] [-pr F] [-pd F] "
-                    "[-c N] [-b N] [--ignore-eos] [--target-only] [--results file.csv] [--mpi-layer-split w1,w2,...[/1.0] [--rank R] [--world N] [--job NAME] [--device D]]\n", a0);
+                    "[-c N] [-b N] [--ignore-eos] [--target-only] [--orig] [--results file.csv] [--seg-layers N] [--coalesce N] [--mpi-layer-split w1,w2,...[/1.0] [--rank R] [--world N] [--job NAME] [--device D]]\n", a0);
 }
 
 static int env_int(const char * const * names, int fallback) {
@@ -42,6 +42,7 @@ int main(int argc, char ** argv) {
     static const char * const local_env[] = { "PIPEINFER_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK", "LOCAL_RANK", NULL };
     int rank = env_int(rank_env, 0), world = env_int(world_env, 1), device = env_int(local_env, -1);
     std::string job = getenv("PIPEINFER_JOB") ? getenv("PIPEINFER_JOB") : "";
+    int seg_layers = -1, coalesce = 16;                                    // -1: a quarter of the target's layers
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(argv[0]); exit(2); } return argv[++i]; };
@@ -75,6 +76,8 @@ int main(int argc, char ** argv) {
             }
             if (list > 1 || (list == 1 && n_second != 1)) { fprintf(stderr, "%s: --mpi-layer-split: the draft model is not split here (second list: one entry)\n", argv[0]); return 2; }
         }
+        else if (a == "--seg-layers")                    seg_layers = atoi(next());   // one GPU: layers per segment of the target's graphs (0: one graph, no feeder)
+        else if (a == "--coalesce")                      coalesce = atoi(next());     // one GPU: tokens the target's feeder may carry in one pass (0: one pass per run)
         else if (a == "--rank")                          rank = atoi(next());
         else if (a == "--world")                         world = atoi(next());
         else if (a == "--job")                           job = next();
@@ -138,6 +141,17 @@ int main(int argc, char ** argv) {
     if (!md) { fprintf(stderr, "%s: unable to load model\n", argv[0]); return 1; }
     llama_context * cd = llama_new_context_with_model(md, cp);
     if (!cd) { fprintf(stderr, "%s: failed to create the contexts\n", argv[0]); return 1; }
+    if (!pipelined && sp.mode == 0) {
+        // both models on ONE GPU (BASELINE configs[1]): the target's stage is launched segment by segment by a feeder thread that lets the (priority) draft go first
+        // between segments and carries the runs waiting in its queue in one forward pass; none of this changes a token
+        if (seg_layers < 0) seg_layers = pipeinfer_model_n_layer(mt) / 4 > 0 ? pipeinfer_model_n_layer(mt) / 4 : 1;
+        if (seg_layers > 0) {
+            if (pipeinfer_context_set_segments(ct, seg_layers) != 0 || pipeinfer_context_set_priority(cd, 1) != 0 || pipeinfer_context_prepare(ct) != 0 || pipeinfer_context_prepare(cd) != 0 ||
+                (coalesce > 1 && pipeinfer_context_set_coalescing(ct, coalesce) != 0)) {
+                fprintf(stderr, "%s: %s / %s\n", argv[0], pipeinfer_context_error(ct), pipeinfer_context_error(cd)); return 1;
+            }
+        }
+    }
 
     if (prompt.empty()) {                                                  // llama_tokenize with add_bos, like ::llama_tokenize(ctx, prompt, true)
         prompt.resize(prompt_text.size() + 8);

@@ -40,6 +40,7 @@ LLAMA_API int  pipeinfer_context_set_coalescing(struct llama_context * ctx, int 
 /* 0: launch the decode kernels one by one instead of replaying the captured HIP graph (profiling / per-kernel event timing) */
 LLAMA_API void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable);
 LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
+LLAMA_API int32_t pipeinfer_model_n_layer(const struct llama_model * model);
 /* first KV cell find_slot allotted to a run in flight (ticket of llama_start_async_decode); tests */
 LLAMA_API int32_t pipeinfer_run_first_cell(const struct ggml_cgraph * ticket);
 

@@ -96,11 +96,6 @@ PI_API int pi_op_mul_mat(const pi_weight * w, const void * q8_dev, int n_tok, fl
 PI_API int pi_op_mul_mat_qkv_rope_ok(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, int neox, int head_dim);
 PI_API int pi_op_mul_mat_qkv_rope(const pi_weight * wq, const pi_weight * wk, const pi_weight * wv, const void * q8_dev, int n_tok, const int32_t * pos_dev, const void * rope_table,
                                   int head_dim, int n_head, int n_head_kv, int kv_head, const int32_t * dyn_dev, uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, void * stream);
-/* Activation prologue for small models at decode width (K <= 4096, one token): the NEXT pi_op_mul_mat / _multi / _qkv_rope call of this thread quantises the fp32 vector
- * x_dev itself, inside every workgroup (mode 1: RMS norm with eps, times norm_w_dev, then Q8_K — pi_op_norm_quantize's arithmetic to the bit; mode 2: Q8_K of x_dev as it
- * is — pi_op_quantize's), and is passed q8_dev = NULL: one launch instead of two.  Ask pi_op_mul_mat_prologue_ok for the same weights first. */
-PI_API int  pi_op_mul_mat_prologue_ok(int n_w, const pi_weight * const * ws, int n_tok);
-PI_API void pi_set_mul_mat_prologue(const float * x_dev, const float * norm_w_dev, float eps, int mode);
 PI_API int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void * q8_dev, int n_tok, float * const * outs_dev, const float * const * residuals_dev, void * stream);
 
 /* RoPE tables as the reference iterates them: cos/sin [n_pos][head_dim/2] f32, built on the host (theta *= theta_scale) */

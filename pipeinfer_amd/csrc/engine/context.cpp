@@ -117,7 +117,6 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
         if (hipStreamCreateWithPriority(&ctx->ctl_stream, hipStreamNonBlocking, hi) != hipSuccess) { err = "hipStreamCreate(control) failed"; return false; }
     }
     ctx->use_graphs = getenv("PI_NO_GRAPHS") == nullptr;
-    if (getenv("PIPEINFER_FUSE_MAX_K")) ctx->fuse_max_k = atoi(getenv("PIPEINFER_FUSE_MAX_K"));      // 0: no prologue fusion; 4096: also for 7B-shaped models (tuning)
     if (pi_op_attention_reserve(hp.head_dim(), ctx->n_ctx) != 0 || pi_op_mul_mat_reserve() != 0) { err = pi_last_error(); return false; }
     ctx->mask_cap_words = (size_t) nb * ((ctx->n_ctx + 31) / 32);
     if (!(ctx->mask_dev = (uint32_t *) dev(ctx->mask_cap_words * 4))) return false;
@@ -212,12 +211,6 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
         if (hp.arch == PI_ARCH_LLAMA) {
             float * q = ctx->qkv, * k = q + (size_t) n_tok * n_embd, * v = k + (size_t) n_tok * n_gqa;
             const int vq = vdt_of(L.wq);
-            const bool fuse = n_tok == 1 && n_embd <= ctx->fuse_max_k && !trace_enabled();        // small model, one token: quantisers as prologues of their consumers
-            const pi_weight * qkv_w[3] = { L.wq, L.wk, L.wv };
-            if (fuse && pi_op_mul_mat_qkv_rope_ok(L.wq, L.wk, L.wv, 0, hd) && pi_op_mul_mat_prologue_ok(3, qkv_w, 1)) {
-                pi_set_mul_mat_prologue(x, L.attn_norm, hp.f_norm_rms_eps, 1);                     // attn_norm + Q8_K inside the projection launch
-                OP_OK(pi_op_mul_mat_qkv_rope(L.wq, L.wk, L.wv, nullptr, n_tok, ctx->pos_dev, ctx->rope, hd, hp.n_head, hp.n_head_kv, kv_head, ctx->dyn_dev, ctx->q16, kc, vc, s));
-            } else {
             if (!norm_for(ctx, x, L.attn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vq, ctx->q8a)) return false;
             if (!trace_enabled() && pi_op_mul_mat_qkv_rope_ok(L.wq, L.wk, L.wv, 0, hd)) {
                 // projections, RoPE, f16 rounding and the K/V cache writes in the mat-vec launch(es) themselves
@@ -234,25 +227,11 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
                 trace(ctx, "q", il, q, n_embd, n_tok); trace(ctx, "k", il, k, n_gqa, n_tok); trace(ctx, "v", il, v, n_gqa, n_tok);
                 OP_OK(pi_op_rope_kv_store(q, k, v, n_embd, n_gqa, n_gqa, ctx->pos_dev, ctx->rope, 0, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             }
-            }
             OP_OK(pi_op_attention_ex(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, multi ? 1 : 0, s));
             trace(ctx, "att", il, ctx->att, n_embd, n_tok);
-            const pi_weight * wo_w[1] = { L.wo };
-            if (fuse && pi_op_mul_mat_prologue_ok(1, wo_w, 1)) {
-                pi_set_mul_mat_prologue(ctx->att, nullptr, 0.0f, 2);                                                 // Q8_K of the attention output inside wo's launch
-                OP_OK(pi_op_mul_mat(L.wo, nullptr, n_tok, x2, x, s));
-            } else {
-                OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
-                OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, x, s));                                               // ffn_inp = wo.att + inpSA
-            }
+            OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
+            OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, x, s));                                                   // ffn_inp = wo.att + inpSA
             const int vu = vdt_of(L.ffn_up);
-            const pi_weight * ug_w[2] = { L.ffn_up, L.ffn_gate };
-            const bool fuse_ffn = fuse && pi_weight_type(L.ffn_up) == pi_weight_type(L.ffn_gate) && pi_op_mul_mat_prologue_ok(2, ug_w, 1);
-            if (fuse_ffn) {
-                float * outs[2] = { ctx->up, ctx->gate };
-                pi_set_mul_mat_prologue(x2, L.ffn_norm, hp.f_norm_rms_eps, 1);                                       // ffn_norm + Q8_K inside the up / gate launch
-                OP_OK(pi_op_mul_mat_multi(2, ug_w, nullptr, n_tok, outs, nullptr, s));
-            } else {
             if (!norm_for(ctx, x2, L.ffn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vu, ctx->q8a)) return false;
             if (vdt_of(L.ffn_gate) != vu && !norm_for(ctx, x2, L.ffn_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vdt_of(L.ffn_gate), ctx->q8c)) return false;
             {
@@ -260,7 +239,6 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
                 const void * ins[2] = { ctx->q8a, vdt_of(L.ffn_gate) == vu ? ctx->q8a : ctx->q8c };
                 float * outs[2] = { ctx->up, ctx->gate };
                 if (!mul_mat_grouped(2, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
-            }
             }
             OP_OK(pi_op_act_quantize(ctx->gate, ctx->up, 0, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));        // silu(gate) * up
             OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, x2, s));                                             // l_out = down(..) + ffn_inp
@@ -291,15 +269,9 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
     }
     if (tail && ctx->is_last) {
         const int vo = vdt_of(m->output);
-        const pi_weight * out_w[1] = { m->output };
-        if (hp.arch == PI_ARCH_LLAMA && n_tok == 1 && n_embd <= ctx->fuse_max_k && !trace_enabled() && pi_op_mul_mat_prologue_ok(1, out_w, 1)) {
-            pi_set_mul_mat_prologue(x, m->output_norm, hp.f_norm_rms_eps, 1);                                        // output_norm + Q8_K inside the lm_head launch
-            OP_OK(pi_op_mul_mat(m->output, nullptr, n_tok, ctx->logits_dev, nullptr, s));
-        } else {
         if (hp.arch == PI_ARCH_LLAMA) { if (!norm_for(ctx, x, m->output_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vo, ctx->q8a)) return false; }
         else                          { if (!norm_for(ctx, x, m->output_norm, m->output_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vo, ctx->q8a)) return false; }
         OP_OK(pi_op_mul_mat(m->output, ctx->q8a, n_tok, ctx->logits_dev, nullptr, s));
-        }
         OP_OK(pi_op_topk(ctx->logits_dev, hp.n_vocab, n_tok, 8, ctx->topk_ids_dev, ctx->topk_vals_dev, ctx->topk_sum_dev, ctx->topk_scratch_dev, s));
     }
     return true;

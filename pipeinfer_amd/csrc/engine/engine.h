@@ -123,9 +123,6 @@ struct llama_context {
     struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; };
     std::map<std::pair<int, int>, graph_entry> graphs;   // one captured graph per (n_tokens, segment) (kv_head / n_kv come from dyn_dev)
     bool use_graphs = true;
-    // single-token passes of small models (n_embd <= fuse_max_k): the activation quantisers (norm + quantise, quantise of the attention output) run as prologues of the
-    // consuming mat-vec launches instead of as launches of their own (mmvq.hip: k_mmvq_kq_pro) — a draft step is a chain of ~200 dependent 3-5 us launches
-    int fuse_max_k = 2048;
     // Segmented launch (pipeinfer_context_set_segments): the stage's layers are captured as segments of `seg_layers` layers and a feeder
     // thread enqueues them one or two ahead of the GPU.  Between segments it (a) drops the rest of a run that has been cancelled meanwhile
     // — the reference polls its abort callback between graph nodes (llama.cpp:5665-5687, ggml.c:15748-15811) — and (b) lets contexts of

@@ -264,6 +264,7 @@ extern "C" int pipeinfer_context_set_coalescing(struct llama_context * ctx, int 
     if (max_tokens > 1 && !pi::context_precapture(ctx, std::min(max_tokens, ctx->n_batch))) { ctx->coalesce_max.store(0); return -1; }
     return 0;
 }
+extern "C" int32_t pipeinfer_model_n_layer(const struct llama_model * model) { return model ? model->hparams.n_layer : 0; }
 extern "C" int32_t pipeinfer_run_first_cell(const struct ggml_cgraph * ticket) { return ticket ? ((const pi_run *) ticket)->kv_head : -1; }
 extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }
 

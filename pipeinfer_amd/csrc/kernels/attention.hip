@@ -56,7 +56,6 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     extern __shared__ float smem[];
     __shared__ float redf[RW][4];
     __shared__ unsigned long long redu[RW][4];
-    if (pi_aborted(ga.abort_w)) return;
     att_args g = ga;
     const int s_stride = ga.n_kv;                           // LDS rows keep the static stride
     const int hk = blockIdx.x, chunk = blockIdx.y;
@@ -103,6 +102,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         for (int i = 0; i < NTAIL; i++) vt[i] = vtb[(int64_t) min(np + i, g.n_kv - 1) * n_gqa];
     }
 
+    int aborted = 0;
     // ---- phase 1: scores, ggml_vec_dot_f16 order ----
     {
         constexpr int NS = HD / 32;                         // 32-element steps
@@ -153,6 +153,9 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
             }
         };
         load_k(0, kr[0]);
+        // the run's abort word (pi_device.h) is requested behind the first K loads and the V prefetch — in front of them its round trip would gate them (loads retire in
+        // order) — and looked at before anything is stored: the kernel writes only its output rows, at the very end
+        aborted = pi_abort_peek(ga.abort_w);
         // visibility words of this workgroup's rows go to LDS once (a global load inside the scoring loop would put its latency
         // on every step); the K loads above are already in flight
         for (int i = tid; i < n_rows * g.mask_words; i += 256) {
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         float mine = res[0];                                                            // every lane of the 8 holds all 8 sums: lane l keeps dim l
 #pragma unroll
         for (int e = 1; e < 8; e++) mine = l == e ? res[e] : mine;
-        if (rr < n_rows) {
+        if (rr < n_rows && !(aborted & 1)) {
             const int row = row0 + rr, t = row / r, gq = row % r;
             if (n_tail > 0) {
                 double sd = (double) mine;

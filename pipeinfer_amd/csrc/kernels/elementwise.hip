@@ -232,9 +232,6 @@ static __device__ __forceinline__ void wave_quantize_q8_0(const float xs[4], int
 // One workgroup per token; every wave normalises and quantises whole 256-value chunks (a Q8_K block, or eight Q8_0 blocks).
 __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ yf,
                                                       int n, float eps, int rms, int vdt, int64_t ng, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
-    // the abort word is requested first and looked at only in front of the stores: this kernel is ONE dependent chain of round trips (a 1 024-thread workgroup per token),
-    // a test on entry would add one (measured +0.9 us on 6.8), and an aborted norm saves nothing worth saving
-    const int aborted = pi_abort_peek(abort_w);
     __shared__ double sh[16];
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const float * xr = x + (int64_t) t * n;
@@ -265,6 +262,10 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
             br4[cc] = in && b ? *(const float4 *) (b + e0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
+    // the abort word is requested BEHIND the kernel's own loads (loads retire in order: in front of them its round trip — past L1, to where the device-scope atomics
+    // live — would gate x) and looked at only in front of the stores: this kernel is ONE chain of dependent round trips (a 1 024-thread workgroup per token), a test on
+    // entry adds one (measured +0.9 us on 6.8), and an aborted norm saves nothing worth saving
+    const int aborted = pi_abort_peek(abort_w);
     float mean = 0.0f;
     double acc = 0.0;
     if (in_regs) {

@@ -478,78 +478,6 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
     else                           mmvq_kq_body<TA, NT, R, ST, LSTR>(g, lds);
 }
 
-// ---- activation prologue: small models at decode width are a chain of ~200 dependent launches of 3-5 us, two of every five of them an activation quantiser
-//      (k_norm_quant, k_quantize_q8_K) that keeps ONE workgroup busy.  Here every workgroup of the consuming mat-vec quantises the K <= 4096 inputs itself, into LDS:
-//      redundant work (8-16 KB from L2 per workgroup), one launch less.  The arithmetic is k_norm_quant's / k_quantize_q8_K's to the bit, including the order of the
-//      double-precision sum of squares: per 256-value chunk a wave sum (thread l of the chunk owns x[4l..4l+3], added x, y, z, w), then the chunks in order — exactly
-//      what k_norm_quant does when it is launched with one wave per chunk (K <= 4096: it is).  Act planes in LDS: qs [K] | d [nb] f32 | bsums [nb][16] i16.
-template <int WPB>
-static __device__ __forceinline__ void mmvq_prologue(const mmvq_args & g, uint8_t * act, double * sh) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int K = g.K, chunks = K >> 8;
-    float scale = 1.0f;
-    if (g.pro_mode == 1) {
-        for (int v = wave; v < chunks; v += WPB) {
-            const float4 xv = *(const float4 *) (g.pro_x + (int64_t) v * 256 + lane * 4);
-            double acc = 0.0;
-            acc += (double) (xv.x * xv.x); acc += (double) (xv.y * xv.y); acc += (double) (xv.z * xv.z); acc += (double) (xv.w * xv.w);
-            acc = pi_wave_sum_f64(acc);
-            if (lane == 0) sh[v] = acc;
-        }
-        __syncthreads();
-        double s = 0.0;
-        for (int i = 0; i < chunks; i++) s += sh[i];
-        const float var = (float) (s / K);
-        scale = 1.0f / sqrtf(var + g.pro_eps);
-    }
-    int8_t * qs = (int8_t *) act; float * dd = (float *) (act + K); int16_t * bsums = (int16_t *) (act + K + ((chunks * 4 + 15) & ~15));
-    for (int v = wave; v < chunks; v += WPB) {
-        const float4 xv = *(const float4 *) (g.pro_x + (int64_t) v * 256 + lane * 4);
-        float ys[4] = { xv.x, xv.y, xv.z, xv.w };
-        if (g.pro_mode == 1) {
-            const float4 wv = *(const float4 *) (g.pro_w + (int64_t) v * 256 + lane * 4);
-            const float ww[4] = { wv.x, wv.y, wv.z, wv.w };
-#pragma unroll
-            for (int i = 0; i < 4; i++) { float y = (ys[i] - 0.0f) * scale; y = y * ww[i]; ys[i] = y; }      // k_norm_quant: (x - mean) * scale, then * weight (rms: mean == 0)
-        }
-        int q[4], s16;
-        const float d = pi_wave_q8K(ys, lane, q, s16);
-        pi_wave_q8K_store(q, s16, d, lane, v, qs, dd, bsums);
-    }
-    __syncthreads();
-}
-static size_t mmvq_pro_act_bytes(int K) { const int nb = K >> 8; return (size_t) K + ((nb * 4 + 15) & ~15) + (size_t) nb * 32; }
-
-// one token, rows of one tile (K <= 4096), four waves per workgroup: prologue, then the decode body on the LDS activations
-template <int TYPE, int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_mmvq_kq_pro(const mmvq_args g) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ double sh[16];
-    if (pi_aborted(g.abort_w)) return;
-    constexpr int LSTR = kq_lds<TYPE, R>::FLOATS;
-    uint8_t * act = lds + (size_t) 4 * LSTR * 4;
-    mmvq_prologue<4>(g, act, sh);
-    mmvq_args gl = g;
-    gl.aq = act; gl.ad = act + g.K; gl.abs_ = act + g.K + (((g.K >> 8) * 4 + 15) & ~15);
-    mmvq_kq_body<TYPE, 1, R, 1, LSTR>(gl, lds);
-}
-template <int TA, int TB, int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_mmvq_kq2_pro(const mmvq_args g) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ double sh[16];
-    if (pi_aborted(g.abort_w)) return;
-    constexpr int FA = kq_lds<TA, R>::FLOATS, FB = kq_lds<TB, R>::FLOATS, LSTR = FA > FB ? FA : FB;
-    uint8_t * act = lds + (size_t) 4 * LSTR * 4;
-    mmvq_prologue<4>(g, act, sh);
-    mmvq_args gl = g;
-    gl.aq = act; gl.ad = act + g.K; gl.abs_ = act + g.K + (((g.K >> 8) * 4 + 15) & ~15);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave_id = (int) (blockIdx.x * 4 + wave);
-    const int si = (wave_id >= g.seg[1].wave0) + (wave_id >= g.seg[2].wave0);
-    if ((g.type_b_mask >> si) & 1) mmvq_kq_body<TB, 1, R, 1, LSTR>(gl, lds);
-    else                           mmvq_kq_body<TA, 1, R, 1, LSTR>(gl, lds);
-}
-
 // ================================================================================================================
 // Q4_0 / Q8_0 x Q8_0 at decode widths: the workgroup is 8 rows, wave w takes the groups [w*G, (w+1)*G) of those rows — every
 // group of the rows is in flight at once (8x the waves of k_mmvq_q0 below) — and keeps its (d_x*d_y, integer dot) pairs in
@@ -1032,58 +960,6 @@ static int launch_mmvq2(mmvq_launch & L, hipStream_t stream) {
     return 0;
 }
 
-// ---- activation prologue (k_mmvq_kq_pro): requested by the caller for the NEXT mat-vec of this thread (pi_set_mul_mat_prologue), taken by mul_mat_multi_impl ----
-struct mmvq_pro_req { const float * x; const float * w; float eps; int mode; };
-static thread_local mmvq_pro_req g_pro = { nullptr, nullptr, 0.0f, 0 };
-extern "C" void pi_set_mul_mat_prologue(const float * x_dev, const float * norm_w_dev, float eps, int mode) { g_pro = mmvq_pro_req{ x_dev, norm_w_dev, eps, mode }; }
-// does the prologue form of the mat-vec exist for these weights?  one token, K-quant rows of one tile with K <= 4096, one type of Q4_K / Q5_K / Q6_K or Q4_K with Q5_K / Q6_K
-extern "C" int pi_op_mul_mat_prologue_ok(int n_w, const pi_weight * const * ws, int n_tok) {
-    static const bool off = getenv("PI_MMVQ_NO_PROLOGUE") != nullptr;        // tuning / tests
-    if (off || n_tok != 1 || n_w < 1 || n_w > MMVQ_MAX_SEG) return 0;
-    const int64_t K = ws[0]->ne0;
-    if (K % 256 || K > 4096) return 0;
-    int tb = -1;
-    for (int i = 0; i < n_w; i++) {
-        const int t = ws[i]->type;
-        if (ws[i]->ne0 != K || (t != PI_Q4_K && t != PI_Q5_K && t != PI_Q6_K)) return 0;
-        if (t != PI_Q4_K) { if (tb >= 0 && tb != t) return 0; tb = t; }
-    }
-    return 1;
-}
-template <int TYPE>
-static int launch_mmvq_pro(mmvq_launch & L, hipStream_t stream, int type_b) {
-    mmvq_args & g = L.g;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    const bool sample = kt_begin(TYPE, 1, ea, eb);
-    int R = 2;
-    while (R > 1 && L.m_total / R < 2048) R >>= 1;
-    if (L.rope && R < 2) R = 2;
-    int waves = 0;
-    for (int i = 0; i < MMVQ_MAX_SEG; i++) {
-        if (i < L.nseg) { g.seg[i].wave0 = waves; waves += (g.seg[i].M + R - 1) / R; }
-        else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
-    }
-    const unsigned grid = (unsigned) ((waves + 3) / 4);
-    const size_t act = mmvq_pro_act_bytes(g.K);
-    auto go = [&](auto rc) {
-        constexpr int RR = decltype(rc)::value;
-        auto one = [&](auto kern, size_t lstr) {
-            const size_t lds = 4 * lstr * 4 + act;
-            if (sample) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, ea, eb, 0, g);
-            else        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, g);
-        };
-        if constexpr (TYPE == PI_Q4_K) {
-            if (type_b == PI_Q5_K)      one(k_mmvq_kq2_pro<PI_Q4_K, PI_Q5_K, RR>, (size_t) std::max(kq_lds<PI_Q4_K, RR>::FLOATS, kq_lds<PI_Q5_K, RR>::FLOATS));
-            else if (type_b == PI_Q6_K) one(k_mmvq_kq2_pro<PI_Q4_K, PI_Q6_K, RR>, (size_t) std::max(kq_lds<PI_Q4_K, RR>::FLOATS, kq_lds<PI_Q6_K, RR>::FLOATS));
-            else                        one(k_mmvq_kq_pro<PI_Q4_K, RR>, (size_t) kq_lds<PI_Q4_K, RR>::FLOATS);
-        } else one(k_mmvq_kq_pro<TYPE, RR>, (size_t) kq_lds<TYPE, RR>::FLOATS);
-    };
-    if (R == 1) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
-    if (sample) kt_end(TYPE, 1, L, ea, eb);
-    PI_CHECK_LAUNCH();
-    return 0;
-}
-
 template <int TYPE>
 static int dispatch_nt(mmvq_launch & L, int nt, hipStream_t stream) {
     switch (nt) {
@@ -1106,12 +982,8 @@ struct mmvq_rope { int store[MMVQ_MAX_SEG]; uint16_t * dst16[MMVQ_MAX_SEG]; int 
 
 static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void * q8, int n_tok, float * const * outs, const float * const * ress, const mmvq_rope * rope, void * stream_) {
     hipStream_t stream = (hipStream_t) stream_;
-    const mmvq_pro_req pro = g_pro;                                             // a prologue request belongs to THIS call, whatever becomes of it
-    g_pro = mmvq_pro_req{ nullptr, nullptr, 0.0f, 0 };
     if (n_tok <= 0 || n_w <= 0) return 0;
     if (n_w > MMVQ_MAX_SEG) { pi_set_error("pi_op_mul_mat_multi: n_w=%d > %d", n_w, MMVQ_MAX_SEG); return -1; }
-    if (pro.mode && !pi_op_mul_mat_prologue_ok(n_w, ws, n_tok)) { pi_set_error("pi_op_mul_mat: an activation prologue was requested for a launch that has none (ask pi_op_mul_mat_prologue_ok first)"); return -1; }
-    if (!pro.mode && !q8) { pi_set_error("pi_op_mul_mat: no quantised activations"); return -1; }
     const pi_weight * w0 = ws[0];
     const int vdt = pi_vec_dot_type(w0->type);
     if (vdt != PI_Q8_K && vdt != PI_Q8_0 && vdt != PI_Q8_1) { pi_set_error("pi_op_mul_mat: weight type %d has no quantised mat-vec", w0->type); return -1; }
@@ -1156,7 +1028,6 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
         L.g.pos = rope ? rope->pos : nullptr; L.g.rope_cs = rope ? rope->cs : nullptr; L.g.dyn = rope ? rope->dyn : nullptr;
         L.g.kv_head = rope ? rope->kv_head : 0; L.g.hd = rope ? rope->hd : 2; L.g.tok0 = t0;
         L.g.frag = nullptr; L.g.aux = nullptr; L.g.nt = nt; L.g.abort_w = pi_abort_word(); L.g.type_b_mask = mixed ? type_b_mask : 0;
-        L.g.pro_x = pro.x; L.g.pro_w = pro.w; L.g.pro_eps = pro.eps; L.g.pro_mode = pro.mode;
         L.rope = rope != nullptr;
         for (int i = 0; i < n_w; i++) {
             const pi_weight * w = ws[i];
@@ -1176,14 +1047,6 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             else { L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr; }
         }
         int rc = -1;
-        if (pro.mode) {                                                           // (one token, K <= 4096: a single pass of the loop)
-            const int t0_type = mixed ? PI_Q4_K : w0->type;
-            if (t0_type == PI_Q4_K)      rc = launch_mmvq_pro<PI_Q4_K>(L, stream, mixed ? type_b : -1);
-            else if (t0_type == PI_Q5_K) rc = launch_mmvq_pro<PI_Q5_K>(L, stream, -1);
-            else                         rc = launch_mmvq_pro<PI_Q6_K>(L, stream, -1);
-            if (rc) return rc;
-            continue;
-        }
         if (mixed) {
             if (type_b == PI_Q5_K) rc = nt == 1 ? launch_mmvq2<PI_Q5_K, 1>(L, stream) : launch_mmvq2<PI_Q5_K, 2>(L, stream);
             else                   rc = nt == 1 ? launch_mmvq2<PI_Q6_K, 1>(L, stream) : launch_mmvq2<PI_Q6_K, 2>(L, stream);

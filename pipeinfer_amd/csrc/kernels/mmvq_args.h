@@ -31,9 +31,6 @@ struct mmvq_args {
     int kv_head, hd, tok0;
     // multi-token MFMA kernel (mmq_mfma.hip): operand planes of this launch's chunk of <= 16 tokens (pi_q8_frag_layout), tokens in the chunk
     const uint8_t * frag; const uint8_t * aux; int nt;
-    // activation prologue (k_mmvq_kq_pro, one token, rows of one tile): the workgroup quantises the fp32 vector itself — pro_mode 1: RMS norm * pro_w first
-    // (k_norm_quant's arithmetic), 2: as it is (k_quantize_q8_K) — into LDS instead of reading the planes aq / ad / abs_
-    const float * pro_x; const float * pro_w; float pro_eps; int pro_mode;
     int type_b_mask;            // k_mmvq_kq2 (two weight types in one launch): bit i set <=> segment i is of the second type
     const int32_t * abort_w;    // abort word of the run (pi_device.h), nullable: a kernel whose run has been cancelled returns on entry
     int dbg;                    // tuning only (PI_MMQ_DBG): 1 = skip the arithmetic, 2 = skip the activation staging and its barriers (results are then garbage)

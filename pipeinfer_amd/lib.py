@@ -102,8 +102,6 @@ def _declare(lib):
     lib.pi_op_act_quantize.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
     lib.pi_op_mul_mat.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.pi_op_mul_mat_multi.argtypes = [i32, vp, vp, i32, vp, vp, vp]
-    lib.pi_op_mul_mat_prologue_ok.argtypes = [i32, vp, i32]
-    lib.pi_set_mul_mat_prologue.argtypes = [vp, vp, f32, i32]; lib.pi_set_mul_mat_prologue.restype = None
     lib.pi_op_mul_mat_qkv_rope_ok.argtypes = [vp, vp, vp, i32, i32]
     lib.pi_op_mul_mat_qkv_rope.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.pi_rope_table_create.restype = vp

@@ -497,48 +497,6 @@ def test_two_weight_types_share_one_launch(gpu, types, k, n_tok):
         lib.pi_weight_free(w)
 
 
-@pytest.mark.parametrize("types", [(O.Q4_K,), (O.Q6_K,), (O.Q5_K,), (O.Q4_K, O.Q4_K), (O.Q4_K, O.Q4_K, O.Q4_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q4_K, O.Q5_K, O.Q5_K)])
-@pytest.mark.parametrize("k,rows,mode", [(256, 40, 1), (2048, 2048, 1), (2048, 5632, 2), (4096, 1024, 1), (2048, 256, 2), (1024, 7000, 1)])
-def test_activation_prologue_equals_the_separate_quantiser_launch(gpu, types, k, rows, mode):
-    """small models at decode width: the consuming mat-vec quantises its own activations (k_mmvq_kq_pro: RMS norm * weight + Q8_K, or Q8_K of the vector as it is, inside
-    every workgroup) instead of reading planes a quantiser launch wrote — the same bits as pi_op_norm_quantize / pi_op_quantize followed by the plain mat-vec (which the
-    other tests hold to the oracle), for one, two and three matrices per launch, one and two weight types, one and two rows per wave"""
-    lib, U = gpu
-    from pipeinfer_amd import lib as L
-    rng = np.random.default_rng(k + rows + mode)
-    ms = [rows, max(2, rows // 8), max(2, rows // 8)][:len(types)]
-    ws = []
-    for t, m in zip(types, ms):
-        ws.append(upload_weight(lib, t, m, k, synth.random_blocks(t, m * k, rng, 0.05).reshape(m, -1)))
-    wl = (C.c_void_p * len(ws))(*ws)
-    assert lib.pi_op_mul_mat_prologue_ok(len(ws), wl, 1) == 1 and lib.pi_op_mul_mat_prologue_ok(len(ws), wl, 2) == 0
-    x = (signal(k, 3) * 0.7).astype(np.float32).reshape(1, k)
-    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float32)
-    xd, nwd = U.Dev(x), U.Dev(nw)
-    res = U.Dev(rng.standard_normal((1, ms[0])).astype(np.float32))
-    q8 = U.Dev(nbytes=lib.pi_q8_nbytes(O.Q8_K, k, 1))
-    if mode == 1:
-        L.check(lib.pi_op_norm_quantize(xd.ptr, nwd.ptr, None, None, k, 1, 1e-5, 1, O.Q8_K, q8.ptr, None))
-    else:
-        L.check(lib.pi_op_quantize(O.Q8_K, xd.ptr, k, 1, q8.ptr, None))
-    got = []
-    for fused in (False, True):
-        outs = [U.Dev(np.full((1, m), 3.25, np.float32)) for m in ms]
-        ol = (C.c_void_p * len(ws))(*[o.ptr for o in outs])
-        rl = (C.c_void_p * len(ws))(*([res.ptr] + [None] * (len(ws) - 1)))
-        if fused:
-            lib.pi_set_mul_mat_prologue(xd.ptr, nwd.ptr if mode == 1 else None, 1e-5, mode)
-        L.check(lib.pi_op_mul_mat_multi(len(ws), wl, None if fused else q8.ptr, 1, ol, rl, None))
-        got.append([o.get(np.float32, (1, m)) for o, m in zip(outs, ms)])
-    for a, b, t in zip(got[0], got[1], types):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (O.TYPE_NAMES[t], float(np.abs(a - b).max()))
-        assert not np.any(b == 3.25)
-    # a request is consumed by the call it was made for: the next plain call needs its planes again
-    assert lib.pi_op_mul_mat_multi(len(ws), wl, None, 1, ol, None, None) != 0
-    for w in ws:
-        lib.pi_weight_free(w)
-
-
 def test_abort_word_stops_kernels_of_the_cancelled_run_only(gpu):
     """Kernel-granular early cancellation (reference: the abort callback polled between graph nodes, ggml.c:15748-15811, llama.cpp:5665-5687): every hot-path
     kernel launched under pi_set_abort_word reads (run id << 1 | aborted) on entry.  pi_op_abort_cancel is a compare-and-swap on the run id: it stops the run that
