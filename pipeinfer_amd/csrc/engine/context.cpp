@@ -383,17 +383,18 @@ static std::atomic<int> g_urgent{0}, g_credit{0};
 static void urgent_begin(llama_context * ctx) { if (ctx->stream_priority > 0) { ctx->urgent_pending++; g_urgent.fetch_add(1); } }
 static void urgent_end(llama_context * ctx) { if (ctx->urgent_pending > 0) { ctx->urgent_pending--; g_credit.store(1); g_urgent.fetch_sub(1); } }
 void urgent_drop_all(llama_context * ctx) { while (ctx->urgent_pending > 0) urgent_end(ctx); }
-static void yield_to_urgent(const llama_context * ctx) {
-    if (ctx->stream_priority > 0) return;
+static bool yield_to_urgent(const llama_context * ctx) {                      // true: it had to wait for an urgent run
+    if (ctx->stream_priority > 0 || g_urgent.load() <= 0) return false;
     // bounded: the claim is released when the CALLER finishes the urgent run, and a caller that blocks on THIS context's run first would wait for ever.
     // 50 ms is several times the longest legitimate wait (a draft step queued behind one 70B target segment, ~7 ms).
     const int64_t t0 = time_us();
     for (int spin = 0; g_urgent.load() > 0; spin++) {
         int c = g_credit.load();
-        if (c > 0 && g_credit.compare_exchange_strong(c, c - 1)) return;
+        if (c > 0 && g_credit.compare_exchange_strong(c, c - 1)) return true;
         if (spin < 4000) std::this_thread::yield();
-        else { if (time_us() - t0 > 50000) return; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+        else { if (time_us() - t0 > 50000) return true; std::this_thread::sleep_for(std::chrono::microseconds(20)); }
     }
+    return true;
 }
 
 // ---- feeder thread of a segmented context ---------------------------------------------------------------------------------------------------
@@ -469,10 +470,14 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
         ok = ok && meta != nullptr;
         const int nseg = n_segments(ctx), kv_head = ok ? ((const int32_t *) meta)[2 * n] : 0;
         if (ok) ok = launch_inputs(ctx, n, meta, nullptr);
-        int seg = 0;
+        // how often a pass stands aside for the priority (draft) context: the first speculative run after a verify has to be queued before the run in flight ends — that is
+        // worth pausing the target for; the chained runs continuous speculation drafts after it are mostly cancelled, and a draft step that merely interleaves with the
+        // target's kernels costs the target nothing.  PIPEINFER_YIELDS_PER_PASS (default 3 = one drafted tree of the bench recipe; -1: at every segment boundary)
+        static const int yield_budget = getenv("PIPEINFER_YIELDS_PER_PASS") ? atoi(getenv("PIPEINFER_YIELDS_PER_PASS")) : -1;
+        int seg = 0, yields = 0;
         for (; ok && seg < nseg; seg++) {
             if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
-            yield_to_urgent(ctx);
+            if (yield_budget < 0 || yields < yield_budget) yields += yield_to_urgent(ctx) ? 1 : 0;
             if (pass_cancelled(*pass)) break;                                   // llama_cancel_run reached every run of the pass while it was in flight
             ok = launch_abort_begin(ctx, pass->id);
             if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink, runs.size() > 1);
