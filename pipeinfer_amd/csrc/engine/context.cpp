@@ -437,8 +437,8 @@ static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
     const size_t need = (size_t) n * 8 + 16 + (size_t) n * 8 + (size_t) n * words * 4;
     if (need > ctx->pass_host_cap) {
         const size_t cap = std::max(need, (size_t) std::max(ctx->coalesce_max.load(), 1) * (16 + (size_t) words * 4) + 16);
+        (void) hipStreamSynchronize(ctx->stream);                              // (an earlier pass may still be copying out of the old blocks)
         for (uint8_t *& b : ctx->pass_host) { if (b) (void) hipHostFree(b); b = nullptr; }
-        (void) hipStreamSynchronize(ctx->stream);
         for (uint8_t *& b : ctx->pass_host) if (hipHostMalloc((void **) &b, cap, hipHostMallocDefault) != hipSuccess) { b = nullptr; ctx->last_error = "out of pinned host memory (pass staging)"; return nullptr; }
         ctx->pass_host_cap = cap;
     }
