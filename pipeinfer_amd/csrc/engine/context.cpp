@@ -470,16 +470,10 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
         ok = ok && meta != nullptr;
         const int nseg = n_segments(ctx), kv_head = ok ? ((const int32_t *) meta)[2 * n] : 0;
         if (ok) ok = launch_inputs(ctx, n, meta, nullptr);
-        // how often a pass stands aside for the priority (draft) context: the first speculative run after a verify has to be queued before the run in flight ends — that is
-        // worth pausing the target for; the chained runs continuous speculation drafts after it are mostly cancelled, and a draft step that merely interleaves with the
-        // target's kernels costs the target nothing.  PIPEINFER_YIELDS_PER_PASS (default 3 = one drafted tree of the bench recipe; -1: at every segment boundary)
-        static const bool segs_ahead_one = getenv("PIPEINFER_SEGS_AHEAD") && atoi(getenv("PIPEINFER_SEGS_AHEAD")) == 1;
-        static const int yield_budget = getenv("PIPEINFER_YIELDS_PER_PASS") ? atoi(getenv("PIPEINFER_YIELDS_PER_PASS")) : -1;
-        int seg = 0, yields = 0;
+        int seg = 0;
         for (; ok && seg < nseg; seg++) {
             if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
-            if (segs_ahead_one && seg >= 1) (void) hipEventSynchronize(seg_done[(seg - 1) & 1]);     // (tuning: one segment ahead — the GPU idles for the host's launch latency at every boundary)
-            if (yield_budget < 0 || yields < yield_budget) yields += yield_to_urgent(ctx) ? 1 : 0;
+            (void) yield_to_urgent(ctx);
             if (pass_cancelled(*pass)) break;                                   // llama_cancel_run reached every run of the pass while it was in flight
             ok = launch_abort_begin(ctx, pass->id);
             if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink, runs.size() > 1);
