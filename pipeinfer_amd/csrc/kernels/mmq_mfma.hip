@@ -50,6 +50,11 @@ int pi_mmq_min_nt() {
     return v;
 }
 extern "C" int pi_op_mmq_min_tokens(void) { return pi_mmq_min_nt(); }
+// tokens one launch of the matrix-core kernel walks: 32 (two chunks of 16 over one weight stream) unless PI_MMQ_CHUNKS=1
+int pi_mmq_max_nt() {
+    static const int v = [] { const char * e = getenv("PI_MMQ_CHUNKS"); return e && atoi(e) == 1 ? 16 : 32; }();
+    return v;
+}
 bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
 // accumulator lane and only wins from 5 tokens (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
@@ -82,8 +87,11 @@ template <int S> struct mq_q { uint4 v[2 / S]; };
 template <> struct mq_q<4> { uint2 v[1]; };
 template <int TYPE, int S> struct mq_w { uint32_t dd, rec, rec2; mq_q<S> q; mq_q<S> h; };       // one lane's share of one block: (d, dmin), its scales / mins record, 8 / S quant dwords (Q5_K: + as many dwords of fifth bits)
 
-template <int TYPE, int S, int R, int TB, bool NT8>
+// NC: chunks of 16 tokens per pass over the weights (prompt batches: NC = 2 walks 32 tokens with ONE weight stream — the operand of a (block, lane k) is built once and
+// fed to one MFMA per chunk; every chunk keeps its own chains, so each token's bits are those of a 16-token pass)
+template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
+    static_assert(NC == 1 || (NC == 2 && !NT8), "two chunks only for full 16-token chunks");
     static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
     constexpr bool Q5 = TYPE == PI_Q5_K, Q6 = TYPE == PI_Q6_K;
     constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q6 ? 1600 : Q5 ? 832 : 320;
@@ -91,7 +99,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if (pi_aborted(g.abort_w)) return;
     constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0) + (Q6 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
-    constexpr int FRAG = NT8 ? 512 : 1024, MQ_BLK_LDS = 8 * FRAG + 1024, NP = NT8 ? 5 : 9;   // NP: DMA pieces of 1 KB per block
+    constexpr int FRAG = NT8 ? 512 : 1024, CH_LDS = 8 * FRAG + 1024, MQ_BLK_LDS = NC * CH_LDS, NP1 = NT8 ? 5 : 9, NP = NC * NP1;   // NP: DMA pieces of 1 KB per block (all chunks)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
     const int r = lane & 15, gq = lane >> 4;                                              // weight row r, K-slice gq: sub-blocks 2gq, 2gq+1; C tile: tokens 4 gq ..
@@ -117,15 +125,18 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     asm volatile("" : "+v"(magic));
     const uint32_t own[4] = { gq == 0 ? 0xffffffffu : 0u, gq == 1 ? 0xffffffffu : 0u, gq == 2 ? 0xffffffffu : 0u, gq == 3 ? 0xffffffffu : 0u };
 
-    float acc[KS][4], accm[CS][4];
+    float acc[NC][KS][4], accm[NC][CS][4];
 #pragma unroll
-    for (int kk = 0; kk < KS; kk++)
+    for (int ch = 0; ch < NC; ch++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc[kk][i] = 0.0f;
+        for (int kk = 0; kk < KS; kk++)
 #pragma unroll
-    for (int cc = 0; cc < CS; cc++)
+            for (int i = 0; i < 4; i++) acc[ch][kk][i] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) accm[cc][i] = 0.0f;
+        for (int cc = 0; cc < CS; cc++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) accm[ch][cc][i] = 0.0f;
+    }
 
     // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = PI_MQ_TILE contiguous bytes
     const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * TILE;
@@ -159,13 +170,14 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             for (int i = 0; i < (NP * TB + NW - 1) / NW; i++) {
                 const int piece = i * NW + wave;
                 if (piece < NP * TB) {
-                    const int u = piece / NP, part = piece % NP;
+                    const int u = piece / NP, ch = (piece % NP) / NP1, part = piece % NP1;
                     const int b = T * TB + u < nb ? T * TB + u : nb - 1;
+                    const size_t cb = (size_t) ch * nb + b;                                   // chunk ch of this launch: its planes follow the first chunk's (pi_q8_frag_layout)
                     const uint8_t * src;
-                    if (part == NP - 1) src = g.aux + (size_t) b * 1024 + lane * 16;
-                    else if (NT8) src = g.frag + (((size_t) b * 8 + 2 * part + (lane >> 5)) * 64 + (lane & 7) + 16 * ((lane & 31) >> 3)) * 16;   // two fragments per piece, tokens 0..7 only
-                    else src = g.frag + ((size_t) b * 8 + part) * 1024 + lane * 16;
-                    const uint32_t dst = buf + u * MQ_BLK_LDS + part * 1024;
+                    if (part == NP1 - 1) src = g.aux + cb * 1024 + lane * 16;
+                    else if (NT8) src = g.frag + ((cb * 8 + 2 * part + (lane >> 5)) * 64 + (lane & 7) + 16 * ((lane & 31) >> 3)) * 16;   // two fragments per piece, tokens 0..7 only
+                    else src = g.frag + (cb * 8 + part) * 1024 + lane * 16;
+                    const uint32_t dst = buf + u * MQ_BLK_LDS + ch * CH_LDS + part * 1024;
                     uint32_t keep;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
                 }
@@ -183,11 +195,12 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     auto compute_q6 = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
         const int n = gq >> 1, hh = gq & 1;
         const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
-        const float4 dy4 = *(const float4 *) (blk + 8 * FRAG + 16 * gq);
-        const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
-        float d[4];
+        float d[NC][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) d[i] = dy[i] * dx;                                                     // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+        for (int ch = 0; ch < NC; ch++) {
+            const float4 dy4 = *(const float4 *) (blk + ch * CH_LDS + 8 * FRAG + 16 * gq);
+            d[ch][0] = dy4.x * dx; d[ch][1] = dy4.y * dx; d[ch][2] = dy4.z * dx; d[ch][3] = dy4.w * dx;   // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+        }
         const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
         const uint32_t aoff = (NT8 ? ((2 * n) * 8 + (r & 7)) : (r + 32 * n)) * 16 + 8 * hh;                // fragment lane (token, 2n), half hh; lane (token, 2n+1) is 16 lanes (NT8: 8) further
 #pragma unroll
@@ -207,13 +220,16 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             const uint32_t w3 = pk_add((q8 & 0x00F000F0u) | magic | ((h8 & 0x00300030u) << 4), 0xE600E600u);
             const uint4 b1 = make_uint4(pk_mul(w0, SHa), pk_mul(w1, SHa), pk_mul(w2, SHb), pk_mul(w3, SHb));
             const uint4 b2 = make_uint4(pk_mul(w0, SLa), pk_mul(w1, SLa), pk_mul(w2, SLb), pk_mul(w3, SLb));
-            const uint8_t * fr = blk + (s * KS + kk) * FRAG + aoff;
-            const uint2 a_lo = *(const uint2 *) fr, a_hi = *(const uint2 *) (fr + (NT8 ? 8 : 16) * 16);
-            const uint4 af = make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
-            pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b1), z, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b2), c, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[kk][i] = fmaf(d[i], c[i], acc[kk][i]);
+            for (int ch = 0; ch < NC; ch++) {
+                const uint8_t * fr = blk + ch * CH_LDS + (s * KS + kk) * FRAG + aoff;
+                const uint2 a_lo = *(const uint2 *) fr, a_hi = *(const uint2 *) (fr + (NT8 ? 8 : 16) * 16);
+                const uint4 af = make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
+                pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b1), z, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b2), c, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[ch][kk][i] = fmaf(d[ch][i], c[i], acc[ch][kk][i]);
+            }
         }
     };
     auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk, bool live) __attribute__((always_inline)) {
@@ -225,11 +241,14 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);                       // (s, s) of sub-block 2gq   (low nibbles)
         const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);          // (1024 + s) / 16 - 64 = s / 16 of sub-block 2gq+1 (high nibbles)
         const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);                                             // -1024 * s'
-        const float4 dy4 = *(const float4 *) (blk + 8 * FRAG + 16 * gq);                                                       // d of tokens 4 gq .. 4 gq + 3
-        const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
-        float d[4];
+        float dy[NC][4], d[NC][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) d[i] = dy[i] * dx;                                                     // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+        for (int ch = 0; ch < NC; ch++) {
+            const float4 dy4 = *(const float4 *) (blk + ch * CH_LDS + 8 * FRAG + 16 * gq);                                     // d of tokens 4 gq .. 4 gq + 3 of chunk ch
+            dy[ch][0] = dy4.x; dy[ch][1] = dy4.y; dy[ch][2] = dy4.z; dy[ch][3] = dy4.w;
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[ch][i] = dy[ch][i] * dx;                                         // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+        }
         const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) {
@@ -249,21 +268,26 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             bw.z = pk_fma((q & 0x00F000F0u) | magic, S2, C2);                                              // sub-block 2gq+1
             bw.w = pk_fma((qh & 0x00F000F0u) | magic, S2, C2);
             }
-            const uint4 af = *(const uint4 *) (blk + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));   // tokens' fragment of accumulator lane k
-            const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
-            if (dbg & 8) { acc[kk][0] += c[0] + c[1] + c[2] + c[3]; continue; }
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[kk][i] = fmaf(d[i], c[i], acc[kk][i]);                         // (float) sumi[k] of row r, token 4 gq + i
+            for (int ch = 0; ch < NC; ch++) {
+                const uint4 af = *(const uint4 *) (blk + ch * CH_LDS + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));   // tokens' fragment of accumulator lane k
+                const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
+                if (dbg & 8) { acc[ch][kk][0] += c[0] + c[1] + c[2] + c[3]; continue; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[ch][kk][i] = fmaf(d[ch][i], c[i], acc[ch][kk][i]);         // (float) sumi[k] of row r, token 4 gq + i
+            }
         }
         if (dbg & 8) return;
         // mins: acc_m[c] = fma(-y.d * dmin, (float) (m[2c]*(bs[4c]+bs[4c+1]) + m[2c+1]*(bs[4c+2]+bs[4c+3])), acc_m[c])   (ggml-quants.c:5339-5345)
         const uint32_t M0 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04020402u), 0xE400E400u);   // (m[2gq], m[2gq])
         const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);   // (m[2gq+1], m[2gq+1])
-        const uint2 bs = *(const uint2 *) (blk + 8 * FRAG + 64 + (NT8 ? (gq * 16 + (r & 7)) : lane) * 8);  // f16 (bs[4gq] .. bs[4gq+3]) of token r
+#pragma unroll
+        for (int ch = 0; ch < NC; ch++) {
+        const uint2 bs = *(const uint2 *) (blk + ch * CH_LDS + 8 * FRAG + 64 + (NT8 ? (gq * 16 + (r & 7)) : lane) * 8);  // f16 (bs[4gq] .. bs[4gq+3]) of token r
         const uint4 am = make_uint4(bs.x, bs.y, 0u, 0u);
         float nd[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) nd[i] = -dy[i] * dminx;
+        for (int i = 0; i < 4; i++) nd[i] = -dy[ch][i] * dminx;
         if constexpr (Q5) {
             // Q5_K (ggml-quants.c:5998-6002): ONE scalar chain, summs += dmin * (float) sum_j m_j * (bs[2j] + bs[2j+1]) — a multiply, then an add; every K-slice
             // contributes to the one product, so B is unmasked.  Wave 0 of the row group carries it.
@@ -271,7 +295,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
                 const uint4 bm = make_uint4(M0, M1, 0u, 0u);
                 const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; i++) { const float prod = nd[i] * cm[i]; accm[0][i] = accm[0][i] + prod; }
+                for (int i = 0; i < 4; i++) { const float prod = nd[i] * cm[i]; accm[ch][0][i] = accm[ch][0][i] + prod; }
             }
         } else {
 #pragma unroll
@@ -280,7 +304,8 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);                                 // only K-slice c contributes to chain c
             const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) accm[cc][i] = fmaf(nd[i], cm[i], accm[cc][i]);                     // the products are integers below 2^24: exact in any form
+            for (int i = 0; i < 4; i++) accm[ch][cc][i] = fmaf(nd[i], cm[i], accm[ch][cc][i]);             // the products are integers below 2^24: exact in any form
+        }
         }
         }
     };
@@ -315,7 +340,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
                 for (int u = 0; u < TB; u++) {
                     const int b = T * TB + u;
                     mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
-                    if (dbg & 1) acc[0][0] += __builtin_bit_cast(float, W.dd ^ W.rec ^ qdword(W, 0) ^ qdword(W, KS - 1));
+                    if (dbg & 1) acc[0][0][0] += __builtin_bit_cast(float, W.dd ^ W.rec ^ qdword(W, 0) ^ qdword(W, KS - 1));
                     else if (b < nb) compute(W, buf + u * MQ_BLK_LDS, true);
                     load_w(b + D, W);
                 }
@@ -329,58 +354,63 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (no DMA may still be writing LDS when the fold reuses it)
     __syncthreads();
 
-    // ---- fold: the eight chains of every (row, token) like hsum_float_8, the four mins chains like the reference's two hadds ----
+    // ---- fold: the eight chains of every (row, token) like hsum_float_8, the four mins chains like the reference's two hadds; chunk by chunk through the same LDS ----
     float * F = (float *) lds + (size_t) rgl * (8 * 16 * 17 + 4 * 16 * 17 + 256);       // [8 k][16 rows][17]
     float * FM = F + 8 * 16 * 17;                                                         // [4 c][16 rows][17]
     float * X = FM + 4 * 16 * 17;                                                         // [16 rows][16 tokens] results (RoPE epilogue)
-#pragma unroll
-    for (int kk = 0; kk < KS; kk++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) F[((s * KS + kk) * 16 + r) * 17 + 4 * gq + i] = acc[kk][i];
-#pragma unroll
-    for (int cc = 0; cc < CS; cc++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) FM[((s * CS + cc) * 16 + r) * 17 + 4 * gq + i] = accm[cc][i];
-    __syncthreads();
     const int tid_g = s * 64 + lane;                                                      // thread inside the row group
-    if (active) {
-        for (int idx = tid_g; idx < 256; idx += 64 * S) {
-            const int rr = idx >> 4, t = idx & 15;
-            float a[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) a[k] = F[(k * 16 + rr) * 17 + t];
-            float v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
-            const float m0 = FM[(0 * 16 + rr) * 17 + t], m1 = FM[(1 * 16 + rr) * 17 + t], m2 = FM[(2 * 16 + rr) * 17 + t], m3 = FM[(3 * 16 + rr) * 17 + t];
-            v = Q6 ? v : Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
-            if (rr < rows && t < nt) {
-                if (sg.store) X[rr * 16 + t] = v;
-                else {
-                    const int64_t o = (int64_t) t * sg.M + row0 + rr;
-                    sg.out[o] = sg.res ? sg.res[o] + v : v;
+    for (int ch = 0; ch < NC; ch++) {
+        const int ntc = nt - 16 * ch < 16 ? nt - 16 * ch : 16, tokc = g.tok0 + 16 * ch;  // tokens of this chunk, index of its first token in the pass
+        if (ch > 0) __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) F[((s * KS + kk) * 16 + r) * 17 + 4 * gq + i] = acc[ch][kk][i];
+#pragma unroll
+        for (int cc = 0; cc < CS; cc++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) FM[((s * CS + cc) * 16 + r) * 17 + 4 * gq + i] = accm[ch][cc][i];
+        __syncthreads();
+        if (active) {
+            for (int idx = tid_g; idx < 256; idx += 64 * S) {
+                const int rr = idx >> 4, t = idx & 15;
+                float a[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) a[k] = F[(k * 16 + rr) * 17 + t];
+                float v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+                const float m0 = FM[(0 * 16 + rr) * 17 + t], m1 = FM[(1 * 16 + rr) * 17 + t], m2 = FM[(2 * 16 + rr) * 17 + t], m3 = FM[(3 * 16 + rr) * 17 + t];
+                v = Q6 ? v : Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
+                if (rr < rows && t < ntc) {
+                    if (sg.store) X[rr * 16 + t] = v;
+                    else {
+                        const int64_t o = (int64_t) (16 * ch + t) * sg.M + row0 + rr;
+                        sg.out[o] = sg.res ? sg.res[o] + v : v;
+                    }
                 }
             }
         }
-    }
-    if (g.seg[0].store) {                                                                 // (a launch either stores all its segments through the epilogue or none)
-        // llm_build_kv_store / ggml_rope mode 0 (llama.cpp:3546-3577, ggml.c:11062-11163) as the epilogue of the projection, exactly as in
-        // k_mmvq_kq: rows 2i, 2i+1 of a head are neighbours in this row group; the rounding points are those of k_rope_kv
-        __syncthreads();
-        if (active) {
-            if (sg.store == 3) {
-                for (int j = tid_g; j < rows * nt; j += 64 * S) {
-                    const int rr = j / nt, t = j % nt;
-                    sg.dst16[(int64_t) pi_cell_of(g.dyn, g.kv_head, g.tok0 + t) * sg.stride16 + row0 + rr] = pi_f2h(X[rr * 16 + t]);
-                }
-            } else {
-                for (int j = tid_g; j < (rows / 2) * nt; j += 64 * S) {
-                    const int pr = j / nt, t = j % nt;
-                    const float x0 = X[(2 * pr) * 16 + t], x1 = X[(2 * pr + 1) * 16 + t];
-                    const int64_t rw = row0 + 2 * pr;
-                    const int i = (int) (rw % g.hd) >> 1;
-                    const float2 cs = *(const float2 *) (g.rope_cs + ((int64_t) g.pos[g.tok0 + t] * (g.hd / 2) + i) * 2);
-                    uint16_t * dd = sg.dst16 + (int64_t) (sg.store == 2 ? pi_cell_of(g.dyn, g.kv_head, g.tok0 + t) : g.tok0 + t) * sg.stride16 + rw;
-                    dd[0] = pi_f2h(x0 * cs.x - x1 * cs.y);
-                    dd[1] = pi_f2h(x0 * cs.y + x1 * cs.x);
+        if (g.seg[0].store) {                                                             // (a launch either stores all its segments through the epilogue or none)
+            // llm_build_kv_store / ggml_rope mode 0 (llama.cpp:3546-3577, ggml.c:11062-11163) as the epilogue of the projection, exactly as in
+            // k_mmvq_kq: rows 2i, 2i+1 of a head are neighbours in this row group; the rounding points are those of k_rope_kv
+            __syncthreads();
+            if (active && ntc > 0) {
+                if (sg.store == 3) {
+                    for (int j = tid_g; j < rows * ntc; j += 64 * S) {
+                        const int rr = j / ntc, t = j % ntc;
+                        sg.dst16[(int64_t) pi_cell_of(g.dyn, g.kv_head, tokc + t) * sg.stride16 + row0 + rr] = pi_f2h(X[rr * 16 + t]);
+                    }
+                } else {
+                    for (int j = tid_g; j < (rows / 2) * ntc; j += 64 * S) {
+                        const int pr = j / ntc, t = j % ntc;
+                        const float x0 = X[(2 * pr) * 16 + t], x1 = X[(2 * pr + 1) * 16 + t];
+                        const int64_t rw = row0 + 2 * pr;
+                        const int i = (int) (rw % g.hd) >> 1;
+                        const float2 cs = *(const float2 *) (g.rope_cs + ((int64_t) g.pos[tokc + t] * (g.hd / 2) + i) * 2);
+                        uint16_t * dd = sg.dst16 + (int64_t) (sg.store == 2 ? pi_cell_of(g.dyn, g.kv_head, tokc + t) : tokc + t) * sg.stride16 + rw;
+                        dd[0] = pi_f2h(x0 * cs.x - x1 * cs.y);
+                        dd[1] = pi_f2h(x0 * cs.y + x1 * cs.x);
+                    }
                 }
             }
         }
@@ -389,26 +419,29 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 
 #include <hip/hip_ext.h>
 
-template <int TYPE, int S, int R, int TB, bool NT8>
+template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1>
 static void mmq_go2(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    constexpr size_t tiles = (size_t) 3 * TB * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
+    constexpr size_t tiles = (size_t) 3 * TB * NC * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
     static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
-    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB, NT8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB, NT8, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
     const unsigned grid = (unsigned) ((groups + R - 1) / R);
-    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
-    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8, NC>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
+    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8, NC>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
 }
-// batches of <= 8 tokens stage half the fragment bytes and take twice the blocks per tile (TB8) in the same LDS
+// batches of <= 8 tokens stage half the fragment bytes and take twice the blocks per tile (TB8) in the same LDS; 17..32 tokens are two chunks over one weight
+// stream, one block per tile (the three tiles of two chunks are 54 KB)
 template <int TYPE, int S, int R, int TB16, int TB8>
 static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     if (g.nt <= 8) mmq_go2<TYPE, S, R, TB8, true>(g, groups, stream, ea, eb);
-    else           mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
+    else if (g.nt <= 16) mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
+    else if constexpr (S >= 2) mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
 }
 
 template <int TYPE>
 static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     constexpr int T8 = TYPE == PI_Q4_K ? 4 : 2;                 // blocks per tile at <= 8 tokens (Q5_K: the ring carries the fifth bits too)
+    if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14)) cfg = 24;      // two chunks double the chains a wave carries: the one-wave row groups (96 accumulators) would spill
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;
@@ -431,7 +464,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     static bool done = false;
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
-    for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
     done = true;
     PI_CHECK_LAUNCH();
     return 0;

@@ -1019,7 +1019,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
     if (mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
-    const int step = mfma ? 16 : 8;
+    const int step = mfma ? (n_tok > 16 ? pi_mmq_max_nt() : 16) : 8;
     for (int t0 = 0; t0 < n_tok; t0 += step) {
         const int nt = n_tok - t0 < step ? n_tok - t0 : step;
         mmvq_launch L;

@@ -64,6 +64,7 @@ const pi_tables & pi_get_tables();
 // smallest batch width that takes the MFMA kernel (mmq_mfma.hip) instead of the VALU mat-vec; the quantisers write its operand
 // planes from the same width on.  PI_MMQ_MIN_NT overrides (tuning / A-B tests; read once).
 int pi_mmq_min_nt();
+int pi_mmq_max_nt();
 
 static inline bool pi_type_is_legacy(int t) { return t == PI_Q4_1 || t == PI_Q5_0 || t == PI_Q5_1; }
 static inline int pi_type_blck(int t) {

@@ -115,6 +115,8 @@ def test_mul_mat_golden_blocks(gpu, t):
                                           (4096, 64, 16), (4096, 49, 9), (8192, 2064, 12), (28672, 40, 16), (2048, 16, 2), (512, 4100, 13), (4096, 80, 17), (1024, 32, 37),
                                           # ... batches of <= 8 tokens reach it from rows x tokens >= 16384 (half-size fragments); 513..768 row groups run three to a workgroup
                                           (512, 4100, 5), (1024, 2100, 8), (256, 5500, 3), (512, 9222, 5), (256, 8200, 3), (768, 12288, 16), (512, 12000, 2),
+                                          # ... 17..32 tokens: two chunks of 16 over ONE weight stream (every waves-per-row-group choice; a ragged second chunk; prompts in steps of 32)
+                                          (4096, 2064, 32), (2048, 9000, 24), (1024, 14000, 33), (512, 20000, 32), (768, 12288, 48), (256, 30000, 31), (8192, 130, 64), (1024, 6200, 18),
                                           # Q4_0 / Q8_0 range-per-wave kernel: 4, 8, 12 groups per wave, ragged last wave, rows not a multiple of 8
                                           (1024, 19, 1), (4544, 71, 1), (4544, 71, 2), (16384, 9, 1), (18176, 13, 1), (24576, 11, 1), (24576, 11, 2), (32768, 8, 1)])
 def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
@@ -406,7 +408,8 @@ def test_mul_mat_multi_equals_single_launches(gpu, wtype, n_tok):
 
 @pytest.mark.parametrize("types", [(O.Q4_K, O.Q4_K, O.Q4_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q5_K, O.Q6_K, O.Q4_K)])
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,kv_head", [(128, 8, 8, 1, 5), (64, 8, 2, 3, 0), (128, 4, 1, 8, 17), (64, 4, 4, 11, 2),
-                                                               (128, 64, 8, 1, 3), (128, 64, 8, 2, 9), (128, 64, 8, 4, 1), (128, 40, 40, 1, 0)])   # K = 8192 / 5120: the tile-per-wave instance with the RoPE epilogue
+                                                               (128, 64, 8, 1, 3), (128, 64, 8, 2, 9), (128, 64, 8, 4, 1), (128, 40, 40, 1, 0),    # K = 8192 / 5120: the tile-per-wave instance with the RoPE epilogue
+                                                               (64, 4, 4, 20, 2), (128, 64, 8, 32, 1), (64, 8, 2, 27, 5)])                            # two chunks of 16 per launch of the matrix-core kernel
 def test_qkv_rope_epilogue_equals_separate_launches(gpu, types, hd, n_head, n_head_kv, n_tok, kv_head):
     """RoPE + f16 rounding + KV-cache writes done by the projection's own waves == mat-vecs into fp32 + pi_op_rope_kv_store"""
     lib, U = gpu
