@@ -100,6 +100,9 @@ PI_API int pi_op_mul_mat_multi(int n_w, const pi_weight * const * ws, const void
 
 /* RoPE tables as the reference iterates them: cos/sin [n_pos][head_dim/2] f32, built on the host (theta *= theta_scale) */
 PI_API void *  pi_rope_table_create(int n_pos, int head_dim, float freq_base, float freq_scale, int neox);
+/* NeoX mode with n_rot < head_dim (StableLM, llama.cpp:4860-4871): the reference walks head_dim / n_rot blocks of n_rot values, pairs (i, i + n_rot/2) inside a block,
+ * theta_scale = freq_base^(-2/n_rot) and theta keeps advancing across the blocks (ggml.c:11133-11160) */
+PI_API void *  pi_rope_table_create_ex(int n_pos, int head_dim, int n_rot, float freq_base, float freq_scale, int neox);
 PI_API void    pi_rope_table_free(void * table);
 /* q/k/v: f32 rows of n_head*hd / n_head_kv*hd values per token, *_stride floats apart (a fused QKV output is passed as three
  * views); writes roped Q as f16 [n_tok][n_head*hd]; K and V as f16 rows of the layer's cache at cells kv_head..
@@ -117,6 +120,12 @@ PI_API int pi_op_attention(const uint16_t * q16_dev, const uint16_t * k_cache_de
  * has_table set every token attends over the n_kv of ITS run (kv_self.n at that run's start, llama.cpp:5571) */
 PI_API int pi_op_attention_ex(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
                               int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, const int32_t * dyn_dev, int per_token_kv, void * stream);
+/* ... with ALiBi (llm_build_kqv with max_alibi_bias > 0, llama.cpp:3735-3740; ggml_compute_forward_alibi_f32, ggml.c:10736-10793): score = i * m_k + kq * scale, i the cell's index in
+ * the n_kv view, m_k the slope of query head k.  alibi_slopes_dev: f32 [n_head] (pi_alibi_slopes writes the host values), nullable = no bias */
+PI_API void pi_alibi_slopes(int n_head, float max_bias, float * out_host);
+PI_API int pi_op_attention_alibi(const uint16_t * q16_dev, const uint16_t * k_cache_dev, const uint16_t * v_cache_dev, const uint32_t * mask_dev,
+                                 int head_dim, int n_head, int n_head_kv, int n_tok, int n_kv, float * out_dev, const int32_t * dyn_dev, int per_token_kv,
+                                 const float * alibi_slopes_dev, void * stream);
 PI_API int pi_op_mmq_min_tokens(void);                             /* narrowest batch that pi_op_mul_mat sends to the matrix-core kernel (and its tile-major weight copies) */
 PI_API int pi_op_mul_mat_reserve(void);                            /* once per process, outside graph capture: dynamic-LDS limits of the matrix-core kernels */
 PI_API int pi_op_attention_max_cells(void);                       /* longest context the attention kernel serves (one score row per workgroup in LDS): 36 200 cells */
@@ -124,6 +133,10 @@ PI_API int pi_op_attention_reserve(int head_dim, int n_kv_max);   /* once per co
 PI_API int pi_op_silu_mul(const float * gate_dev, const float * up_dev, float * out_dev, int64_t n, void * stream);
 PI_API int pi_op_gelu(const float * x_dev, float * out_dev, int64_t n, void * stream);
 PI_API int pi_op_add(const float * a_dev, const float * b_dev, float * out_dev, int64_t n, void * stream);
+/* ggml_add with a row broadcast (the bias of a projection, llama.cpp:3628-3630, 3770-3772): x[t][i] += b[i] */
+PI_API int pi_op_add_bias(float * x_dev, const float * b_dev, int64_t n, int n_tok, void * stream);
+/* ggml_clamp (ggml.c:10893-10931: MAX(MIN(x, max), min); MPT's clamp_kqv, llama.cpp:4755-4757) in place */
+PI_API int pi_op_clamp(float * x_dev, float lo, float hi, int64_t n, void * stream);
 /* per token: ids/logits of the k largest (logit desc, id asc), max logit and sum_i expf(l_i - max) over the full vocab */
 PI_API size_t pi_op_topk_scratch_bytes(int n_tok);                  /* caller-owned scratch, one per stream */
 PI_API int pi_op_topk(const float * logits_dev, int n_vocab, int n_tok, int k, int32_t * ids_dev, float * vals_dev, float * sumexp_dev, void * scratch_dev, void * stream);

@@ -30,6 +30,9 @@ struct o_model {
     int n_tensors; o_tensor * tensors;
     int is_falcon, n_layer, n_embd, n_head, n_head_kv, n_ff, n_vocab, n_ctx;
     float eps, freq_base;
+    // the other builders (build_baichuan / _starcoder / _refact / _bloom / _mpt / _stablelm, llama.cpp:3985-4939) as one sequential block
+    int generic, rms, fused_qkv, rope_mode /* -1 none, 0, 2 */, gated, n_rot;
+    float alibi, clamp_kqv;
     o_kv_cache * kv;
     uint16_t * k_cache, * v_cache;     // per layer: K [n_ctx][n_embd_gqa], V [n_embd_gqa][n_ctx]  (llama.cpp:1529-1560, 3565-3576)
 };
@@ -79,6 +82,7 @@ o_model * o_model_load(const char * path, int n_ctx, int max_seq) {
     const uint64_t n_tensors = rd_u64(&r), n_kv = rd_u64(&r);
     char arch[64] = "llama";
     uint32_t alignment = 32;
+    float max_alibi = 0.0f, clamp_kqv = 0.0f;
     m->freq_base = 10000.0f; m->n_head_kv = -1;
     for (uint64_t i = 0; i < n_kv; i++) {
         char key[256]; rd_str(&r, key, sizeof key);
@@ -94,16 +98,29 @@ o_model * o_model_load(const char * path, int n_ctx, int max_seq) {
             else if (!strcmp(sub, "feed_forward_length"))      m->n_ff = v;
             else if (!strcmp(sub, "attention.head_count"))     m->n_head = v;
             else if (!strcmp(sub, "attention.head_count_kv"))  m->n_head_kv = v;
+            else if (!strcmp(sub, "rope.dimension_count"))     m->n_rot = v;
         }
         if (type == 6 && dot) {
             rd peek = r; float v; memcpy(&v, peek.p, 4);
             if (!strcmp(sub, "attention.layer_norm_rms_epsilon") || !strcmp(sub, "attention.layer_norm_epsilon")) m->eps = v;
             else if (!strcmp(sub, "rope.freq_base")) m->freq_base = v;
+            else if (!strcmp(sub, "attention.max_alibi_bias")) max_alibi = v;
+            else if (!strcmp(sub, "attention.clamp_kqv")) clamp_kqv = v;
         }
         skip_value(&r, type);
     }
     m->is_falcon = strcmp(arch, "falcon") == 0;
     if (m->n_head_kv < 0) m->n_head_kv = m->n_head;
+    if (!m->n_rot) m->n_rot = m->n_embd / m->n_head;                          // llama.cpp:2265-2267
+    m->rope_mode = -1;
+    if (!strcmp(arch, "baichuan")) {                                          // 7B (32 layers) rotates, 13B (40) has ALiBi (llama.cpp:4030-4063)
+        m->generic = m->rms = m->gated = 1;
+        if (m->n_layer == 32) m->rope_mode = 0; else m->alibi = 8.0f;
+    } else if (!strcmp(arch, "refact"))    { m->generic = m->rms = m->gated = 1; m->alibi = 8.0f; }
+    else if (!strcmp(arch, "starcoder"))   { m->generic = m->fused_qkv = 1; }
+    else if (!strcmp(arch, "bloom"))       { m->generic = m->fused_qkv = 1; m->alibi = 8.0f; }
+    else if (!strcmp(arch, "mpt"))         { m->generic = m->fused_qkv = 1; m->alibi = max_alibi; m->clamp_kqv = clamp_kqv; }
+    else if (!strcmp(arch, "stablelm"))    { m->generic = m->gated = 1; m->rope_mode = 2; }
     m->n_tensors = (int) n_tensors;
     m->tensors = calloc(n_tensors, sizeof(o_tensor));
     uint64_t * offs = calloc(n_tensors, 8);
@@ -169,7 +186,14 @@ static void norm_wb(const float * x, float * y, int n, int rows, int rms, float 
     }
 }
 
-// build_llama (llama.cpp:3872-3983) / build_falcon (llama.cpp:4106-4227)
+// ggml_add of a row vector to every token's row (the projections' biases, llama.cpp:3628-3630, 3770-3772); no-op without the tensor
+static void add_bias(float * x, const o_tensor * b, int n, int rows) {
+    if (!b) return;
+    const float * bd = b->data;
+    for (int r = 0; r < rows; r++) for (int i = 0; i < n; i++) x[(size_t) r * n + i] = x[(size_t) r * n + i] + bd[i];
+}
+
+// build_llama (llama.cpp:3872-3983) / build_falcon (llama.cpp:4106-4227) / the sequential block of the six other builders (llama.cpp:3985-4939)
 int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, int n_tok, int kv_head, int n_kv, const float * mask, float * logits) {
     const int n_embd = m->n_embd, hd = n_embd / m->n_head, n_embd_gqa = hd * m->n_head_kv, n_ff = m->n_ff;
     const size_t T = n_tok;
@@ -183,7 +207,61 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
     o_get_rows(te->type, te->data, n_embd, tokens, n_tok, inpL);
     const size_t kv_layer = (size_t) m->n_ctx * n_embd_gqa;
 
+    if (find_tensor(m, "position_embd.weight")) {                            // build_starcoder (llama.cpp:4251-4255)
+        const o_tensor * pe = find_tensor(m, "position_embd.weight");
+        o_get_rows(pe->type, pe->data, n_embd, pos, n_tok, cur);
+        for (size_t i = 0; i < T * n_embd; i++) inpL[i] = inpL[i] + cur[i];
+    }
+    if (find_tensor(m, "token_embd_norm.weight")) {                          // build_bloom (llama.cpp:4650-4654)
+        norm_wb(inpL, cur, n_embd, n_tok, 0, m->eps, find_tensor(m, "token_embd_norm.weight"), find_tensor(m, "token_embd_norm.bias"));
+        memcpy(inpL, cur, 4 * T * n_embd);
+    }
+
     for (int il = 0; il < m->n_layer; il++) {
+        if (m->generic) {
+            const int nq = n_embd + 2 * n_embd_gqa;
+            norm_wb(inpL, cur, n_embd, n_tok, m->rms, m->eps, layer_tensor(m, il, "attn_norm.weight", 1), layer_tensor(m, il, "attn_norm.bias", 0));
+            if (m->fused_qkv) {
+                mm(layer_tensor(m, il, "attn_qkv.weight", 1), cur, n_tok, qkv);
+                add_bias(qkv, layer_tensor(m, il, "attn_qkv.bias", 0), nq, n_tok);
+                if (m->clamp_kqv > 0.0f) for (size_t i = 0; i < T * nq; i++) { const float lo = qkv[i] < m->clamp_kqv ? qkv[i] : m->clamp_kqv; qkv[i] = lo > -m->clamp_kqv ? lo : -m->clamp_kqv; }   // MAX(MIN(x, max), min), ggml.c:10928
+                for (size_t t = 0; t < T; t++) {
+                    memcpy(Q + t * n_embd,     qkv + t * nq,                       4 * (size_t) n_embd);
+                    memcpy(K + t * n_embd_gqa, qkv + t * nq + n_embd,              4 * (size_t) n_embd_gqa);
+                    memcpy(V + t * n_embd_gqa, qkv + t * nq + n_embd + n_embd_gqa, 4 * (size_t) n_embd_gqa);
+                }
+            } else {
+                mm(layer_tensor(m, il, "attn_q.weight", 1), cur, n_tok, Q);
+                mm(layer_tensor(m, il, "attn_k.weight", 1), cur, n_tok, K);
+                mm(layer_tensor(m, il, "attn_v.weight", 1), cur, n_tok, V);
+            }
+            trace("q", il, Q, n_embd, n_tok); trace("k", il, K, n_embd_gqa, n_tok); trace("v", il, V, n_embd_gqa, n_tok);
+            if (m->rope_mode >= 0) {
+                o_rope_ex(Q, Qr, hd, m->rope_mode == 2 ? m->n_rot : hd, m->n_head,    n_tok, pos, m->rope_mode, m->freq_base, 1.0f);
+                o_rope_ex(K, Kr, hd, m->rope_mode == 2 ? m->n_rot : hd, m->n_head_kv, n_tok, pos, m->rope_mode, m->freq_base, 1.0f);
+            } else { memcpy(Qr, Q, 4 * T * n_embd); memcpy(Kr, K, 4 * T * n_embd_gqa); }
+            o_attention_alibi(m->k_cache + il * kv_layer, m->v_cache + il * kv_layer, m->n_ctx, Qr, Kr, V, mask, hd, m->n_head, m->n_head_kv, n_tok, kv_head, n_kv, m->alibi, att);
+            trace("att", il, att, n_embd, n_tok);
+            mm(layer_tensor(m, il, "attn_output.weight", 1), att, n_tok, cur);
+            add_bias(cur, layer_tensor(m, il, "attn_output.bias", 0), n_embd, n_tok);
+            for (size_t i = 0; i < T * n_embd; i++) ffn_inp[i] = cur[i] + inpL[i];
+            trace("ffn_inp", il, ffn_inp, n_embd, n_tok);
+            norm_wb(ffn_inp, cur, n_embd, n_tok, m->rms, m->eps, layer_tensor(m, il, "ffn_norm.weight", 1), layer_tensor(m, il, "ffn_norm.bias", 0));
+            mm(layer_tensor(m, il, "ffn_up.weight", 1), cur, n_tok, up);          // llm_build_ffn (llama.cpp:3611-3695)
+            add_bias(up, layer_tensor(m, il, "ffn_up.bias", 0), n_ff, n_tok);
+            if (m->gated) {
+                mm(layer_tensor(m, il, "ffn_gate.weight", 1), cur, n_tok, gate);
+                o_silu(gate, gate, (int) (T * n_ff));
+                for (size_t i = 0; i < T * n_ff; i++) gate[i] = gate[i] * up[i];
+            } else {
+                o_gelu(up, gate, (int) (T * n_ff));
+            }
+            mm(layer_tensor(m, il, "ffn_down.weight", 1), gate, n_tok, tmp);
+            add_bias(tmp, layer_tensor(m, il, "ffn_down.bias", 0), n_embd, n_tok);
+            for (size_t i = 0; i < T * n_embd; i++) inpL[i] = tmp[i] + ffn_inp[i];
+            trace("lout", il, inpL, n_embd, n_tok);
+            continue;
+        }
         if (!m->is_falcon) {
             norm_wb(inpL, cur, n_embd, n_tok, 1, m->eps, layer_tensor(m, il, "attn_norm.weight", 1), NULL);
             mm(layer_tensor(m, il, "attn_q.weight", 1), cur, n_tok, Q);
@@ -231,8 +309,9 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
             trace("lout", il, inpL, n_embd, n_tok);
         }
     }
-    if (m->is_falcon) norm_wb(inpL, cur, n_embd, n_tok, 0, m->eps, find_tensor(m, "output_norm.weight"), find_tensor(m, "output_norm.bias"));
-    else              norm_wb(inpL, cur, n_embd, n_tok, 1, m->eps, find_tensor(m, "output_norm.weight"), NULL);
+    if (m->generic)        norm_wb(inpL, cur, n_embd, n_tok, m->rms, m->eps, find_tensor(m, "output_norm.weight"), find_tensor(m, "output_norm.bias"));
+    else if (m->is_falcon) norm_wb(inpL, cur, n_embd, n_tok, 0, m->eps, find_tensor(m, "output_norm.weight"), find_tensor(m, "output_norm.bias"));
+    else                   norm_wb(inpL, cur, n_embd, n_tok, 1, m->eps, find_tensor(m, "output_norm.weight"), NULL);
     mm(find_tensor(m, "output.weight"), cur, n_tok, logits);
     free(inpL); free(cur); free(attn_norm); free(qkv); free(Q); free(K); free(V); free(Qr); free(Kr);
     free(att); free(ffn_inp); free(up); free(gate); free(tmp);

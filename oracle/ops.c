@@ -59,7 +59,11 @@ void o_norm(const float * x, float * y, int n, int rows, float eps) {
 
 // ggml.c:11006-11168 with ext_factor = 0, attn_factor = 1 (all configs): theta advances by repeated multiplication
 void o_rope(const float * x, float * y, int head_dim, int n_head, int n_tok, const int32_t * pos, int mode, float freq_base, float freq_scale) {
-    const int n_dims = head_dim;
+    o_rope_ex(x, y, head_dim, head_dim, n_head, n_tok, pos, mode, freq_base, freq_scale);
+}
+// n_dims < head_dim (StableLM's partial rotary, llama.cpp:4860-4871) exists in NeoX mode only: the reference walks head_dim / n_dims blocks and
+// theta keeps advancing from block to block (ggml.c:11133-11160)
+void o_rope_ex(const float * x, float * y, int head_dim, int n_dims, int n_head, int n_tok, const int32_t * pos, int mode, float freq_base, float freq_scale) {
     const float theta_scale = powf(freq_base, -2.0f / n_dims);
     const int is_neox = mode & 2;
     for (int t = 0; t < n_tok; t++) {
@@ -78,11 +82,12 @@ void o_rope(const float * x, float * y, int head_dim, int n_head, int n_tok, con
                 }
             } else {
                 theta_base *= freq_scale;                                     // ggml.c:11136
+                for (int ib = 0; ib < head_dim / n_dims; ib++)
                 for (int ic = 0; ic < n_dims; ic += 2) {
                     const float theta = freq_scale * theta_base;            // (the reference applies freq_scale twice here)
                     const float cos_theta = cosf(theta) * 1.0f, sin_theta = sinf(theta) * 1.0f;
                     theta_base *= theta_scale;
-                    const int i0 = ic / 2;
+                    const int i0 = ib * n_dims + ic / 2;
                     const float x0 = src[i0], x1 = src[i0 + n_dims / 2];
                     dst[i0]              = x0 * cos_theta - x1 * sin_theta;
                     dst[i0 + n_dims / 2] = x0 * sin_theta + x1 * cos_theta;
@@ -165,6 +170,13 @@ void o_get_rows(int type, const void * w, int ne00, const int32_t * ids, int n, 
 // Reference layouts: K rows [cell][n_embd_gqa] f16; V transposed [n_embd_gqa][n_ctx] f16.
 void o_attention(uint16_t * k_cache, uint16_t * v_cache, int n_ctx, const float * q_cur, const float * k_cur, const float * v_cur,
                  const float * mask, int hd, int n_head, int n_head_kv, int n_tok, int kv_head, int n_kv, float * out) {
+    o_attention_alibi(k_cache, v_cache, n_ctx, q_cur, k_cur, v_cur, mask, hd, n_head, n_head_kv, n_tok, kv_head, n_kv, 0.0f, out);
+}
+// max_alibi_bias > 0: ggml_alibi between the scale and the mask (llama.cpp:3735-3740; ggml_compute_forward_alibi_f32, ggml.c:10736-10793)
+void o_attention_alibi(uint16_t * k_cache, uint16_t * v_cache, int n_ctx, const float * q_cur, const float * k_cur, const float * v_cur,
+                       const float * mask, int hd, int n_head, int n_head_kv, int n_tok, int kv_head, int n_kv, float max_alibi_bias, float * out) {
+    const int n_heads_log2_floor = 1 << (int) floor(log2(n_head));
+    const float m0 = powf(2.0f, -(max_alibi_bias) / n_heads_log2_floor), m1 = powf(2.0f, -(max_alibi_bias / 2.0f) / n_heads_log2_floor);
     const int n_embd = hd * n_head, n_embd_gqa = hd * n_head_kv, r = n_head / n_head_kv;
     for (int t = 0; t < n_tok; t++) {
         for (int e = 0; e < n_embd_gqa; e++) {
@@ -183,6 +195,10 @@ void o_attention(uint16_t * k_cache, uint16_t * v_cache, int n_ctx, const float 
             for (int i = 0; i < n_kv; i++) {
                 float s = o_vec_dot_f16(hd, k_cache + (size_t) i * n_embd_gqa + (h / r) * hd, q16);
                 s = s * scale;
+                if (max_alibi_bias > 0.0f) {
+                    const float m_k = h < n_heads_log2_floor ? powf(m0, h + 1) : powf(m1, 2 * (h - n_heads_log2_floor) + 1);
+                    s = i * m_k + s;                                         // ggml.c:10789
+                }
                 kq[i] = s + mask[(size_t) t * n_kv + i];
             }
             o_soft_max(kq, kq, n_kv, 1);

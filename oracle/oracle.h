@@ -68,6 +68,8 @@ ORACLE_API void     o_rms_norm(const float * x, float * y, int n, int rows, floa
 ORACLE_API void     o_norm(const float * x, float * y, int n, int rows, float eps);
 ORACLE_API void     o_rope(const float * x, float * y, int head_dim, int n_head, int n_tok, const int32_t * pos,
                            int mode, float freq_base, float freq_scale);
+ORACLE_API void     o_rope_ex(const float * x, float * y, int head_dim, int n_dims, int n_head, int n_tok, const int32_t * pos,
+                              int mode, float freq_base, float freq_scale);       // n_dims < head_dim: NeoX blocks (ggml.c:11133-11160)
 ORACLE_API void     o_soft_max(const float * x, float * y, int nc, int nr);
 ORACLE_API void     o_silu(const float * x, float * y, int n);
 ORACLE_API void     o_gelu(const float * x, float * y, int n);
@@ -77,6 +79,9 @@ ORACLE_API void     o_get_rows(int type, const void * w, int ne00, const int32_t
 ORACLE_API void     o_attention(uint16_t * k_cache, uint16_t * v_cache, int n_ctx,
                                 const float * q_cur, const float * k_cur, const float * v_cur, const float * mask,
                                 int head_dim, int n_head, int n_head_kv, int n_tok, int kv_head, int n_kv, float * out);
+ORACLE_API void     o_attention_alibi(uint16_t * k_cache, uint16_t * v_cache, int n_ctx,
+                                const float * q_cur, const float * k_cur, const float * v_cur, const float * mask,
+                                int head_dim, int n_head, int n_head_kv, int n_tok, int kv_head, int n_kv, float max_alibi_bias, float * out);
 
 // ---- kvcache.c ------------------------------------------------------------------------------------------
 typedef struct o_kv_cache o_kv_cache;

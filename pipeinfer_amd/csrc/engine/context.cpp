@@ -95,10 +95,11 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     const size_t kv_elems = (size_t) n_layer_local * ctx->n_ctx * n_gqa;
     if (!(ctx->k_cache = (uint16_t *) dev(kv_elems * 2)) || !(ctx->v_cache = (uint16_t *) dev(kv_elems * 2))) return false;
     pi_memset(ctx->k_cache, 0, kv_elems * 2, nullptr); pi_memset(ctx->v_cache, 0, kv_elems * 2, nullptr);   // llama.cpp:1543 memset(cache.buf, 0)
-    const int neox = hp.arch == PI_ARCH_FALCON;
+    // rotation mode of the context's table: 0 pairs (2i, 2i+1), 1 NeoX over n_rot values, -1 none (identity table: ALiBi or learned positions)
+    const int neox = hp.arch == PI_ARCH_FALCON ? 1 : !hp.generic() ? 0 : hp.block.rope == 2 ? 1 : hp.block.rope == 0 ? 0 : -1;
     const float freq_base  = ctx->cparams.rope_freq_base  == 0.0f ? hp.rope_freq_base_train  : ctx->cparams.rope_freq_base;     // llama.cpp:8729-8731
     const float freq_scale = ctx->cparams.rope_freq_scale == 0.0f ? hp.rope_freq_scale_train : ctx->cparams.rope_freq_scale;
-    if (!(ctx->rope = pi_rope_table_create(std::max(ctx->n_ctx, 32), hp.head_dim(), freq_base, freq_scale, neox))) { err = pi_last_error(); return false; }
+    if (!(ctx->rope = pi_rope_table_create_ex(std::max(ctx->n_ctx, 32), hp.head_dim(), neox == 1 ? hp.n_rot : hp.head_dim(), freq_base, freq_scale, neox))) { err = pi_last_error(); return false; }
     const size_t qkv_w = (size_t) n_embd + 2 * n_gqa;
     const size_t kmax = (size_t) std::max(n_embd, n_ff);
     const size_t q8_bytes = std::max(pi_q8_nbytes(PI_Q8_K, (int64_t) ((kmax + 255) / 256 * 256), nb), std::max(pi_q8_nbytes(PI_Q8_0, (int64_t) kmax, nb), pi_q8_nbytes(PI_Q8_1, (int64_t) kmax, nb)));
@@ -203,7 +204,14 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
     const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff, hd = hp.head_dim();
     hipStream_t s = ctx->stream;
     float * x = ctx->x, * x2 = ctx->x2;
-    if (head && ctx->is_first) OP_OK(pi_op_get_rows(m->tok_embd, ctx->tokens_dev, n_tok, x, s));
+    if (head && ctx->is_first) {
+        OP_OK(pi_op_get_rows(m->tok_embd, ctx->tokens_dev, n_tok, x, s));
+        if (m->pos_embd) {                                                                                          // build_starcoder: inpL + get_rows(pos_embd, inp_pos) (llama.cpp:4251-4255)
+            OP_OK(pi_op_get_rows(m->pos_embd, ctx->pos_dev, n_tok, ctx->att, s));
+            OP_OK(pi_op_add(x, ctx->att, x, (int64_t) n_tok * n_embd, s));
+        }
+        if (m->tok_norm) OP_OK(pi_op_norm(x, m->tok_norm, m->tok_norm_b, x, n_embd, n_tok, hp.f_norm_eps, 0, s));   // build_bloom: LayerNorm of the embeddings (llama.cpp:4650-4654)
+    }
     const size_t kv_layer = (size_t) ctx->n_ctx * n_gqa;
     for (int il = la; il < lb; il++) {
         const pi_layer & L = m->layers[il];
@@ -243,6 +251,64 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
             OP_OK(pi_op_act_quantize(ctx->gate, ctx->up, 0, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));        // silu(gate) * up
             OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, x2, s));                                             // l_out = down(..) + ffn_inp
             trace(ctx, "lout", il, x, n_embd, n_tok);
+        } else if (hp.generic()) {
+            // the sequential block of build_baichuan / _starcoder / _refact / _bloom / _mpt / _stablelm: every operator in the reference's order, biases and the
+            // residual as separate fp32 adds where the reference has separate ggml_add nodes
+            const pi_block & B = hp.block;
+            const float eps = B.rms ? hp.f_norm_rms_eps : hp.f_norm_eps;
+            const int rms = B.rms ? 1 : 0;
+            const int64_t qw = n_embd + 2 * n_gqa;
+            const float * q, * k, * v; int64_t qs, ks, vs;
+            if (B.fused_qkv) {
+                if (!norm_for(ctx, x, L.attn_norm, L.attn_norm_b, n_embd, n_tok, eps, rms, vdt_of(L.wqkv), ctx->q8a)) return false;
+                OP_OK(pi_op_mul_mat(L.wqkv, ctx->q8a, n_tok, ctx->qkv, nullptr, s));
+                if (L.bqkv) OP_OK(pi_op_add_bias(ctx->qkv, L.bqkv, qw, n_tok, s));
+                if (B.clamp_kqv > 0.0f) OP_OK(pi_op_clamp(ctx->qkv, -B.clamp_kqv, B.clamp_kqv, (int64_t) n_tok * qw, s));
+                q = ctx->qkv; k = q + n_embd; v = k + n_gqa; qs = ks = vs = qw;
+            } else {
+                float * qo = ctx->qkv, * ko = qo + (size_t) n_tok * n_embd, * vo = ko + (size_t) n_tok * n_gqa;
+                const int vq = vdt_of(L.wq);
+                if (!norm_for(ctx, x, L.attn_norm, L.attn_norm_b, n_embd, n_tok, eps, rms, vq, ctx->q8a)) return false;
+                if (vdt_of(L.wk) != vq && !norm_for(ctx, x, L.attn_norm, L.attn_norm_b, n_embd, n_tok, eps, rms, vdt_of(L.wk), ctx->q8c)) return false;
+                if (vdt_of(L.wv) != vq && vdt_of(L.wv) != vdt_of(L.wk) && !norm_for(ctx, x, L.attn_norm, L.attn_norm_b, n_embd, n_tok, eps, rms, vdt_of(L.wv), ctx->q8c)) return false;
+                const pi_weight * ws[3] = { L.wq, L.wk, L.wv };
+                const void * ins[3] = { ctx->q8a, vdt_of(L.wk) == vq ? ctx->q8a : ctx->q8c, vdt_of(L.wv) == vq ? ctx->q8a : ctx->q8c };
+                float * outs[3] = { qo, ko, vo };
+                if (!mul_mat_grouped(3, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
+                q = qo; k = ko; v = vo; qs = n_embd; ks = vs = n_gqa;
+            }
+            trace(ctx, "q", il, q, n_embd, n_tok, qs); trace(ctx, "k", il, k, n_gqa, n_tok, ks); trace(ctx, "v", il, v, n_gqa, n_tok, vs);
+            // (without RoPE the context's table is the identity: cos 1, sin 0 — x0 * 1 - x1 * 0 is x0 bit for bit — so the f16 rounding and the cache writes stay one kernel)
+            OP_OK(pi_op_rope_kv_store(q, k, v, qs, ks, vs, ctx->pos_dev, ctx->rope, B.rope == 2, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
+            OP_OK(pi_op_attention_alibi(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, multi ? 1 : 0, m->alibi_slopes, s));
+            trace(ctx, "att", il, ctx->att, n_embd, n_tok);
+            OP_OK(pi_op_quantize(vdt_of(L.wo), ctx->att, n_embd, n_tok, ctx->q8a, s));
+            if (L.bo) {                                                                                               // wo . att, + bo, + inpL (llama.cpp:3766-3772, 4283)
+                OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, nullptr, s));
+                OP_OK(pi_op_add_bias(x2, L.bo, n_embd, n_tok, s));
+                OP_OK(pi_op_add(x2, x, x2, (int64_t) n_tok * n_embd, s));
+            } else OP_OK(pi_op_mul_mat(L.wo, ctx->q8a, n_tok, x2, x, s));
+            trace(ctx, "ffn_inp", il, x2, n_embd, n_tok);
+            const int vu = vdt_of(L.ffn_up);
+            if (!norm_for(ctx, x2, L.ffn_norm, L.ffn_norm_b, n_embd, n_tok, eps, rms, vu, ctx->q8a)) return false;
+            if (B.gated) {                                                                                            // llm_build_ffn LLM_FFN_SILU / LLM_FFN_PAR (llama.cpp:3611-3695)
+                if (vdt_of(L.ffn_gate) != vu && !norm_for(ctx, x2, L.ffn_norm, L.ffn_norm_b, n_embd, n_tok, eps, rms, vdt_of(L.ffn_gate), ctx->q8c)) return false;
+                const pi_weight * ws[2] = { L.ffn_up, L.ffn_gate };
+                const void * ins[2] = { ctx->q8a, vdt_of(L.ffn_gate) == vu ? ctx->q8a : ctx->q8c };
+                float * outs[2] = { ctx->up, ctx->gate };
+                if (!mul_mat_grouped(2, ws, ins, outs, n_tok, s)) { ctx->last_error = std::string("mul_mat_grouped: ") + pi_last_error(); return false; }
+                OP_OK(pi_op_act_quantize(ctx->gate, ctx->up, 0, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));
+            } else {                                                                                                  // LLM_FFN_GELU / LLM_FFN_SEQ: up (+ bias) -> gelu -> down (+ bias)
+                OP_OK(pi_op_mul_mat(L.ffn_up, ctx->q8a, n_tok, ctx->up, nullptr, s));
+                if (L.ffn_up_b) OP_OK(pi_op_add_bias(ctx->up, L.ffn_up_b, n_ff, n_tok, s));
+                OP_OK(pi_op_act_quantize(ctx->up, nullptr, 1, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));
+            }
+            if (L.ffn_down_b) {
+                OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, nullptr, s));
+                OP_OK(pi_op_add_bias(x, L.ffn_down_b, n_embd, n_tok, s));
+                OP_OK(pi_op_add(x, x2, x, (int64_t) n_tok * n_embd, s));
+            } else OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, x2, s));
+            trace(ctx, "lout", il, x, n_embd, n_tok);
         } else {
             const int64_t qw = n_embd + 2 * n_gqa;
             const int vqkv = vdt_of(L.wqkv), vup = vdt_of(L.ffn_up);
@@ -269,8 +335,8 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
     }
     if (tail && ctx->is_last) {
         const int vo = vdt_of(m->output);
-        if (hp.arch == PI_ARCH_LLAMA) { if (!norm_for(ctx, x, m->output_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vo, ctx->q8a)) return false; }
-        else                          { if (!norm_for(ctx, x, m->output_norm, m->output_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vo, ctx->q8a)) return false; }
+        if (hp.arch == PI_ARCH_LLAMA || (hp.generic() && hp.block.rms)) { if (!norm_for(ctx, x, m->output_norm, nullptr, n_embd, n_tok, hp.f_norm_rms_eps, 1, vo, ctx->q8a)) return false; }
+        else                                                              { if (!norm_for(ctx, x, m->output_norm, m->output_norm_b, n_embd, n_tok, hp.f_norm_eps, 0, vo, ctx->q8a)) return false; }
         OP_OK(pi_op_mul_mat(m->output, ctx->q8a, n_tok, ctx->logits_dev, nullptr, s));
         OP_OK(pi_op_topk(ctx->logits_dev, hp.n_vocab, n_tok, 8, ctx->topk_ids_dev, ctx->topk_vals_dev, ctx->topk_sum_dev, ctx->topk_scratch_dev, s));
     }
@@ -794,7 +860,12 @@ int context_finish(llama_context * ctx, pi_run * run) {
         }
         if (run->run_id > ctx->last_finished_id.load()) ctx->last_finished_id.store(run->run_id);
         ctx->epoch_after_finish.store(ctx->caller_epoch.fetch_add(1) + 1);
+        // experiment knob (tools_dev/draft_sensitivity.sh): what does the schedule lose per microsecond of draft latency?  > 0: the priority context's run holds the
+        // device that much longer; < 0: only its caller sees the result later
+        static const int prio_delay_us = getenv("PIPEINFER_PRIORITY_DELAY_US") ? atoi(getenv("PIPEINFER_PRIORITY_DELAY_US")) : 0;
+        if (prio_delay_us > 0 && ctx->stream_priority > 0) std::this_thread::sleep_for(std::chrono::microseconds(prio_delay_us));
         urgent_end(ctx);
+        if (prio_delay_us < 0 && ctx->stream_priority > 0) std::this_thread::sleep_for(std::chrono::microseconds(-prio_delay_us));
         if (run->failed) {
             // a launch of this run failed (graph capture, a kernel launch, a copy): that is an error, not a cancelled run — the caller gets -1, the cells
             // find_slot allotted go back (nothing valid was written to them) and the run leaves the queue

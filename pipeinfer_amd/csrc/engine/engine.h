@@ -26,20 +26,35 @@
 #include "vocab.h"
 #include "../kernels/kernel_timing.h"
 
-enum pi_arch { PI_ARCH_LLAMA = 0, PI_ARCH_FALCON = 1 };
+// LLAMA and FALCON have their own blocks in forward(); the others are one generic sequential block (norm -> attention -> + -> norm -> MLP -> +) described by pi_block below
+enum pi_arch { PI_ARCH_LLAMA = 0, PI_ARCH_FALCON = 1, PI_ARCH_BAICHUAN = 2, PI_ARCH_STARCODER = 3, PI_ARCH_REFACT = 4, PI_ARCH_BLOOM = 5, PI_ARCH_MPT = 6, PI_ARCH_STABLELM = 7 };
+
+// what the reference's build_* functions differ in (llama.cpp:3985-4104 baichuan, 4229-4327 starcoder, 4540-4630 refact, 4632-4725 bloom, 4727-4825 mpt, 4827-4939 stablelm)
+struct pi_block {
+    bool rms = false;            // LLM_NORM_RMS or LLM_NORM (weights, and biases where the file has them)
+    bool fused_qkv = false;      // attn_qkv [q | k | v] or attn_q / attn_k / attn_v
+    int rope = -1;               // -1 none, 0 pairs (2i, 2i+1), 2 NeoX over n_rot
+    float alibi = 0.0f;          // max_alibi_bias (> 0: ggml_alibi on the scaled scores)
+    bool gated = false;          // SiLU(gate) * up (LLM_FFN_PAR) or GELU(up) (LLM_FFN_SEQ)
+    float clamp_kqv = 0.0f;
+};
 
 struct pi_hparams {
     pi_arch arch = PI_ARCH_LLAMA;
     int n_vocab = 0, n_ctx_train = 0, n_embd = 0, n_head = 0, n_head_kv = 0, n_layer = 0, n_ff = 0, n_rot = 0;
     float f_norm_eps = 0.0f, f_norm_rms_eps = 0.0f, rope_freq_base_train = 10000.0f, rope_freq_scale_train = 1.0f;
+    float f_max_alibi_bias = 0.0f, f_clamp_kqv = 0.0f;
+    pi_block block;
     int head_dim() const { return n_embd / n_head; }
     int n_embd_gqa() const { return head_dim() * n_head_kv; }
+    bool generic() const { return arch != PI_ARCH_LLAMA && arch != PI_ARCH_FALCON; }
 };
 
 struct pi_layer {
     pi_weight * wq = nullptr, * wk = nullptr, * wv = nullptr, * wo = nullptr, * wqkv = nullptr;
     pi_weight * ffn_gate = nullptr, * ffn_down = nullptr, * ffn_up = nullptr;
-    float * attn_norm = nullptr, * attn_norm_b = nullptr, * attn_norm_2 = nullptr, * attn_norm_2_b = nullptr, * ffn_norm = nullptr;
+    float * attn_norm = nullptr, * attn_norm_b = nullptr, * attn_norm_2 = nullptr, * attn_norm_2_b = nullptr, * ffn_norm = nullptr, * ffn_norm_b = nullptr;
+    float * bqkv = nullptr, * bo = nullptr, * ffn_up_b = nullptr, * ffn_down_b = nullptr;       // biases of the projections (StarCoder, Bloom)
     bool loaded = false;
 };
 
@@ -50,8 +65,9 @@ struct llama_model {
     std::string name, path;
     int device = 0;
     uint64_t n_elements = 0, n_bytes = 0;
-    pi_weight * tok_embd = nullptr, * output = nullptr;
-    float * output_norm = nullptr, * output_norm_b = nullptr;
+    pi_weight * tok_embd = nullptr, * output = nullptr, * pos_embd = nullptr;                 // pos_embd: StarCoder's learned positions (llama.cpp:4251-4255)
+    float * output_norm = nullptr, * output_norm_b = nullptr, * tok_norm = nullptr, * tok_norm_b = nullptr;   // tok_norm: Bloom's LayerNorm on the embeddings (llama.cpp:4650-4654)
+    float * alibi_slopes = nullptr;                                                              // f32 [n_head] on the device when block.alibi > 0
     std::vector<pi_layer> layers;
     std::vector<void *> f32_allocs;
     size_t hbm_bytes = 0;                     // bytes resident in HBM for this process's stage(s)

@@ -24,6 +24,24 @@ extern "C" struct llama_context_params llama_context_default_params(void) {
     return r;
 }
 
+// PIPEINFER_CRASH_TRACE=1: a fatal signal prints the C stack of the faulting thread before the default action (debugging aid for rare crashes under pytest,
+// whose output capture otherwise leaves nothing behind); offsets resolve with addr2line against this library
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void crash_trace(int sig) {
+    void * frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "\npipeinfer: fatal signal, C stack of the faulting thread:\n";
+    (void) !write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+__attribute__((constructor)) static void crash_trace_install() {
+    if (!getenv("PIPEINFER_CRASH_TRACE")) return;
+    for (int sig : { SIGSEGV, SIGABRT, SIGBUS, SIGFPE, SIGILL }) signal(sig, crash_trace);
+}
 extern "C" void llama_backend_init(bool) {}
 extern "C" void llama_backend_free(void) {}
 extern "C" int64_t llama_time_us(void) { return pi::time_us(); }

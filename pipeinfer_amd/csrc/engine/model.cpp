@@ -16,7 +16,7 @@ llama_model::~llama_model() {
         pi_weight_free(l.wq); pi_weight_free(l.wk); pi_weight_free(l.wv); pi_weight_free(l.wo); pi_weight_free(l.wqkv);
         pi_weight_free(l.ffn_gate); pi_weight_free(l.ffn_down); pi_weight_free(l.ffn_up);
     }
-    pi_weight_free(tok_embd); pi_weight_free(output);
+    pi_weight_free(tok_embd); pi_weight_free(output); pi_weight_free(pos_embd);
     for (void * p : f32_allocs) pi_free(p);
 }
 
@@ -50,7 +50,21 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
     const int n_embd = hp.n_embd, n_gqa = hp.n_embd_gqa(), n_ff = hp.n_ff;
     struct mq_scope { ~mq_scope() { pi_weight_set_mq_copies(1); } } restore;      // (the setting is the calling thread's)
     pi_weight_set_mq_copies(0);                                                  // the embedding table is only ever gathered from (get_rows): no matrix-core copy
-    if (first && !tok_embd) { if (!(tok_embd = upload_matrix(*this, "token_embd.weight", n_embd, hp.n_vocab, err))) return false; }
+    if (first && !tok_embd) {
+        if (!(tok_embd = upload_matrix(*this, "token_embd.weight", n_embd, hp.n_vocab, err))) return false;
+        if (hp.arch == PI_ARCH_STARCODER && !(pos_embd = upload_matrix(*this, "position_embd.weight", n_embd, hp.n_ctx_train, err))) return false;
+        if (hp.arch == PI_ARCH_BLOOM) {
+            if (!(tok_norm = upload_f32(*this, "token_embd_norm.weight", n_embd, true, err))) return false;
+            if (!(tok_norm_b = upload_f32(*this, "token_embd_norm.bias", n_embd, true, err))) return false;
+        }
+    }
+    if (hp.block.alibi > 0.0f && !alibi_slopes) {
+        std::vector<float> m((size_t) hp.n_head);
+        pi_alibi_slopes(hp.n_head, hp.block.alibi, m.data());
+        alibi_slopes = (float *) pi_malloc(m.size() * 4);
+        if (!alibi_slopes || pi_memcpy_h2d(alibi_slopes, m.data(), m.size() * 4, nullptr) || pi_stream_sync(nullptr)) { err = std::string("upload of the ALiBi slopes failed: ") + pi_last_error(); return false; }
+        f32_allocs.push_back(alibi_slopes);
+    }
     // tile-major copies (+78 % HBM on a Q4_K_M model) only where a pass can be wide enough to use them
     pi_weight_set_mq_copies(want_mq ? 1 : 0);
     for (int il = l0; il < l1; il++) {
@@ -67,6 +81,29 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
             if (!(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err))) return false;
             if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
             if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+        } else if (hp.generic()) {
+            // tensor sets of llama.cpp:2825-2890 (baichuan; refact shares llama's, :2756-2824), :2969-3047 (starcoder), :3116-3197 (bloom), :3198-3264 (mpt), :3265-3345 (stablelm)
+            const bool norm_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM;
+            const bool proj_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM;
+            if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
+            if (norm_b && !(L.attn_norm_b = upload_f32(*this, p + "attn_norm.bias", n_embd, true, err))) return false;
+            if (hp.block.fused_qkv) {
+                if (!(L.wqkv = upload_matrix(*this, p + "attn_qkv.weight", n_embd, n_embd + 2 * n_gqa, err))) return false;
+                if (proj_b && !(L.bqkv = upload_f32(*this, p + "attn_qkv.bias", n_embd + 2 * n_gqa, true, err))) return false;
+            } else {
+                if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err))) return false;
+                if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err))) return false;
+                if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err))) return false;
+            }
+            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
+            if (proj_b && !(L.bo = upload_f32(*this, p + "attn_output.bias", n_embd, true, err))) return false;
+            if (!(L.ffn_norm = upload_f32(*this, p + "ffn_norm.weight", n_embd, true, err))) return false;
+            if (norm_b && !(L.ffn_norm_b = upload_f32(*this, p + "ffn_norm.bias", n_embd, true, err))) return false;
+            if (hp.block.gated && !(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err))) return false;
+            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
+            if (proj_b && !(L.ffn_down_b = upload_f32(*this, p + "ffn_down.bias", n_embd, true, err))) return false;
+            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+            if (proj_b && !(L.ffn_up_b = upload_f32(*this, p + "ffn_up.bias", n_ff, true, err))) return false;
         } else {
             if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
             if (!(L.attn_norm_b = upload_f32(*this, p + "attn_norm.bias", n_embd, true, err))) return false;
@@ -83,7 +120,8 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
     }
     if (last && !output) {
         if (!(output_norm = upload_f32(*this, "output_norm.weight", n_embd, true, err))) return false;
-        if (hp.arch == PI_ARCH_FALCON && !(output_norm_b = upload_f32(*this, "output_norm.bias", n_embd, true, err))) return false;
+        const bool out_b = hp.arch == PI_ARCH_FALCON || hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM;
+        if (out_b && !(output_norm_b = upload_f32(*this, "output_norm.bias", n_embd, true, err))) return false;
         if (!(output = upload_matrix(*this, "output.weight", n_embd, hp.n_vocab, err))) return false;
     }
     return true;
@@ -97,8 +135,10 @@ size_t llama_model::stage_weight_bytes(int l0, int l1, bool first, bool last, in
         if (t) b += rows_used < 0 ? t->nbytes : pi::type_row_size(t->type, t->ne[0]) * (size_t) rows_used;
     };
     if (first) add("token_embd.weight", n_tok);
+    if (first) { add("position_embd.weight", n_tok); add("token_embd_norm.weight", -1); add("token_embd_norm.bias", -1); }
     static const char * names[] = { "attn_norm.weight", "attn_norm.bias", "attn_norm_2.weight", "attn_norm_2.bias", "attn_q.weight", "attn_k.weight", "attn_v.weight",
-                                    "attn_qkv.weight", "attn_output.weight", "ffn_norm.weight", "ffn_gate.weight", "ffn_down.weight", "ffn_up.weight" };
+                                    "attn_qkv.weight", "attn_qkv.bias", "attn_output.weight", "attn_output.bias", "ffn_norm.weight", "ffn_norm.bias", "ffn_gate.weight",
+                                    "ffn_down.weight", "ffn_down.bias", "ffn_up.weight", "ffn_up.bias" };
     for (int il = l0; il < l1; il++) for (const char * n : names) add("blk." + std::to_string(il) + "." + n, -1);
     if (last) { add("output_norm.weight", -1); add("output_norm.bias", -1); add("output.weight", -1); }
     return b;
@@ -115,7 +155,13 @@ extern "C" struct llama_model * llama_load_model_from_file(const char * path, st
     pi_hparams & hp = m->hparams;
     if (arch == "llama") hp.arch = PI_ARCH_LLAMA;
     else if (arch == "falcon") hp.arch = PI_ARCH_FALCON;
-    else { fprintf(stderr, "llama_load_model_from_file: architecture '%s' is outside this engine's scope (llama, falcon)\n", arch.c_str()); return nullptr; }
+    else if (arch == "baichuan") hp.arch = PI_ARCH_BAICHUAN;
+    else if (arch == "starcoder") hp.arch = PI_ARCH_STARCODER;
+    else if (arch == "refact") hp.arch = PI_ARCH_REFACT;
+    else if (arch == "bloom") hp.arch = PI_ARCH_BLOOM;
+    else if (arch == "mpt") hp.arch = PI_ARCH_MPT;
+    else if (arch == "stablelm") hp.arch = PI_ARCH_STABLELM;
+    else { fprintf(stderr, "llama_load_model_from_file: architecture '%s' is outside this engine's scope (llama, falcon, baichuan, starcoder, refact, bloom, mpt, stablelm; not persimmon)\n", arch.c_str()); return nullptr; }
     m->name = f.get_str("general.name", "");
     hp.n_ctx_train = (int) f.get_u32(arch + ".context_length", 0);
     hp.n_embd      = (int) f.get_u32(arch + ".embedding_length", 0);
@@ -131,7 +177,30 @@ extern "C" struct llama_model * llama_load_model_from_file(const char * path, st
     float ropescale = f.get_f32(arch + ".rope.scaling.factor", 0.0f);
     if (ropescale == 0.0f) ropescale = f.get_f32(arch + ".rope.scale_linear", 0.0f);
     hp.rope_freq_scale_train = ropescale == 0.0f ? 1.0f : 1.0f / ropescale;
-    if (hp.n_rot != hp.n_embd / hp.n_head) { fprintf(stderr, "llama_load_model_from_file: invalid n_rot %d (expected %d)\n", hp.n_rot, hp.n_embd / hp.n_head); return nullptr; }   // llama.cpp:2269-2273
+    if ((hp.arch == PI_ARCH_LLAMA || hp.arch == PI_ARCH_FALCON) && hp.n_rot != hp.n_embd / hp.n_head) { fprintf(stderr, "llama_load_model_from_file: invalid n_rot %d (expected %d)\n", hp.n_rot, hp.n_embd / hp.n_head); return nullptr; }   // llama.cpp:2269-2273
+    hp.f_max_alibi_bias = f.get_f32(arch + ".attention.max_alibi_bias", 0.0f);
+    hp.f_clamp_kqv      = f.get_f32(arch + ".attention.clamp_kqv", 0.0f);
+    {   // the block of each generic architecture, as its build_* function strings it together
+        pi_block & b = hp.block;
+        switch (hp.arch) {
+            case PI_ARCH_BAICHUAN:                                                       // llama.cpp:4030-4063: the 7B rotates, the 13B carries ALiBi instead; other depths assert
+                b.rms = true; b.gated = true;
+                if (hp.n_layer == 32) b.rope = 0;
+                else if (hp.n_layer == 40) b.alibi = 8.0f;
+                else { fprintf(stderr, "llama_load_model_from_file: baichuan with %d layers is neither the 7B (32) nor the 13B (40) the reference builds a graph for (llama.cpp:4030-4050)\n", hp.n_layer); return nullptr; }
+                break;
+            case PI_ARCH_REFACT:    b.rms = true; b.gated = true; b.alibi = 8.0f; break;      // llama.cpp:4591
+            case PI_ARCH_STARCODER: b.fused_qkv = true; break;
+            case PI_ARCH_BLOOM:     b.fused_qkv = true; b.alibi = 8.0f; break;               // llama.cpp:4683
+            case PI_ARCH_MPT:
+                b.fused_qkv = true; b.alibi = hp.f_max_alibi_bias; b.clamp_kqv = hp.f_clamp_kqv;
+                if (!f.find(arch + ".attention.max_alibi_bias")) { fprintf(stderr, "llama_load_model_from_file: mpt needs %s.attention.max_alibi_bias (llama.cpp:2359)\n", arch.c_str()); return nullptr; }
+                break;
+            case PI_ARCH_STABLELM:  b.rope = 2; b.gated = true; break;
+            default: break;
+        }
+        if (b.rope == 2 && (hp.n_rot <= 0 || hp.n_rot % 2 || hp.head_dim() % hp.n_rot)) { fprintf(stderr, "llama_load_model_from_file: n_rot %d does not divide head_dim %d\n", hp.n_rot, hp.head_dim()); return nullptr; }
+    }
     if (hp.head_dim() != 64 && hp.head_dim() != 128) { fprintf(stderr, "llama_load_model_from_file: head_dim %d not supported by the attention kernel\n", hp.head_dim()); return nullptr; }
     if (!m->vocab.load(f, err)) { fprintf(stderr, "llama_load_model_from_file: %s\n", err.c_str()); return nullptr; }
     if (hp.n_ff == 0) { const pi::gguf_tensor * t = f.tensor("blk.0.ffn_up.weight"); if (t) hp.n_ff = (int) t->ne[1]; }
@@ -156,7 +225,8 @@ extern "C" enum llama_vocab_type llama_vocab_type(const struct llama_model * m) 
 extern "C" uint64_t llama_model_size(const struct llama_model * m) { return m->n_bytes; }
 extern "C" uint64_t llama_model_n_params(const struct llama_model * m) { return m->n_elements; }
 extern "C" int llama_model_desc(const struct llama_model * m, char * buf, size_t n) {
-    return snprintf(buf, n, "%s %s", m->hparams.arch == PI_ARCH_LLAMA ? "llama" : "falcon", m->name.c_str());
+    static const char * names[] = { "llama", "falcon", "baichuan", "starcoder", "refact", "bloom", "mpt", "stablelm" };
+    return snprintf(buf, n, "%s %s", names[m->hparams.arch], m->name.c_str());
 }
 
 extern "C" const char * llama_token_get_text(const struct llama_model * m, llama_token t) { return m->vocab.id_to_token[t].text.c_str(); }

@@ -37,6 +37,7 @@ struct att_args {
     float scale;
     const int32_t * dyn;                                    // optional {kv_head, n_kv} in device memory: lets one captured graph serve every call
     const int32_t * abort_w;                                // abort word of the run (pi_device.h), nullable
+    const float * alibi_m;                                  // ALiBi slope of every query head (ggml_alibi, ggml.c:10736-10793), nullable
     int per_token;                                          // the pass may carry several runs: dyn = {.., n_kv of the widest, n, has_table, cell[n], n_kv[n]} and a workgroup's rows belong to ONE token
 };
 
@@ -51,7 +52,7 @@ template <int CTRL> static __device__ __forceinline__ float dpp_add(float x) {
 #endif
 }
 
-template <int HD, int RW>
+template <int HD, int RW, bool ALIBI = false>
 __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     extern __shared__ float smem[];
     __shared__ float redf[RW][4];
@@ -117,6 +118,9 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
 #pragma unroll
             for (int st = 0; st < NS; st++) { const uint32_t w = qp[16 * st + a]; q[rr][2 * st] = pi_h2f((uint16_t) (w & 0xffff)); q[rr][2 * st + 1] = pi_h2f((uint16_t) (w >> 16)); }
         }
+        float am[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++) am[rr] = ALIBI ? ga.alibi_m[hk * r + (row0 + (rr < n_rows ? rr : 0)) % r] : 0.0f;
         constexpr int U = 4;                                // cells per 16-lane group and step; two steps are in flight
         uint32_t kr[2][U][NS];
         auto load_k = [&](int c0, uint32_t (&dst)[U][NS]) __attribute__((always_inline)) {
@@ -147,7 +151,9 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
                     x = dpp_add<0x101>(x);                                 // (t0+t1) + (t2+t3)                    row_shl:1
                     if (a == 0 && c < g.n_kv && rr < n_rows) {
                         const bool vis = (M[rr * g.mask_words + (c >> 5)] >> (c & 31)) & 1;
-                        S[(size_t) rr * s_stride + c] = vis ? x * g.scale : -INFINITY;
+                        float sc = x * g.scale;                                  // ggml_scale
+                        if constexpr (ALIBI) sc = (float) c * am[rr] + sc;      // ggml_alibi: pdst = i * m_k + src, i = the cell's index in the view (ggml.c:10789), then + mask
+                        S[(size_t) rr * s_stride + c] = vis ? sc : -INFINITY;
                     }
                 }
             }
@@ -310,7 +316,8 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
 
 // raises the dynamic-LDS limit of the kernel for contexts longer than ~2000 cells; call once outside any graph capture
 template <int HD, int RW> static int att_set_lds(size_t lds) {
-    PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<HD, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<HD, RW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<HD, RW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     return 0;
 }
 // LDS a workgroup of rw rows needs for contexts of n_kv cells (score rows + visibility words); the single-row instance also has 8 KiB of static LDS
@@ -333,6 +340,15 @@ template <int HD>
 static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream) {
     const dim3 grid(g.n_head_kv, (rows + rw - 1) / rw);
     const size_t lds = (size_t) rw * (g.n_kv + g.mask_words) * sizeof(float);
+    if (g.alibi_m) {
+        switch (rw) {
+            case 1: hipLaunchKernelGGL((k_attention<HD, 1, true>), grid, dim3(256), lds, stream, g); break;
+            case 2: hipLaunchKernelGGL((k_attention<HD, 2, true>), grid, dim3(256), lds, stream, g); break;
+            case 4: hipLaunchKernelGGL((k_attention<HD, 4, true>), grid, dim3(256), lds, stream, g); break;
+            default: hipLaunchKernelGGL((k_attention<HD, 8, true>), grid, dim3(256), lds, stream, g); break;
+        }
+        return;
+    }
     switch (rw) {
         case 1: hipLaunchKernelGGL((k_attention<HD, 1>), grid, dim3(256), lds, stream, g); break;
         case 2: hipLaunchKernelGGL((k_attention<HD, 2>), grid, dim3(256), lds, stream, g); break;
@@ -343,12 +359,25 @@ static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream)
 
 extern "C" int pi_op_attention(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
                                int n_tok, int n_kv, float * out, const int32_t * dyn_dev, void * stream) {
-    return pi_op_attention_ex(q16, kc, vc, mask, hd, n_head, n_head_kv, n_tok, n_kv, out, dyn_dev, 0, stream);
+    return pi_op_attention_alibi(q16, kc, vc, mask, hd, n_head, n_head_kv, n_tok, n_kv, out, dyn_dev, 0, nullptr, stream);
 }
 extern "C" int pi_op_attention_ex(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
                                   int n_tok, int n_kv, float * out, const int32_t * dyn_dev, int per_token_kv, void * stream) {
+    return pi_op_attention_alibi(q16, kc, vc, mask, hd, n_head, n_head_kv, n_tok, n_kv, out, dyn_dev, per_token_kv, nullptr, stream);
+}
+// ALiBi slopes of the query heads exactly as ggml_compute_forward_alibi_f32 forms them (ggml.c:10768-10787): m_k = powf(m0, k + 1) for the first
+// 2^floor(log2 n_head) heads, powf(m1, 2 (k - that) + 1) for the rest (host libm, the values the reference adds)
+extern "C" void pi_alibi_slopes(int n_head, float max_bias, float * out) {
+    const int n_heads_log2_floor = 1 << (int) floor(log2(n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_heads_log2_floor);
+    const float m1 = powf(2.0f, -(max_bias / 2.0f) / n_heads_log2_floor);
+    for (int k = 0; k < n_head; k++) out[k] = k < n_heads_log2_floor ? powf(m0, k + 1) : powf(m1, 2 * (k - n_heads_log2_floor) + 1);
+}
+extern "C" int pi_op_attention_alibi(const uint16_t * q16, const uint16_t * kc, const uint16_t * vc, const uint32_t * mask, int hd, int n_head, int n_head_kv,
+                                     int n_tok, int n_kv, float * out, const int32_t * dyn_dev, int per_token_kv, const float * alibi_slopes_dev, void * stream) {
     if (n_tok <= 0) return 0;
     att_args g;
+    g.alibi_m = alibi_slopes_dev;
     g.q16 = q16; g.kc = kc; g.vc = vc; g.mask = mask; g.out = out;
     g.n_head = n_head; g.n_head_kv = n_head_kv; g.n_tok = n_tok; g.n_kv = n_kv; g.mask_words = (n_kv + 31) / 32;
     g.exp_tab = pi_get_tables().exp_f16;

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
     // requested together with x, so the kernel has a single dependent round trip to memory instead of three.
     constexpr int NQ_REG = 4;
     const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;
-    const int per = (int) ((n_pad / 256 + nw - 1) / nw);
+    const int per = (int) (((n_pad + 255) / 256 + nw - 1) / nw);                 // chunks per wave (a last half chunk counts: rows of 128 (2k + 1) values with 32-blocks)
     const bool in_regs = per <= NQ_REG;
     float4 xr4[NQ_REG], wr4[NQ_REG], br4[NQ_REG];
     if (in_regs) {
@@ -415,14 +415,18 @@ extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, vo
 // RoPE (ggml.c:11006-11168) + KV store as f16 (llama.cpp:3546-3577).  cos/sin come from a host-built table so that
 // theta (iterated `theta *= theta_scale` in fp32) and libm cosf/sinf are exactly the reference's.
 // =================================================================================================================
-struct pi_rope_table { float * cs; int n_pos; int head_dim; };   // cs: [n_pos][head_dim/2][2] = (cos, sin)
+struct pi_rope_table { float * cs; int n_pos; int head_dim; int n_rot; };   // cs: [n_pos][head_dim/2][2] = (cos, sin)
 
 extern "C" void * pi_rope_table_create(int n_pos, int head_dim, float freq_base, float freq_scale, int neox) {
+    return pi_rope_table_create_ex(n_pos, head_dim, head_dim, freq_base, freq_scale, neox);
+}
+extern "C" void * pi_rope_table_create_ex(int n_pos, int head_dim, int n_rot, float freq_base, float freq_scale, int neox) {
+    if (n_rot <= 0 || n_rot % 2 || head_dim % n_rot || (n_rot != head_dim && neox <= 0)) { pi_set_error("pi_rope_table_create: n_rot %d does not divide head_dim %d (or is not NeoX mode)", n_rot, head_dim); return nullptr; }
     std::vector<float> h((size_t) n_pos * head_dim);
-    const float theta_scale = powf(freq_base, -2.0f / head_dim);
+    const float theta_scale = powf(freq_base, -2.0f / n_rot);             // ggml.c:11062: n_dims is the rope's, not the head's
     for (int p = 0; p < n_pos; p++) {
-        float theta_base = (float) p;
-        if (neox) theta_base *= freq_scale;                           // ggml.c:11136
+        float theta_base = neox < 0 ? 0.0f : (float) p;               // neox < 0: no rotation (cosf(0) = 1, sinf(0) = 0: x0 * 1 - x1 * 0 == x0)
+        if (neox > 0) theta_base *= freq_scale;                       // ggml.c:11136
         for (int i = 0; i < head_dim / 2; i++) {
             const float theta = freq_scale * theta_base;              // rope_yarn with ext_factor == 0 (ggml.c:10979-10989)
             h[((size_t) p * (head_dim / 2) + i) * 2 + 0] = cosf(theta) * 1.0f;
@@ -430,7 +434,7 @@ extern "C" void * pi_rope_table_create(int n_pos, int head_dim, float freq_base,
             theta_base *= theta_scale;
         }
     }
-    pi_rope_table * t = new pi_rope_table{ nullptr, n_pos, head_dim };
+    pi_rope_table * t = new pi_rope_table{ nullptr, n_pos, head_dim, n_rot };
     if (hipMalloc((void **) &t->cs, h.size() * 4) != hipSuccess || hipMemcpy(t->cs, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
         pi_set_error("pi_rope_table_create: device allocation/copy failed"); delete t; return nullptr;
     }
@@ -440,7 +444,7 @@ extern "C" void pi_rope_table_free(void * t_) { pi_rope_table * t = (pi_rope_tab
 
 // grid (n_tok, n_head + 2*n_head_kv) — one workgroup of hd/2 threads per head vector
 __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict__ k, const float * __restrict__ v, int64_t qs, int64_t ks, int64_t vs,
-                          const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int hd, int n_head, int n_head_kv, int kv_head_,
+                          const int32_t * __restrict__ pos, const float * __restrict__ cs, int neox, int n_rot, int hd, int n_head, int n_head_kv, int kv_head_,
                           uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc, const int32_t * __restrict__ dyn, const int32_t * __restrict__ abort_w) {
     if (pi_aborted(abort_w)) return;
     const int t = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;           // i: pair index
@@ -458,7 +462,9 @@ __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict
     const float * src = is_q ? q + (int64_t) t * qs + h * hd : k + (int64_t) t * ks + h * hd;
     uint16_t * dst = is_q ? q16 + (int64_t) t * n_embd + h * hd : kc + (int64_t) cell * n_gqa + h * hd;
     const float2 c = *(const float2 *) (cs + ((int64_t) pos[t] * (hd / 2) + i) * 2);
-    const int i0 = neox ? i : 2 * i, i1 = neox ? i + hd / 2 : 2 * i + 1;
+    // NeoX: block ib = i / (n_rot/2) of n_rot values, pair (ib n_rot + k, ib n_rot + k + n_rot/2), table entry i = ib (n_rot/2) + k (ggml.c:11138-11157)
+    const int hr = n_rot >> 1, ib = i / hr, kk = i - ib * hr;
+    const int i0 = neox ? ib * n_rot + kk : 2 * i, i1 = neox ? i0 + hr : 2 * i + 1;
     const float x0 = src[i0], x1 = src[i1];
     dst[i0] = pi_f2h(x0 * c.x - x1 * c.y);
     dst[i1] = pi_f2h(x0 * c.y + x1 * c.x);
@@ -472,7 +478,7 @@ extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float
     const pi_rope_table * t = (const pi_rope_table *) table_;
     if (t->head_dim != hd) { pi_set_error("pi_op_rope_kv_store: table head_dim %d != %d", t->head_dim, hd); return -1; }
     hipLaunchKernelGGL(k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
-                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, hd, n_head, n_head_kv, kv_head, q16, kc, vc, dyn_dev, pi_abort_word());
+                       q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, t->n_rot, hd, n_head, n_head_kv, kv_head, q16, kc, vc, dyn_dev, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -496,6 +502,28 @@ __global__ void k_add(const float * __restrict__ a, const float * __restrict__ b
     if (i < n) o[i] = a[i] + b[i];
 }
 
+__global__ void k_add_bias(float * __restrict__ x, const float * __restrict__ b, int64_t n, int64_t total, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) x[i] = x[i] + b[i % n];
+}
+__global__ void k_clamp(float * __restrict__ x, float lo, float hi, int64_t n, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(fminf(x[i], hi), lo);                             // ggml.c:10928: MAX(MIN(x, max), min)
+}
+
+extern "C" int pi_op_add_bias(float * x, const float * b, int64_t n, int n_tok, void * stream) {
+    const int64_t total = n * n_tok;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_add_bias, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, b, n, total, pi_abort_word());
+    PI_CHECK_LAUNCH(); return 0;
+}
+extern "C" int pi_op_clamp(float * x, float lo, float hi, int64_t n, void * stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_clamp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, lo, hi, n, pi_abort_word());
+    PI_CHECK_LAUNCH(); return 0;
+}
 extern "C" int pi_op_silu_mul(const float * g, const float * u, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_silu_mul, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, g, u, o, n, pi_get_tables().silu_f16, pi_abort_word());

@@ -1098,7 +1098,7 @@ extern "C" int pi_op_mul_mat_qkv_rope_ok(const pi_weight * wq, const pi_weight *
     return 1;
 }
 
-struct pi_rope_table_view { float * cs; int n_pos; int head_dim; };          // == pi_rope_table (elementwise.hip)
+struct pi_rope_table_view { float * cs; int n_pos; int head_dim; int n_rot; };   // == pi_rope_table (elementwise.hip)
 
 // q16 = f16(rope(Wq . act)), K cache cells <- f16(rope(Wk . act)), V cache cells <- f16(Wv . act): the attention projections,
 // ggml_rope and llm_build_kv_store (llama.cpp:3546-3577, 4064-4100) with the rotation and the cache writes done by the mat-vec

@@ -27,7 +27,25 @@ SPECS = {
     "tiny-llama-b":   ("llama", 3, 256, 4, 4, 768, 512, 512),
     "tiny-falcon":    ("falcon", 2, 256, 4, 1, 1024, 512, 512),
     "tiny-falcon40":  ("falcon", 2, 256, 4, 2, 1024, 512, 512),   # two-norm (40B-style) variant
+    # the other graph builders of the reference (llama.cpp:3985-4939); depths 32 / 40 are what build_baichuan tells its 7B (RoPE) from its 13B (ALiBi) by
+    "tiny-baichuan7":  ("baichuan", 32, 128, 2, 2, 256, 256, 512),
+    "tiny-baichuan13": ("baichuan", 40, 128, 2, 2, 256, 256, 512),
+    "tiny-starcoder":  ("starcoder", 2, 256, 4, 1, 1024, 512, 512),    # MQA, learned positions, biases everywhere
+    "tiny-refact":     ("refact", 2, 384, 6, 1, 512, 512, 512),        # 6 heads: ALiBi slopes of both series (4 + 2); MQA
+    "tiny-bloom":      ("bloom", 2, 384, 6, 6, 768, 512, 512),
+    "tiny-mpt":        ("mpt", 2, 256, 4, 4, 1024, 512, 512),
+    "tiny-stablelm":   ("stablelm", 2, 256, 4, 4, 512, 512, 512),      # rotates n_rot = 16 of the 64 values of a head
 }
+# extra hyper-parameters of the synthetic files (name -> value): MPT's ALiBi bound and QKV clamp, StableLM's partial rotary width
+EXTRA_KV = {
+    "tiny-mpt": {"attention.max_alibi_bias": 8.0, "attention.clamp_kqv": 1.5},
+    "tiny-stablelm": {"rope.dimension_count": 16},
+}
+RMS_ARCHS = ("llama", "baichuan", "refact")
+NORM_BIAS_ARCHS = ("falcon", "starcoder", "bloom", "stablelm")
+PROJ_BIAS_ARCHS = ("starcoder", "bloom")
+FUSED_QKV_ARCHS = ("falcon", "starcoder", "bloom", "mpt")
+GATED_ARCHS = ("llama", "baichuan", "refact", "stablelm")
 
 FTYPE_IDS = {"f32": 0, "f16": 1, "q4_0": 2, "q8_0": 7, "q4_k_s": 14, "q4_k_m": 15, "q5_k_s": 16, "q5_k_m": 17, "q6_k": 18}
 
@@ -94,6 +112,10 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None, layers=None):
         return t
 
     plan = [("token_embd.weight", (n_embd, n_vocab), fix(base, n_embd), "embd")]
+    if arch == "starcoder":
+        plan.append(("position_embd.weight", (n_embd, SPECS[spec_name][7]), fix(base, n_embd), "pos"))
+    if arch == "bloom":
+        plan += [("token_embd_norm.weight", (n_embd,), G.T_F32, "gain"), ("token_embd_norm.bias", (n_embd,), G.T_F32, "bias")]
     two_norms = falcon_two_norms if falcon_two_norms is not None else (arch == "falcon" and n_head_kv > 1)
     l_off, l_cnt = layers if layers else (0, n_layer)
     for li in range(l_cnt):
@@ -111,6 +133,35 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None, layers=None):
                 (p + "ffn_down.weight", (n_ff, n_embd), fix(down_type(i) if kq else base, n_ff), "out"),
                 (p + "ffn_up.weight", (n_embd, n_ff), fix(G.T_Q3_K if ftype == "q2_k" else base, n_embd), "proj"),
             ]
+        elif arch != "falcon":
+            # tensor sets of llama.cpp:2825-2890 (baichuan; refact: llama's), 2969-3047 (starcoder), 3116-3197 (bloom), 3198-3264 (mpt), 3265-3345 (stablelm); norm gains and all
+            # biases are random here (the reference's own files carry trained ones): a bias dropped or added in the wrong place must show
+            nb_, pb_ = arch in NORM_BIAS_ARCHS, arch in PROJ_BIAS_ARCHS
+            qkv_t = G.T_Q5_K if ftype == "q4_k_m" else (G.T_Q6_K if ftype == "q5_k_m" else (G.T_Q4_K if ftype == "q3_k_m" else base))
+            plan.append((p + "attn_norm.weight", (n_embd,), G.T_F32, "gain"))
+            if nb_:
+                plan.append((p + "attn_norm.bias", (n_embd,), G.T_F32, "bias"))
+            if arch in FUSED_QKV_ARCHS:
+                plan.append((p + "attn_qkv.weight", (n_embd, n_embd + 2 * n_gqa), fix(qkv_t, n_embd), "proj"))
+                if pb_:
+                    plan.append((p + "attn_qkv.bias", (n_embd + 2 * n_gqa,), G.T_F32, "bias"))
+            else:
+                plan += [(p + "attn_q.weight", (n_embd, n_embd), fix(base, n_embd), "proj"), (p + "attn_k.weight", (n_embd, n_gqa), fix(base, n_embd), "proj"),
+                         (p + "attn_v.weight", (n_embd, n_gqa), fix(v_type(i) if kq else base, n_embd), "proj")]
+            plan.append((p + "attn_output.weight", (n_embd, n_embd), fix(base, n_embd), "out"))
+            if pb_:
+                plan.append((p + "attn_output.bias", (n_embd,), G.T_F32, "bias"))
+            plan.append((p + "ffn_norm.weight", (n_embd,), G.T_F32, "gain"))
+            if nb_:
+                plan.append((p + "ffn_norm.bias", (n_embd,), G.T_F32, "bias"))
+            if arch in GATED_ARCHS:
+                plan.append((p + "ffn_gate.weight", (n_embd, n_ff), fix(base, n_embd), "proj"))
+            plan.append((p + "ffn_down.weight", (n_ff, n_embd), fix(down_type(i) if kq else base, n_ff), "out"))
+            if pb_:
+                plan.append((p + "ffn_down.bias", (n_embd,), G.T_F32, "bias"))
+            plan.append((p + "ffn_up.weight", (n_embd, n_ff), fix(base, n_embd), "proj"))
+            if pb_:
+                plan.append((p + "ffn_up.bias", (n_ff,), G.T_F32, "bias"))
         else:
             plan += [(p + "attn_norm.weight", (n_embd,), G.T_F32, "ones"), (p + "attn_norm.bias", (n_embd,), G.T_F32, "zeros")]
             if two_norms:
@@ -122,9 +173,11 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None, layers=None):
                 (p + "ffn_up.weight", (n_embd, n_ff), fix(base, n_embd), "proj"),
                 (p + "ffn_down.weight", (n_ff, n_embd), fix(down_type(i) if kq else base, n_ff), "out"),
             ]
-    plan.append(("output_norm.weight", (n_embd,), G.T_F32, "ones"))
+    plan.append(("output_norm.weight", (n_embd,), G.T_F32, "ones" if arch in ("llama", "falcon") else "gain"))
     if arch == "falcon":
         plan.append(("output_norm.bias", (n_embd,), G.T_F32, "zeros"))
+    elif arch in NORM_BIAS_ARCHS:
+        plan.append(("output_norm.bias", (n_embd,), G.T_F32, "bias"))
     plan.append(("output.weight", (n_embd, n_vocab), out_type(), "lm_head"))
     return plan
 
@@ -369,8 +422,12 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
     if arch == "llama":
         w.add("llama.rope.dimension_count", G.U32, n_embd // n_head)
         w.add("llama.attention.layer_norm_rms_epsilon", G.F32, 1e-5)
+    elif arch in RMS_ARCHS:
+        w.add(f"{arch}.attention.layer_norm_rms_epsilon", G.F32, 1e-6)
     else:
-        w.add("falcon.attention.layer_norm_epsilon", G.F32, 1e-5)
+        w.add(f"{arch}.attention.layer_norm_epsilon", G.F32, 1e-5)
+    for key, val in EXTRA_KV.get(spec_name, {}).items():
+        w.add(f"{arch}.{key}", G.U32 if isinstance(val, int) else G.F32, val)
     _vocab_kv(w, arch, n_vocab, vocab)
 
     pi = np.random.default_rng(pi_seed).permutation(n_vocab) if structure == "bigram" else None
@@ -400,6 +457,10 @@ def write_model(path, spec_name, ftype, seed=0x5EED, std=0.02, structure="random
                 return np.ones(n, np.float32)
             if role == "zeros":
                 return np.zeros(n, np.float32)
+            if role == "gain":
+                return (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+            if role == "bias":
+                return (0.05 * rng.standard_normal(n)).astype(np.float32)
             rows, k = (ne[1], ne[0])
             if structure == "bigram" and role in ("embd", "lm_head"):
                 e = embedding_matrix()

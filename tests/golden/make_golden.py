@@ -28,7 +28,16 @@ MODELS = [  # (file stem, spec, ftype, seed)
     ("tiny_llama_q5_1", "tiny-llama", "q5_1", 18),             # legacy 32-blocks with min and fifth bit (x Q8_1 activations), Q6_K head
     ("tiny_llama_q5_0", "tiny-llama", "q5_0", 19),             # signed 5-bit (x Q8_0)
     ("tiny_llama_q4_1", "tiny-llama", "q4_1", 20),
+    # the other architectures: expected logits from the reference's OWN loader + build_* graph (O.RefLlama = oracle/_ref/libref_kv.so), not from our graph over its kernels
+    ("tiny_baichuan7_q4_0", "tiny-baichuan7", "q4_0", 21),     # 32 layers: build_baichuan's RoPE arm
+    ("tiny_baichuan13_q4_0", "tiny-baichuan13", "q4_0", 22),   # 40 layers: its ALiBi arm
+    ("tiny_starcoder_q4_0", "tiny-starcoder", "q4_0", 23),
+    ("tiny_refact_q4_0", "tiny-refact", "q4_0", 24),
+    ("tiny_bloom_q4_0", "tiny-bloom", "q4_0", 25),
+    ("tiny_mpt_q4_k_m", "tiny-mpt", "q4_k_m", 26),
+    ("tiny_stablelm_q4_k_m", "tiny-stablelm", "q4_k_m", 27),
 ]
+REF_BUILDERS = {"baichuan", "starcoder", "refact", "bloom", "mpt", "stablelm"}
 
 
 def ref_quantizer():
@@ -181,14 +190,15 @@ def model_vectors(only=None):
         synth.write_model(path, spec, ftype, seed=seed, std=0.08, quantizer=q)
         n_vocab = synth.SPECS[spec][6]
         res = {}
-        m = O.RefModel(path, n_ctx=128, max_seq=8)
+        Ref = O.RefLlama if synth.SPECS[spec][0] in REF_BUILDERS else O.RefModel
+        m = Ref(path, n_ctx=128, max_seq=8)
         ops = S.scenario_spec_like(n_vocab, seed=seed)
         for i, lg in enumerate(S.run_scenario(ops, m)):
             res[f"spec_like_{i}"] = lg
         m.close()
         # greedy continuation: prompt batched, then token by token (the lossless-speculation ground truth)
         prompt, n_gen = S.scenario_greedy(n_vocab, seed=seed)
-        m = O.RefModel(path, n_ctx=128, max_seq=8)
+        m = Ref(path, n_ctx=128, max_seq=8)
         lg = m.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
         res["greedy_prompt_logits"] = lg
         toks = []
@@ -214,6 +224,8 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
         model_vectors(only=["tiny_llama_q3_k_m"])
+    elif sys.argv[1:] == ["archs"]:                  # round 3: the generic-block architectures
+        model_vectors(only=[m[0] for m in MODELS if synth.SPECS[m[1]][0] in REF_BUILDERS])
     elif sys.argv[1:] == ["q2k"]:
         kernel_vectors_q3k(O.Q2_K, "kernels_q2k.npz")
         model_vectors(only=["tiny_llama_q2_k"])

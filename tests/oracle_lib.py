@@ -67,6 +67,8 @@ def oracle():
         lib.o_block_isums.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.o_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.o_attention_alibi.argtypes = lib.o_attention.argtypes[:-1] + [C.c_float, C.c_void_p]
+        lib.o_rope_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float]
         for name, nargs in (("o_kv_free", 1), ("o_kv_clear", 1), ("o_kv_head", 1), ("o_kv_used", 1), ("o_kv_cell_max", 1), ("o_kv_n", 1)):
             getattr(lib, name).argtypes = [C.c_void_p]
         lib.o_kv_pre_decode.argtypes = [C.c_void_p, C.c_int]
@@ -245,6 +247,16 @@ class Impl:
             self.lib.ref_rope(_ptr(x), _ptr(y), hd, n_head, n_tok, _ptr(pos), mode, 4096, freq_base, freq_scale)
         return y
 
+    def rope_ex(self, x, pos, mode, n_dims, freq_base=10000.0, freq_scale=1.0):
+        """x: [n_tok, n_head, head_dim]; rotates blocks of n_dims values (oracle only: the NeoX block walk of ggml.c:11133-11160)"""
+        x = np.ascontiguousarray(x, np.float32)
+        pos = np.ascontiguousarray(pos, np.int32)
+        y = np.zeros_like(x)
+        n_tok, n_head, hd = x.shape
+        assert self.which == "oracle"
+        self.lib.o_rope_ex(_ptr(x), _ptr(y), hd, n_dims, n_head, n_tok, _ptr(pos), mode, freq_base, freq_scale)
+        return y
+
     def soft_max(self, x):
         x = np.ascontiguousarray(x, np.float32)
         y = np.zeros_like(x)
@@ -277,7 +289,7 @@ class Impl:
             self.lib.ref_get_rows(t, _ptr(w), ne00, ne01, _ptr(ids), ids.size, _ptr(out))
         return out
 
-    def attention(self, k_cache, v_cache, n_ctx, q, k, v, mask, hd, n_head, n_head_kv, kv_head, n_kv, n_threads=4):
+    def attention(self, k_cache, v_cache, n_ctx, q, k, v, mask, hd, n_head, n_head_kv, kv_head, n_kv, n_threads=4, max_alibi_bias=0.0):
         """k_cache [n_ctx, n_embd_gqa] f16 (uint16), v_cache [n_embd_gqa, n_ctx]; updated in place. q [n_tok,n_head,hd]..."""
         q = np.ascontiguousarray(q, np.float32)
         k = np.ascontiguousarray(k, np.float32)
@@ -286,7 +298,10 @@ class Impl:
         n_tok = q.shape[0]
         out = np.zeros((n_tok, n_head * hd), np.float32)
         args = [_ptr(k_cache), _ptr(v_cache), n_ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(mask), hd, n_head, n_head_kv, n_tok, kv_head, n_kv, _ptr(out)]
-        if self.which == "oracle":
+        if max_alibi_bias > 0.0:
+            assert self.which == "oracle"
+            self.lib.o_attention_alibi(*args[:-1], C.c_float(max_alibi_bias), args[-1])
+        elif self.which == "oracle":
             self.lib.o_attention(*args)
         else:
             self.lib.ref_attention(*args, n_threads)

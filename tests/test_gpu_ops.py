@@ -118,7 +118,9 @@ def test_mul_mat_golden_blocks(gpu, t):
                                           # ... 17..32 tokens: two chunks of 16 over ONE weight stream (every waves-per-row-group choice; a ragged second chunk; prompts in steps of 32)
                                           (4096, 2064, 32), (2048, 9000, 24), (1024, 14000, 33), (512, 20000, 32), (768, 12288, 48), (256, 30000, 31), (8192, 130, 64), (1024, 6200, 18),
                                           # Q4_0 / Q8_0 range-per-wave kernel: 4, 8, 12 groups per wave, ragged last wave, rows not a multiple of 8
-                                          (1024, 19, 1), (4544, 71, 1), (4544, 71, 2), (16384, 9, 1), (18176, 13, 1), (24576, 11, 1), (24576, 11, 2), (32768, 8, 1)])
+                                          (1024, 19, 1), (4544, 71, 1), (4544, 71, 2), (16384, 9, 1), (18176, 13, 1), (24576, 11, 1), (24576, 11, 2), (32768, 8, 1),
+                                          # rows shorter than a 256-value chunk / with a last half chunk (32-blocks only): the tiny Baichuan, Refact and Bloom fixtures
+                                          (128, 40, 1), (128, 40, 4), (384, 20, 2), (384, 20, 9), (32, 16, 1)])
 def test_mul_mat_vs_oracle(gpu, t, k, rows, n_tok):
     if k % O.BLCK[t]:
         pytest.skip("K-quants need K % 256 == 0")
@@ -241,6 +243,50 @@ def test_rope_kv_store_exact(gpu, neox, hd, n_head, n_head_kv):
     lib.pi_rope_table_free(table)
 
 
+@pytest.mark.parametrize("hd,n_rot,n_head,n_head_kv", [(64, 16, 4, 2), (128, 32, 2, 2), (64, 64, 3, 1), (128, 64, 4, 1), (64, 2, 2, 2)])
+def test_partial_rotary_neox_blocks_exact(gpu, hd, n_rot, n_head, n_head_kv):
+    """StableLM rotates with n_dims = n_rot < head_dim in NeoX mode (llama.cpp:4860-4871): the reference walks head_dim / n_rot blocks, pairs (i, i + n_rot/2) inside a
+    block, theta_scale from n_rot, theta advancing across the blocks (ggml.c:11133-11160)"""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(hd + n_rot)
+    n_tok, n_ctx, kv_head = 4, 32, 7
+    pos = np.array([0, 3, 77, 500], np.int32)
+    q = rng.standard_normal((n_tok, n_head, hd)).astype(np.float32)
+    k = rng.standard_normal((n_tok, n_head_kv, hd)).astype(np.float32)
+    v = rng.standard_normal((n_tok, n_head_kv * hd)).astype(np.float32)
+    table = lib.pi_rope_table_create_ex(512, hd, n_rot, 10000.0, 1.0, 1)
+    assert table
+    g = n_head_kv * hd
+    q16, kc, vc = U.Dev(nbytes=2 * q.size), U.Dev(np.zeros(n_ctx * g, np.uint16)), U.Dev(np.zeros(n_ctx * g, np.uint16))
+    qd, kd, vd, pd = U.Dev(q), U.Dev(k), U.Dev(v), U.Dev(pos)
+    L.check(lib.pi_op_rope_kv_store(qd.ptr, kd.ptr, vd.ptr, n_head * hd, g, g, pd.ptr, table, 1, hd, n_head, n_head_kv, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
+    assert np.array_equal(q16.get(np.uint16, q.shape), O.f32_to_f16_bits(o.rope_ex(q, pos, 2, n_rot)))
+    assert np.array_equal(kc.get(np.uint16, (n_ctx, g))[kv_head:kv_head + n_tok].reshape(k.shape), O.f32_to_f16_bits(o.rope_ex(k, pos, 2, n_rot)))
+    lib.pi_rope_table_free(table)
+    # no rotation at all (ALiBi / learned positions): the identity table leaves f16(x)
+    table = lib.pi_rope_table_create_ex(512, hd, hd, 10000.0, 1.0, -1)
+    L.check(lib.pi_op_rope_kv_store(qd.ptr, kd.ptr, vd.ptr, n_head * hd, g, g, pd.ptr, table, 0, hd, n_head, n_head_kv, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
+    assert np.array_equal(q16.get(np.uint16, q.shape), O.f32_to_f16_bits(q))
+    assert np.array_equal(kc.get(np.uint16, (n_ctx, g))[kv_head:kv_head + n_tok].reshape(k.shape), O.f32_to_f16_bits(k))
+    lib.pi_rope_table_free(table)
+
+
+def test_bias_and_clamp_exact(gpu):
+    """ggml_add of a projection's bias row (llama.cpp:3628-3630) and ggml_clamp (ggml.c:10893-10931)"""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    rng = np.random.default_rng(8)
+    n, n_tok = 1000, 7
+    x = rng.standard_normal((n_tok, n)).astype(np.float32); b = rng.standard_normal(n).astype(np.float32)
+    xd, bd = U.Dev(x), U.Dev(b)
+    L.check(lib.pi_op_add_bias(xd.ptr, bd.ptr, n, n_tok, None))
+    assert np.array_equal(xd.get(np.float32, x.shape), x + b[None, :])
+    L.check(lib.pi_op_clamp(xd.ptr, -0.75, 0.5, x.size, None))
+    assert np.array_equal(xd.get(np.float32, x.shape), np.maximum(np.minimum(x + b[None, :], np.float32(0.5)), np.float32(-0.75)))
+
+
 def mask_bits(mask):
     """additive 0/-inf [n_tok, n_kv] -> uint32 bitmap"""
     n_tok, n_kv = mask.shape
@@ -248,6 +294,41 @@ def mask_bits(mask):
     bits = np.zeros((n_tok, words * 32), np.uint8)
     bits[:, :n_kv] = (mask == 0)
     return np.packbits(bits.reshape(n_tok, words, 32), axis=2, bitorder="little").view(np.uint32).reshape(n_tok, words)
+
+
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok,max_bias", [(64, 4, 4, 45, 3, 8.0), (128, 6, 6, 70, 2, 8.0), (64, 12, 1, 33, 1, 8.0), (128, 32, 32, 300, 9, 8.0), (64, 6, 2, 200, 5, 4.0),
+                                                                      (64, 71, 1, 64, 16, 8.0), (128, 8, 8, 6000, 3, 8.0)])
+def test_attention_with_alibi_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok, max_bias):
+    """llm_build_kqv with max_alibi_bias > 0 (Baichuan-13B, Refact, Bloom, MPT; llama.cpp:3735-3740): score = i * m_k + kq * scale with the slopes of
+    ggml_compute_forward_alibi_f32 (ggml.c:10768-10789; head counts that are not a power of two take the second series), then the mask and the soft-max"""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(hd + n_kv + n_head)
+    n_ctx, kv_head = n_kv + 8, n_kv - n_tok
+    g = hd * n_head_kv
+    k_rows = O.f32_to_f16_bits(rng.standard_normal((n_ctx, g)))
+    v_rows = O.f32_to_f16_bits(rng.standard_normal((n_ctx, g)))
+    q = rng.standard_normal((n_tok, n_head, hd)).astype(np.float32)
+    mask = np.zeros((n_tok, n_kv), np.float32)
+    for t in range(n_tok):
+        mask[t, kv_head + t + 1:] = -np.inf
+    mask[:, 5:9] = -np.inf
+    kc_o, vc_o = k_rows.copy(), np.ascontiguousarray(v_rows.T)
+    kcur = k_rows[kv_head:kv_head + n_tok].view(np.float16).astype(np.float32).reshape(n_tok, n_head_kv, hd)
+    vcur = v_rows[kv_head:kv_head + n_tok].view(np.float16).astype(np.float32)
+    want = o.attention(kc_o, vc_o, n_ctx, q, kcur, vcur, mask, hd, n_head, n_head_kv, kv_head, n_kv, max_alibi_bias=max_bias)
+    plain = o.attention(kc_o, vc_o, n_ctx, q, kcur, vcur, mask, hd, n_head, n_head_kv, kv_head, n_kv)
+    assert not np.array_equal(want, plain)                                                          # the bias is in the numbers
+    slopes = np.zeros(n_head, np.float32)
+    lib.pi_alibi_slopes(n_head, max_bias, slopes.ctypes.data_as(C.c_void_p))
+    q16 = O.f32_to_f16_bits(q)
+    out = U.Dev(nbytes=4 * n_tok * n_head * hd)
+    qd, kd, vd, md, sd = U.Dev(q16), U.Dev(k_rows), U.Dev(v_rows), U.Dev(mask_bits(mask)), U.Dev(slopes)
+    L.check(lib.pi_op_attention_reserve(hd, n_kv))
+    L.check(lib.pi_op_attention_alibi(qd.ptr, kd.ptr, vd.ptr, md.ptr, hd, n_head, n_head_kv, n_tok, n_kv, out.ptr, None, 0, sd.ptr, None))
+    got = out.get(np.float32, want.shape)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
 
 
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok", [(128, 8, 8, 45, 3), (64, 32, 4, 70, 2), (64, 71, 1, 33, 1), (128, 64, 8, 300, 9), (64, 8, 2, 1024, 4),
@@ -342,7 +423,7 @@ def test_topk(gpu, n_vocab):
         assert np.all(np.abs(p_dev - op) <= 2e-4 * op + 1e-12), (p_dev, op)
 
 
-@pytest.mark.parametrize("vdt,n", [(O.Q8_K, 256), (O.Q8_K, 4096), (O.Q8_K, 8192), (O.Q8_K, 11008), (O.Q8_0, 4544), (O.Q8_0, 256), (O.Q8_0, 18176)])
+@pytest.mark.parametrize("vdt,n", [(O.Q8_K, 256), (O.Q8_K, 4096), (O.Q8_K, 8192), (O.Q8_K, 11008), (O.Q8_0, 4544), (O.Q8_0, 256), (O.Q8_0, 18176), (O.Q8_0, 128), (O.Q8_0, 384), (O.Q8_0, 4224), (O.Q8_0, 32)])
 def test_fused_norm_and_activation_quantisers(gpu, vdt, n):
     """norm+quantise and act+quantise launches == the separate operators (same bytes as the oracle's quantiser on the oracle's op output)"""
     lib, U = gpu

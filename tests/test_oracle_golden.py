@@ -10,7 +10,10 @@ from tests import scenarios as S
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 K = np.load(os.path.join(GOLD, "kernels.npz"))
-MODELS = ["tiny_llama_q4_k_m", "tiny_llama_q4_0", "tiny_llama_b_q4_k_m", "tiny_falcon_q4_0", "tiny_falcon40_q4_k_m", "tiny_llama_q3_k_m", "tiny_llama_q2_k", "tiny_llama_q5_1", "tiny_llama_q5_0", "tiny_llama_q4_1"]
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20,
+         # the generic-block architectures (goldens made by the reference's own build_* graphs)
+         "tiny_baichuan7_q4_0": 21, "tiny_baichuan13_q4_0": 22, "tiny_starcoder_q4_0": 23, "tiny_refact_q4_0": 24, "tiny_bloom_q4_0": 25, "tiny_mpt_q4_k_m": 26, "tiny_stablelm_q4_k_m": 27}
+MODELS = list(SEEDS)
 
 
 def bits(a):
@@ -69,12 +72,12 @@ def test_model_scenarios_golden(stem):
     g = np.load(os.path.join(GOLD, stem + ".npz"))
     path = os.path.join(GOLD, stem + ".gguf")
     m = O.OracleModel(path, n_ctx=128, max_seq=8)
-    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20}[stem]
+    seed = SEEDS[stem]
     outs = S.run_scenario(S.scenario_spec_like(m.n_vocab, seed=seed), m)
     for i, lg in enumerate(outs):
         assert np.allclose(lg, g[f"spec_like_{i}"], rtol=0, atol=1e-5), (stem, i, np.abs(lg - g[f"spec_like_{i}"]).max())
     m.close()
-    prompt, n_gen = S.scenario_greedy(512, seed=seed)
+    prompt, n_gen = S.scenario_greedy(m.n_vocab, seed=seed)
     m = O.OracleModel(path, n_ctx=128, max_seq=8)
     lg = m.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
     assert np.allclose(lg, g["greedy_prompt_logits"], rtol=0, atol=1e-5)
@@ -96,7 +99,7 @@ def test_model_scenarios_through_the_reference_graph_builders(stem):
         pytest.skip("oracle/_ref/libref_kv.so is not built here (needs the reference sources)")
     g = np.load(os.path.join(GOLD, stem + ".npz"))
     path = os.path.join(GOLD, stem + ".gguf")
-    seed = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20}[stem]
+    seed = SEEDS[stem]
     r, m = O.RefLlama(path, n_ctx=128, max_seq=8), O.OracleModel(path, n_ctx=128, max_seq=8)
     ops = S.scenario_spec_like(m.n_vocab, seed=seed)
     outs_r, outs_m = S.run_scenario(ops, r), S.run_scenario(ops, m)
@@ -105,7 +108,7 @@ def test_model_scenarios_through_the_reference_graph_builders(stem):
         assert np.allclose(a, g[f"spec_like_{i}"], rtol=0, atol=1e-5)
     assert r.lib.refkv_head(r.kv) == m.lib.o_kv_head(m.kv) and r.lib.refkv_used(r.kv) == m.lib.o_kv_used(m.kv)
     r.close(); m.close()
-    prompt, n_gen = S.scenario_greedy(512, seed=seed)
+    prompt, n_gen = S.scenario_greedy(m.n_vocab, seed=seed)
     r = O.RefLlama(path, n_ctx=128, max_seq=8)
     lg = r.decode(prompt, list(range(len(prompt))), [[0]] * len(prompt))
     toks, cur = [], int(np.argmax(lg[-1]))
