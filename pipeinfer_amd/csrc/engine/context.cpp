@@ -61,11 +61,17 @@ size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv) {
 }
 
 static bool context_prepare_impl(llama_context * ctx, std::string & err);
+bool context_precapture(llama_context * ctx, int max_tokens);
 bool context_prepare(llama_context * ctx, std::string & err) {
     if (ctx->prepared || ctx->remote) return true;                           // the head of a remote pipeline owns no device state
     if (ctx->prepare_failed) { err = "an earlier attempt to allocate this context's device state failed: " + ctx->last_error; return false; }
     if (!context_prepare_impl(ctx, err)) { ctx->prepare_failed = true; ctx->last_error = err; return false; }      // (a half-built context must never launch kernels)
     ctx->prepared = true;
+    // A segmented context's graphs are replayed by its feeder thread.  Capture the narrow widths (single tokens, drafted batches) NOW, on the caller's thread and before
+    // that thread exists: captured lazily they would be recorded by the feeder in the middle of a generation, beside the caller's own HIP calls (the draft's first runs,
+    // pinned allocations, cancels) — the combination behind this runtime's rare capture failures, and (seen once in 36 repetitions of the segmented-target tests) a stall.
+    // Prompt-sized passes are still captured on first use: the caller is then blocked in llama_decode on that very run.
+    if (ctx->seg_layers > 0 && !context_precapture(ctx, 8)) { ctx->last_error = "graph capture of the narrow pass widths failed: " + ctx->last_error; err = ctx->last_error; return false; }
     return true;
 }
 static bool context_prepare_impl(llama_context * ctx, std::string & err) {
