@@ -84,7 +84,7 @@ PI_API int pi_op_get_rows(const pi_weight * w, const int32_t * tokens_dev, int n
 PI_API int pi_op_norm(const float * x_dev, const float * w_dev, const float * b_dev, float * y_dev, int n, int n_tok, float eps, int rms, void * stream);
 PI_API int pi_op_quantize(int vdt, const float * x_dev, int64_t k, int n_tok, void * q8_dev, void * stream);
 /* fusions of the above (same arithmetic, same rounding points): norm -> quantised planes (y_f32_dev nullable: also keep the fp32 result);
- * which = 0: silu(gate) * up, 1: gelu(gate) -> quantised planes */
+ * which = 0: silu(gate) * up, 1: gelu(gate), 2: relu(gate)^2 (LLM_FFN_RELU_SQR) -> quantised planes */
 PI_API int pi_op_norm_quantize(const float * x_dev, const float * w_dev, const float * b_dev, float * y_f32_dev, int n, int n_tok, float eps, int rms, int vdt, void * q8_dev, void * stream);
 PI_API int pi_op_act_quantize(const float * gate_dev, const float * up_dev, int which, int64_t n, int n_tok, int vdt, void * q8_dev, void * stream);
 /* out[t][row] = (residual ? residual[t][row] : 0) + W[row] . act[t]      out/residual: f32 [n_tok][ne1] */
@@ -111,6 +111,11 @@ PI_API int pi_op_rope_kv_store(const float * q_dev, const float * k_dev, const f
                                const int32_t * pos_dev, const void * rope_table,
                                int neox, int head_dim, int n_head, int n_head_kv, int n_tok, int kv_head,
                                uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, const int32_t * dyn_dev, void * stream);
+/* build_persimmon's attention inputs (llama.cpp:4372-4460): qkv_dev rows are [head][q | k | v][64] (fused projection + bias); per-head LayerNorm of Q and K
+ * (attn_q_norm / attn_k_norm), NeoX RoPE over the first 32 values of a head (rope_table: pi_rope_table_create_ex(n_pos, 32, 32, ...)), f16 Q and cache rows */
+PI_API int pi_op_persimmon_qkv_store(const float * qkv_dev, int n_head, int head_dim, const float * q_norm_w, const float * q_norm_b, const float * k_norm_w, const float * k_norm_b,
+                                     float eps, const int32_t * pos_dev, const void * rope_table, int n_tok, int kv_head,
+                                     uint16_t * q16_dev, uint16_t * k_cache_dev, uint16_t * v_cache_dev, const int32_t * dyn_dev, void * stream);
 /* mask_dev: uint32 bitmap [n_tok][ceil(n_kv/32)], bit i set <=> cell i visible to the token; out f32 [n_tok][n_head*hd].
  * dyn_dev (nullable): int32 {kv_head, n_kv} in device memory that overrides the scalar arguments at run time, so that a
  * captured HIP graph can be replayed for every call (n_kv then only sizes LDS and the mask row stride). */

@@ -31,7 +31,7 @@ struct o_model {
     int is_falcon, n_layer, n_embd, n_head, n_head_kv, n_ff, n_vocab, n_ctx;
     float eps, freq_base;
     // the other builders (build_baichuan / _starcoder / _refact / _bloom / _mpt / _stablelm, llama.cpp:3985-4939) as one sequential block
-    int generic, rms, fused_qkv, rope_mode /* -1 none, 0, 2 */, gated, n_rot;
+    int generic, rms, fused_qkv, rope_mode /* -1 none, 0, 2 */, gated, n_rot, persimmon;
     float alibi, clamp_kqv;
     o_kv_cache * kv;
     uint16_t * k_cache, * v_cache;     // per layer: K [n_ctx][n_embd_gqa], V [n_embd_gqa][n_ctx]  (llama.cpp:1529-1560, 3565-3576)
@@ -121,6 +121,7 @@ o_model * o_model_load(const char * path, int n_ctx, int max_seq) {
     else if (!strcmp(arch, "bloom"))       { m->generic = m->fused_qkv = 1; m->alibi = 8.0f; }
     else if (!strcmp(arch, "mpt"))         { m->generic = m->fused_qkv = 1; m->alibi = max_alibi; m->clamp_kqv = clamp_kqv; }
     else if (!strcmp(arch, "stablelm"))    { m->generic = m->gated = 1; m->rope_mode = 2; }
+    else if (!strcmp(arch, "persimmon"))   { m->generic = m->fused_qkv = m->persimmon = 1; m->rope_mode = 2; }      // build_persimmon, llama.cpp:4329-4538
     m->n_tensors = (int) n_tensors;
     m->tensors = calloc(n_tensors, sizeof(o_tensor));
     uint64_t * offs = calloc(n_tensors, 8);
@@ -225,6 +226,18 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
                 mm(layer_tensor(m, il, "attn_qkv.weight", 1), cur, n_tok, qkv);
                 add_bias(qkv, layer_tensor(m, il, "attn_qkv.bias", 0), nq, n_tok);
                 if (m->clamp_kqv > 0.0f) for (size_t i = 0; i < T * nq; i++) { const float lo = qkv[i] < m->clamp_kqv ? qkv[i] : m->clamp_kqv; qkv[i] = lo > -m->clamp_kqv ? lo : -m->clamp_kqv; }   // MAX(MIN(x, max), min), ggml.c:10928
+                if (m->persimmon) {
+                    // rows are [head][q | k | v][hd] (reshape_4d(hd, 3, n_head, n_tokens), llama.cpp:4372-4393); Q and K get a LayerNorm over the hd values of their head
+                    for (size_t t = 0; t < T; t++) for (int h = 0; h < m->n_head; h++) {
+                        const float * src = qkv + t * nq + (size_t) h * 3 * hd;
+                        memcpy(Q + t * n_embd + (size_t) h * hd, src,          4 * (size_t) hd);
+                        memcpy(K + t * n_embd + (size_t) h * hd, src + hd,     4 * (size_t) hd);
+                        memcpy(V + t * n_embd + (size_t) h * hd, src + 2 * hd, 4 * (size_t) hd);
+                    }
+                    norm_wb(Q, Qr, hd, n_tok * m->n_head, 0, m->eps, layer_tensor(m, il, "attn_q_norm.weight", 1), layer_tensor(m, il, "attn_q_norm.bias", 1));
+                    norm_wb(K, Kr, hd, n_tok * m->n_head, 0, m->eps, layer_tensor(m, il, "attn_k_norm.weight", 1), layer_tensor(m, il, "attn_k_norm.bias", 1));
+                    memcpy(Q, Qr, 4 * T * n_embd); memcpy(K, Kr, 4 * T * n_embd);
+                } else
                 for (size_t t = 0; t < T; t++) {
                     memcpy(Q + t * n_embd,     qkv + t * nq,                       4 * (size_t) n_embd);
                     memcpy(K + t * n_embd_gqa, qkv + t * nq + n_embd,              4 * (size_t) n_embd_gqa);
@@ -236,6 +249,21 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
                 mm(layer_tensor(m, il, "attn_v.weight", 1), cur, n_tok, V);
             }
             trace("q", il, Q, n_embd, n_tok); trace("k", il, K, n_embd_gqa, n_tok); trace("v", il, V, n_embd_gqa, n_tok);
+            if (m->persimmon) {
+                // NeoX RoPE of a VIEW of the first hd / 2 values of every head with n_dims = hd / 2, the other half passes (llama.cpp:4331, 4395-4455)
+                const int nr = hd / 2;
+                float * a = malloc(4 * (size_t) nr), * b = malloc(4 * (size_t) nr);
+                for (int which = 0; which < 2; which++) {
+                    const float * src = which ? K : Q; float * dst = which ? Kr : Qr;
+                    memcpy(dst, src, 4 * T * n_embd);
+                    for (size_t t = 0; t < T; t++) for (int h = 0; h < m->n_head; h++) {
+                        memcpy(a, src + t * n_embd + (size_t) h * hd, 4 * (size_t) nr);
+                        o_rope_ex(a, b, nr, nr, 1, 1, pos + t, 2, m->freq_base, 1.0f);
+                        memcpy(dst + t * n_embd + (size_t) h * hd, b, 4 * (size_t) nr);
+                    }
+                }
+                free(a); free(b);
+            } else
             if (m->rope_mode >= 0) {
                 o_rope_ex(Q, Qr, hd, m->rope_mode == 2 ? m->n_rot : hd, m->n_head,    n_tok, pos, m->rope_mode, m->freq_base, 1.0f);
                 o_rope_ex(K, Kr, hd, m->rope_mode == 2 ? m->n_rot : hd, m->n_head_kv, n_tok, pos, m->rope_mode, m->freq_base, 1.0f);
@@ -253,6 +281,8 @@ int o_model_forward(o_model * m, const int32_t * tokens, const int32_t * pos, in
                 mm(layer_tensor(m, il, "ffn_gate.weight", 1), cur, n_tok, gate);
                 o_silu(gate, gate, (int) (T * n_ff));
                 for (size_t i = 0; i < T * n_ff; i++) gate[i] = gate[i] * up[i];
+            } else if (m->persimmon) {                                               // LLM_FFN_RELU_SQR: ggml_relu, ggml_sqr (ggml.c:1415, 1407)
+                for (size_t i = 0; i < T * n_ff; i++) { const float a = up[i] > 0.f ? up[i] : 0.f; gate[i] = a * a; }
             } else {
                 o_gelu(up, gate, (int) (T * n_ff));
             }

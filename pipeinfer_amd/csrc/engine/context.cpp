@@ -105,6 +105,9 @@ static bool context_prepare_impl(llama_context * ctx, std::string & err) {
     const int neox = hp.arch == PI_ARCH_FALCON ? 1 : !hp.generic() ? 0 : hp.block.rope == 2 ? 1 : hp.block.rope == 0 ? 0 : -1;
     const float freq_base  = ctx->cparams.rope_freq_base  == 0.0f ? hp.rope_freq_base_train  : ctx->cparams.rope_freq_base;     // llama.cpp:8729-8731
     const float freq_scale = ctx->cparams.rope_freq_scale == 0.0f ? hp.rope_freq_scale_train : ctx->cparams.rope_freq_scale;
+    if (hp.generic() && hp.block.qk_norm) {                                        // build_persimmon ropes a VIEW of the first head_dim / 2 values with n_dims = head_dim / 2 (llama.cpp:4331, 4415-4440)
+        if (!(ctx->rope = pi_rope_table_create_ex(std::max(ctx->n_ctx, 32), hp.head_dim() / 2, hp.head_dim() / 2, freq_base, freq_scale, 1))) { err = pi_last_error(); return false; }
+    } else
     if (!(ctx->rope = pi_rope_table_create_ex(std::max(ctx->n_ctx, 32), hp.head_dim(), neox == 1 ? hp.n_rot : hp.head_dim(), freq_base, freq_scale, neox))) { err = pi_last_error(); return false; }
     const size_t qkv_w = (size_t) n_embd + 2 * n_gqa;
     const size_t kmax = (size_t) std::max(n_embd, n_ff);
@@ -284,6 +287,10 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
                 q = qo; k = ko; v = vo; qs = n_embd; ks = vs = n_gqa;
             }
             trace(ctx, "q", il, q, n_embd, n_tok, qs); trace(ctx, "k", il, k, n_gqa, n_tok, ks); trace(ctx, "v", il, v, n_gqa, n_tok, vs);
+            if (B.qk_norm)                                                                                            // Persimmon: rows are [head][q | k | v]; per-head LayerNorm of Q and K, RoPE on half a head
+                OP_OK(pi_op_persimmon_qkv_store(ctx->qkv, hp.n_head, hd, L.attn_q_norm, L.attn_q_norm_b, L.attn_k_norm, L.attn_k_norm_b, hp.f_norm_eps, ctx->pos_dev, ctx->rope,
+                                                n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
+            else
             // (without RoPE the context's table is the identity: cos 1, sin 0 — x0 * 1 - x1 * 0 is x0 bit for bit — so the f16 rounding and the cache writes stay one kernel)
             OP_OK(pi_op_rope_kv_store(q, k, v, qs, ks, vs, ctx->pos_dev, ctx->rope, B.rope == 2, hd, hp.n_head, hp.n_head_kv, n_tok, kv_head, ctx->q16, kc, vc, ctx->dyn_dev, s));
             OP_OK(pi_op_attention_alibi(ctx->q16, kc, vc, ctx->mask_dev, hd, hp.n_head, hp.n_head_kv, n_tok, n_kv, ctx->att, ctx->dyn_dev, multi ? 1 : 0, m->alibi_slopes, s));
@@ -307,7 +314,7 @@ static bool forward(llama_context * ctx, int n_tok, int kv_head, int n_kv, int l
             } else {                                                                                                  // LLM_FFN_GELU / LLM_FFN_SEQ: up (+ bias) -> gelu -> down (+ bias)
                 OP_OK(pi_op_mul_mat(L.ffn_up, ctx->q8a, n_tok, ctx->up, nullptr, s));
                 if (L.ffn_up_b) OP_OK(pi_op_add_bias(ctx->up, L.ffn_up_b, n_ff, n_tok, s));
-                OP_OK(pi_op_act_quantize(ctx->up, nullptr, 1, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));
+                OP_OK(pi_op_act_quantize(ctx->up, nullptr, B.relu_sqr ? 2 : 1, n_ff, n_tok, vdt_of(L.ffn_down), ctx->q8b, s));
             }
             if (L.ffn_down_b) {
                 OP_OK(pi_op_mul_mat(L.ffn_down, ctx->q8b, n_tok, x, nullptr, s));

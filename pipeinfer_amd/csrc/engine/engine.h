@@ -27,7 +27,7 @@
 #include "../kernels/kernel_timing.h"
 
 // LLAMA and FALCON have their own blocks in forward(); the others are one generic sequential block (norm -> attention -> + -> norm -> MLP -> +) described by pi_block below
-enum pi_arch { PI_ARCH_LLAMA = 0, PI_ARCH_FALCON = 1, PI_ARCH_BAICHUAN = 2, PI_ARCH_STARCODER = 3, PI_ARCH_REFACT = 4, PI_ARCH_BLOOM = 5, PI_ARCH_MPT = 6, PI_ARCH_STABLELM = 7 };
+enum pi_arch { PI_ARCH_LLAMA = 0, PI_ARCH_FALCON = 1, PI_ARCH_BAICHUAN = 2, PI_ARCH_STARCODER = 3, PI_ARCH_REFACT = 4, PI_ARCH_BLOOM = 5, PI_ARCH_MPT = 6, PI_ARCH_STABLELM = 7, PI_ARCH_PERSIMMON = 8 };
 
 // what the reference's build_* functions differ in (llama.cpp:3985-4104 baichuan, 4229-4327 starcoder, 4540-4630 refact, 4632-4725 bloom, 4727-4825 mpt, 4827-4939 stablelm)
 struct pi_block {
@@ -36,6 +36,8 @@ struct pi_block {
     int rope = -1;               // -1 none, 0 pairs (2i, 2i+1), 2 NeoX over n_rot
     float alibi = 0.0f;          // max_alibi_bias (> 0: ggml_alibi on the scaled scores)
     bool gated = false;          // SiLU(gate) * up (LLM_FFN_PAR) or GELU(up) (LLM_FFN_SEQ)
+    bool relu_sqr = false;       // ... or relu(up)^2 (LLM_FFN_RELU_SQR: Persimmon)
+    bool qk_norm = false;        // Persimmon: fused QKV rows are [head][q | k | v], Q and K get a per-head LayerNorm, RoPE covers the first half of a head (llama.cpp:4372-4460)
     float clamp_kqv = 0.0f;
 };
 
@@ -54,7 +56,8 @@ struct pi_layer {
     pi_weight * wq = nullptr, * wk = nullptr, * wv = nullptr, * wo = nullptr, * wqkv = nullptr;
     pi_weight * ffn_gate = nullptr, * ffn_down = nullptr, * ffn_up = nullptr;
     float * attn_norm = nullptr, * attn_norm_b = nullptr, * attn_norm_2 = nullptr, * attn_norm_2_b = nullptr, * ffn_norm = nullptr, * ffn_norm_b = nullptr;
-    float * bqkv = nullptr, * bo = nullptr, * ffn_up_b = nullptr, * ffn_down_b = nullptr;       // biases of the projections (StarCoder, Bloom)
+    float * bqkv = nullptr, * bo = nullptr, * ffn_up_b = nullptr, * ffn_down_b = nullptr;       // biases of the projections (StarCoder, Bloom, Persimmon)
+    float * attn_q_norm = nullptr, * attn_q_norm_b = nullptr, * attn_k_norm = nullptr, * attn_k_norm_b = nullptr;   // Persimmon's per-head LayerNorm of Q and K (64 values)
     bool loaded = false;
 };
 

@@ -83,8 +83,8 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
             if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
         } else if (hp.generic()) {
             // tensor sets of llama.cpp:2825-2890 (baichuan; refact shares llama's, :2756-2824), :2969-3047 (starcoder), :3116-3197 (bloom), :3198-3264 (mpt), :3265-3345 (stablelm)
-            const bool norm_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM;
-            const bool proj_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM;
+            const bool norm_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM || hp.arch == PI_ARCH_PERSIMMON;
+            const bool proj_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_PERSIMMON;
             if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
             if (norm_b && !(L.attn_norm_b = upload_f32(*this, p + "attn_norm.bias", n_embd, true, err))) return false;
             if (hp.block.fused_qkv) {
@@ -94,6 +94,10 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
                 if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err))) return false;
                 if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err))) return false;
                 if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err))) return false;
+            }
+            if (hp.block.qk_norm) {                                                       // llama.cpp:3105-3108: four vectors of 64
+                if (!(L.attn_q_norm = upload_f32(*this, p + "attn_q_norm.weight", 64, true, err)) || !(L.attn_q_norm_b = upload_f32(*this, p + "attn_q_norm.bias", 64, true, err))) return false;
+                if (!(L.attn_k_norm = upload_f32(*this, p + "attn_k_norm.weight", 64, true, err)) || !(L.attn_k_norm_b = upload_f32(*this, p + "attn_k_norm.bias", 64, true, err))) return false;
             }
             if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
             if (proj_b && !(L.bo = upload_f32(*this, p + "attn_output.bias", n_embd, true, err))) return false;
@@ -120,7 +124,7 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
     }
     if (last && !output) {
         if (!(output_norm = upload_f32(*this, "output_norm.weight", n_embd, true, err))) return false;
-        const bool out_b = hp.arch == PI_ARCH_FALCON || hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM;
+        const bool out_b = hp.arch == PI_ARCH_FALCON || hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM || hp.arch == PI_ARCH_PERSIMMON;
         if (out_b && !(output_norm_b = upload_f32(*this, "output_norm.bias", n_embd, true, err))) return false;
         if (!(output = upload_matrix(*this, "output.weight", n_embd, hp.n_vocab, err))) return false;
     }
@@ -138,7 +142,7 @@ size_t llama_model::stage_weight_bytes(int l0, int l1, bool first, bool last, in
     if (first) { add("position_embd.weight", n_tok); add("token_embd_norm.weight", -1); add("token_embd_norm.bias", -1); }
     static const char * names[] = { "attn_norm.weight", "attn_norm.bias", "attn_norm_2.weight", "attn_norm_2.bias", "attn_q.weight", "attn_k.weight", "attn_v.weight",
                                     "attn_qkv.weight", "attn_qkv.bias", "attn_output.weight", "attn_output.bias", "ffn_norm.weight", "ffn_norm.bias", "ffn_gate.weight",
-                                    "ffn_down.weight", "ffn_down.bias", "ffn_up.weight", "ffn_up.bias" };
+                                    "ffn_down.weight", "ffn_down.bias", "ffn_up.weight", "ffn_up.bias", "attn_q_norm.weight", "attn_q_norm.bias", "attn_k_norm.weight", "attn_k_norm.bias" };
     for (int il = l0; il < l1; il++) for (const char * n : names) add("blk." + std::to_string(il) + "." + n, -1);
     if (last) { add("output_norm.weight", -1); add("output_norm.bias", -1); add("output.weight", -1); }
     return b;
@@ -161,7 +165,8 @@ extern "C" struct llama_model * llama_load_model_from_file(const char * path, st
     else if (arch == "bloom") hp.arch = PI_ARCH_BLOOM;
     else if (arch == "mpt") hp.arch = PI_ARCH_MPT;
     else if (arch == "stablelm") hp.arch = PI_ARCH_STABLELM;
-    else { fprintf(stderr, "llama_load_model_from_file: architecture '%s' is outside this engine's scope (llama, falcon, baichuan, starcoder, refact, bloom, mpt, stablelm; not persimmon)\n", arch.c_str()); return nullptr; }
+    else if (arch == "persimmon") hp.arch = PI_ARCH_PERSIMMON;
+    else { fprintf(stderr, "llama_load_model_from_file: architecture '%s' is outside this engine's scope (llama, falcon, baichuan, starcoder, persimmon, refact, bloom, mpt, stablelm)\n", arch.c_str()); return nullptr; }
     m->name = f.get_str("general.name", "");
     hp.n_ctx_train = (int) f.get_u32(arch + ".context_length", 0);
     hp.n_embd      = (int) f.get_u32(arch + ".embedding_length", 0);
@@ -197,9 +202,13 @@ extern "C" struct llama_model * llama_load_model_from_file(const char * path, st
                 if (!f.find(arch + ".attention.max_alibi_bias")) { fprintf(stderr, "llama_load_model_from_file: mpt needs %s.attention.max_alibi_bias (llama.cpp:2359)\n", arch.c_str()); return nullptr; }
                 break;
             case PI_ARCH_STABLELM:  b.rope = 2; b.gated = true; break;
+            case PI_ARCH_PERSIMMON:                                                      // llama.cpp:4329-4538: MHA asserted (:4368), vectors of 64 (:3105-3108)
+                b.fused_qkv = true; b.rope = 2; b.relu_sqr = true; b.qk_norm = true;
+                if (hp.n_head_kv != hp.n_head || hp.head_dim() != 64) { fprintf(stderr, "llama_load_model_from_file: persimmon needs n_head_kv == n_head and a head width of 64 (llama.cpp:4368, 3105)\n"); return nullptr; }
+                break;
             default: break;
         }
-        if (b.rope == 2 && (hp.n_rot <= 0 || hp.n_rot % 2 || hp.head_dim() % hp.n_rot)) { fprintf(stderr, "llama_load_model_from_file: n_rot %d does not divide head_dim %d\n", hp.n_rot, hp.head_dim()); return nullptr; }
+        if (b.rope == 2 && !b.qk_norm && (hp.n_rot <= 0 || hp.n_rot % 2 || hp.head_dim() % hp.n_rot)) { fprintf(stderr, "llama_load_model_from_file: n_rot %d does not divide head_dim %d\n", hp.n_rot, hp.head_dim()); return nullptr; }
     }
     if (hp.head_dim() != 64 && hp.head_dim() != 128) { fprintf(stderr, "llama_load_model_from_file: head_dim %d not supported by the attention kernel\n", hp.head_dim()); return nullptr; }
     if (!m->vocab.load(f, err)) { fprintf(stderr, "llama_load_model_from_file: %s\n", err.c_str()); return nullptr; }
@@ -225,7 +234,7 @@ extern "C" enum llama_vocab_type llama_vocab_type(const struct llama_model * m) 
 extern "C" uint64_t llama_model_size(const struct llama_model * m) { return m->n_bytes; }
 extern "C" uint64_t llama_model_n_params(const struct llama_model * m) { return m->n_elements; }
 extern "C" int llama_model_desc(const struct llama_model * m, char * buf, size_t n) {
-    static const char * names[] = { "llama", "falcon", "baichuan", "starcoder", "refact", "bloom", "mpt", "stablelm" };
+    static const char * names[] = { "llama", "falcon", "baichuan", "starcoder", "refact", "bloom", "mpt", "stablelm", "persimmon" };
     return snprintf(buf, n, "%s %s", names[m->hparams.arch], m->name.c_str());
 }
 

@@ -372,7 +372,10 @@ __global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g,
         float us[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
         if (which == 0) { const float4 uv = *(const float4 *) (u + (int64_t) t * n + e0); us[0] = uv.x; us[1] = uv.y; us[2] = uv.z; us[3] = uv.w; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const float a = pi_h2f(tab[pi_f2h(gs[i])]); ys[i] = which == 0 ? a * us[i] : a; }
+        for (int i = 0; i < 4; i++) {
+            if (which == 2) { const float a = gs[i] > 0.0f ? gs[i] : 0.0f; ys[i] = a * a; }                 // ggml_relu then ggml_sqr (LLM_FFN_RELU_SQR, ggml.c:1415, 1407)
+            else { const float a = pi_h2f(tab[pi_f2h(gs[i])]); ys[i] = which == 0 ? a * us[i] : a; }
+        }
     }
     if (vdt == PI_Q8_K) wave_quantize_q8_K(ys, lane, t, c0 >> 8, n >> 8, (int8_t *) qs, (float *) dd, bsums, F);
     else if (e0 < n_pad) wave_quantize_q8_0(ys, lane, (int64_t) t * ng, e0, (uint32_t *) qs, (uint16_t *) dd, vdt == PI_Q8_1 ? (float *) bsums : nullptr);
@@ -468,6 +471,58 @@ __global__ void k_rope_kv(const float * __restrict__ q, const float * __restrict
     const float x0 = src[i0], x1 = src[i1];
     dst[i0] = pi_f2h(x0 * c.x - x1 * c.y);
     dst[i1] = pi_f2h(x0 * c.y + x1 * c.x);
+}
+
+// build_persimmon's attention inputs (llama.cpp:4372-4460): the fused QKV rows are [head][q | k | v][64]; Q and K get a LayerNorm over the 64 values of their head
+// (attn_q_norm / attn_k_norm, llm_build_norm: norm, * w, + b), then NeoX RoPE over the FIRST 32 values of the head (n_dims = 32: pairs (i, i + 16), theta_scale from 32) while
+// the other 32 pass, then the f16 rounding of the cache / of the KQ product.  One workgroup of 64 threads per (token, head); the statistics are the reference's sequential
+// double sums (ggml.c:8959-9008), by one thread each for Q and K.  cs: table of pi_rope_table_create_ex(n_pos, 32, 32, ...) = [pos][16][2]
+__global__ void __launch_bounds__(64) k_persimmon_qkv(const float * __restrict__ qkv, int n_head, const float * __restrict__ qw, const float * __restrict__ qb,
+                                                     const float * __restrict__ kw, const float * __restrict__ kb, float eps, const int32_t * __restrict__ pos,
+                                                     const float * __restrict__ cs, int kv_head_, const int32_t * __restrict__ dyn,
+                                                     uint16_t * __restrict__ q16, uint16_t * __restrict__ kc, uint16_t * __restrict__ vc, const int32_t * __restrict__ abort_w) {
+    if (pi_aborted(abort_w)) return;
+    __shared__ float sx[2][64];
+    __shared__ float st[4];
+    const int t = blockIdx.x, h = blockIdx.y, e = threadIdx.x;
+    const int n_embd = n_head * 64;
+    const float * base = qkv + (int64_t) t * 3 * n_embd + (int64_t) h * 192;
+    const float xq = base[e], xk = base[64 + e], xv = base[128 + e];
+    sx[0][e] = xq; sx[1][e] = xk;
+    __syncthreads();
+    if (e < 2) {
+        const float * x = sx[e];
+        double sum = 0.0;
+        for (int i = 0; i < 64; i++) sum += (double) x[i];
+        const float mean = (float) (sum / 64);
+        double sum2 = 0.0;
+        for (int i = 0; i < 64; i++) { const float v = x[i] - mean; sum2 += (double) (v * v); }
+        const float var = (float) (sum2 / 64);
+        st[2 * e] = mean; st[2 * e + 1] = 1.0f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    float yq = (xq - st[0]) * st[1]; yq = yq * qw[e]; yq = yq + qb[e];
+    float yk = (xk - st[2]) * st[3]; yk = yk * kw[e]; yk = yk + kb[e];
+    __syncthreads();
+    sx[0][e] = yq; sx[1][e] = yk;
+    __syncthreads();
+    const int cell = pi_cell_of(dyn, kv_head_, t);
+    uint16_t * dq = q16 + (int64_t) t * n_embd + h * 64, * dk = kc + (int64_t) cell * n_embd + h * 64, * dv = vc + (int64_t) cell * n_embd + h * 64;
+    dv[e] = pi_f2h(xv);
+    if (e < 16) {
+        const float2 c = *(const float2 *) (cs + ((int64_t) pos[t] * 16 + e) * 2);
+        { const float x0 = sx[0][e], x1 = sx[0][e + 16]; dq[e] = pi_f2h(x0 * c.x - x1 * c.y); dq[e + 16] = pi_f2h(x0 * c.y + x1 * c.x); }
+        { const float x0 = sx[1][e], x1 = sx[1][e + 16]; dk[e] = pi_f2h(x0 * c.x - x1 * c.y); dk[e + 16] = pi_f2h(x0 * c.y + x1 * c.x); }
+    } else if (e >= 32) { dq[e] = pi_f2h(yq); dk[e] = pi_f2h(yk); }
+}
+extern "C" int pi_op_persimmon_qkv_store(const float * qkv, int n_head, int hd, const float * qw, const float * qb, const float * kw, const float * kb, float eps, const int32_t * pos,
+                                         const void * table_, int n_tok, int kv_head, uint16_t * q16, uint16_t * kc, uint16_t * vc, const int32_t * dyn_dev, void * stream) {
+    if (n_tok <= 0) return 0;
+    const pi_rope_table * t = (const pi_rope_table *) table_;
+    if (hd != 64 || t->head_dim != 32 || t->n_rot != 32) { pi_set_error("pi_op_persimmon_qkv_store: head width %d (the reference fixes 64, llama.cpp:3105-3108) with a rope table of %d/%d (needs 32/32)", hd, t->head_dim, t->n_rot); return -1; }
+    hipLaunchKernelGGL(k_persimmon_qkv, dim3(n_tok, n_head), dim3(64), 0, (hipStream_t) stream, qkv, n_head, qw, qb, kw, kb, eps, pos, t->cs, kv_head, dyn_dev, q16, kc, vc, pi_abort_word());
+    PI_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float * v, int64_t q_stride, int64_t k_stride, int64_t v_stride,

@@ -111,6 +111,7 @@ def _declare(lib):
     lib.pi_rope_table_free.argtypes = [vp]
     lib.pi_alibi_slopes.argtypes = [i32, f32, vp]; lib.pi_alibi_slopes.restype = None
     lib.pi_op_attention_alibi.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    lib.pi_op_persimmon_qkv_store.argtypes = [vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.pi_op_add_bias.argtypes = [vp, vp, i64, i32, vp]
     lib.pi_op_clamp.argtypes = [vp, f32, f32, i64, vp]
     lib.pi_op_rope_kv_store.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -35,6 +35,7 @@ SPECS = {
     "tiny-bloom":      ("bloom", 2, 384, 6, 6, 768, 512, 512),
     "tiny-mpt":        ("mpt", 2, 256, 4, 4, 1024, 512, 512),
     "tiny-stablelm":   ("stablelm", 2, 256, 4, 4, 512, 512, 512),      # rotates n_rot = 16 of the 64 values of a head
+    "tiny-persimmon":  ("persimmon", 2, 256, 4, 4, 512, 512, 512),     # head width 64 as the reference requires; per-head Q / K LayerNorm, relu^2
 }
 # extra hyper-parameters of the synthetic files (name -> value): MPT's ALiBi bound and QKV clamp, StableLM's partial rotary width
 EXTRA_KV = {
@@ -42,9 +43,9 @@ EXTRA_KV = {
     "tiny-stablelm": {"rope.dimension_count": 16},
 }
 RMS_ARCHS = ("llama", "baichuan", "refact")
-NORM_BIAS_ARCHS = ("falcon", "starcoder", "bloom", "stablelm")
-PROJ_BIAS_ARCHS = ("starcoder", "bloom")
-FUSED_QKV_ARCHS = ("falcon", "starcoder", "bloom", "mpt")
+NORM_BIAS_ARCHS = ("falcon", "starcoder", "bloom", "stablelm", "persimmon")
+PROJ_BIAS_ARCHS = ("starcoder", "bloom", "persimmon")
+FUSED_QKV_ARCHS = ("falcon", "starcoder", "bloom", "mpt", "persimmon")
 GATED_ARCHS = ("llama", "baichuan", "refact", "stablelm")
 
 FTYPE_IDS = {"f32": 0, "f16": 1, "q4_0": 2, "q8_0": 7, "q4_k_s": 14, "q4_k_m": 15, "q5_k_s": 16, "q5_k_m": 17, "q6_k": 18}
@@ -148,6 +149,9 @@ def tensor_plan(spec_name, ftype, falcon_two_norms=None, layers=None):
             else:
                 plan += [(p + "attn_q.weight", (n_embd, n_embd), fix(base, n_embd), "proj"), (p + "attn_k.weight", (n_embd, n_gqa), fix(base, n_embd), "proj"),
                          (p + "attn_v.weight", (n_embd, n_gqa), fix(v_type(i) if kq else base, n_embd), "proj")]
+            if arch == "persimmon":                                         # llama.cpp:3105-3108: vectors of 64
+                plan += [(p + "attn_q_norm.weight", (64,), G.T_F32, "gain"), (p + "attn_q_norm.bias", (64,), G.T_F32, "bias"),
+                         (p + "attn_k_norm.weight", (64,), G.T_F32, "gain"), (p + "attn_k_norm.bias", (64,), G.T_F32, "bias")]
             plan.append((p + "attn_output.weight", (n_embd, n_embd), fix(base, n_embd), "out"))
             if pb_:
                 plan.append((p + "attn_output.bias", (n_embd,), G.T_F32, "bias"))

@@ -36,8 +36,9 @@ MODELS = [  # (file stem, spec, ftype, seed)
     ("tiny_bloom_q4_0", "tiny-bloom", "q4_0", 25),
     ("tiny_mpt_q4_k_m", "tiny-mpt", "q4_k_m", 26),
     ("tiny_stablelm_q4_k_m", "tiny-stablelm", "q4_k_m", 27),
+    ("tiny_persimmon_q4_k_m", "tiny-persimmon", "q4_k_m", 28),
 ]
-REF_BUILDERS = {"baichuan", "starcoder", "refact", "bloom", "mpt", "stablelm"}
+REF_BUILDERS = {"baichuan", "starcoder", "refact", "bloom", "mpt", "stablelm", "persimmon"}
 
 
 def ref_quantizer():
@@ -224,6 +225,8 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["q3k"]:                    # later addition: does not regenerate the other fixtures
         kernel_vectors_q3k()
         model_vectors(only=["tiny_llama_q3_k_m"])
+    elif sys.argv[1:] == ["persimmon"]:
+        model_vectors(only=["tiny_persimmon_q4_k_m"])
     elif sys.argv[1:] == ["archs"]:                  # round 3: the generic-block architectures
         model_vectors(only=[m[0] for m in MODELS if synth.SPECS[m[1]][0] in REF_BUILDERS])
     elif sys.argv[1:] == ["q2k"]:

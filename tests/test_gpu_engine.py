@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20,
          # the reference's other graph builders (llama.cpp:3985-4939): goldens from its OWN loader + build_* (tests/golden/make_golden.py archs)
-         "tiny_baichuan7_q4_0": 21, "tiny_baichuan13_q4_0": 22, "tiny_starcoder_q4_0": 23, "tiny_refact_q4_0": 24, "tiny_bloom_q4_0": 25, "tiny_mpt_q4_k_m": 26, "tiny_stablelm_q4_k_m": 27}
+         "tiny_baichuan7_q4_0": 21, "tiny_baichuan13_q4_0": 22, "tiny_starcoder_q4_0": 23, "tiny_refact_q4_0": 24, "tiny_bloom_q4_0": 25, "tiny_mpt_q4_k_m": 26, "tiny_stablelm_q4_k_m": 27, "tiny_persimmon_q4_k_m": 28}
 LOGIT_TOL = 1e-3
 
 
@@ -118,7 +118,7 @@ def greedy_reference(stem, n_prompt, n_gen):
                                       # where its cells lie and "speculative == plain greedy" is not a property of the reference either; those targets are pinned run by run against the
                                       # oracle on the same cells instead (test_every_run_of_a_speculative_generation_equals_the_oracle).  As DRAFTS they only propose.
                                       ("tiny_starcoder_q4_0", "tiny_mpt_q4_k_m"), ("tiny_stablelm_q4_k_m", "tiny_bloom_q4_0"), ("tiny_starcoder_q4_0", "tiny_stablelm_q4_k_m"),
-                                      ("tiny_stablelm_q4_k_m", "tiny_refact_q4_0"), ("tiny_baichuan7_q4_0", "tiny_baichuan13_q4_0")])
+                                      ("tiny_stablelm_q4_k_m", "tiny_refact_q4_0"), ("tiny_baichuan7_q4_0", "tiny_baichuan13_q4_0"), ("tiny_persimmon_q4_k_m", "tiny_starcoder_q4_0")])
 @pytest.mark.parametrize("n_draft,n_parallel,p_split,min_spec", [(3, 3, 0.9, 0), (3, 3, 0.9, 1), (8, 1, 0.9, 2), (4, 3, 0.05, 3)])
 def test_pipeinfer_driver_is_lossless(LL, tgt, dft, n_draft, n_parallel, p_split, min_spec):
     """accepted-token sequence of the asynchronous speculative driver == the reference target's greedy continuation.
@@ -315,7 +315,9 @@ def test_target_only_mode_matches(LL):
 
 
 
-@pytest.mark.parametrize("stem,ranges", [("tiny_llama_b_q4_k_m", "0-1,1-3"), ("tiny_llama_q4_k_m", "0-2"), ("tiny_falcon40_q4_k_m", "0-1,1-2")])
+@pytest.mark.parametrize("stem,ranges", [("tiny_llama_b_q4_k_m", "0-1,1-3"), ("tiny_llama_q4_k_m", "0-2"), ("tiny_falcon40_q4_k_m", "0-1,1-2"),
+                                         # the generic block: learned positions / the embeddings' LayerNorm belong to the FIRST stage only, the ALiBi slopes to every stage
+                                         ("tiny_starcoder_q4_0", "0-1,1-2"), ("tiny_bloom_q4_0", "0-1,1-2"), ("tiny_mpt_q4_k_m", "0-1,1-2"), ("tiny_stablelm_q4_k_m", "0-1,1-2"), ("tiny_persimmon_q4_k_m", "0-1,1-2")])
 def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
     """head proxy context + pipeinfer_stage_run on layer ranges == the whole model in one context (tests/pipeline_gpu_worker.py).
     Runs in its own process (several contexts of several models; keeps the parent's device state clean)."""
@@ -372,7 +374,8 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
 
 @pytest.mark.parametrize("tgt,dft,n_layer", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 3), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 2), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0", 2),
                                              ("tiny_mpt_q4_k_m", "tiny_starcoder_q4_0", 2), ("tiny_bloom_q4_0", "tiny_stablelm_q4_k_m", 2), ("tiny_starcoder_q4_0", "tiny_refact_q4_0", 2),
-                                             ("tiny_stablelm_q4_k_m", "tiny_mpt_q4_k_m", 2), ("tiny_baichuan13_q4_0", "tiny_baichuan7_q4_0", 40)])
+                                             ("tiny_stablelm_q4_k_m", "tiny_mpt_q4_k_m", 2), ("tiny_baichuan13_q4_0", "tiny_baichuan7_q4_0", 40),
+                                             ("tiny_persimmon_q4_k_m", "tiny_stablelm_q4_k_m", 2), ("tiny_starcoder_q4_0", "tiny_persimmon_q4_k_m", 2)])
 def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_layer):
     """the PipeInfer driver runs with the target behind a proxy context; each run's metadata block (tokens, positions, cells,
     visibility mask) is executed by the HIP stage AND by the oracle's forward pass on the same cells: logits must agree bit for

@@ -627,3 +627,43 @@ def test_abort_word_stops_kernels_of_the_cancelled_run_only(gpu):
     assert word.get(np.int32)[0] == 8 << 1
     lib.pi_weight_free(w)
     del flag
+
+
+def test_persimmon_attention_inputs_and_relu_sqr_exact(gpu):
+    """build_persimmon (llama.cpp:4372-4460): fused QKV rows laid out [head][q | k | v][64], a LayerNorm of Q and of K over the 64 values of their head (sequential double
+    sums like ggml_compute_forward_norm_f32), NeoX RoPE with n_dims = 32 over a view of the first 32 values while the other 32 pass, f16 rounding into the query buffer and
+    the cache rows; and its activation relu(x)^2 (LLM_FFN_RELU_SQR) in front of the Q8_K quantiser"""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    o = O.Impl("oracle")
+    rng = np.random.default_rng(64)
+    n_tok, n_head, hd, n_ctx, kv_head = 5, 6, 64, 40, 11
+    n_embd = n_head * hd
+    qkv = rng.standard_normal((n_tok, n_head, 3, hd)).astype(np.float32)
+    qw, qb, kw, kb = [(s0 + 0.1 * rng.standard_normal(hd)).astype(np.float32) for s0 in (1.0, 0.0, 1.0, 0.0)]
+    pos = np.array([0, 2, 9, 130, 400], np.int32)
+    eps = 1e-5
+
+    def want(x, w, b):                                                      # [n_tok, n_head, hd]
+        y = o.norm(x.reshape(-1, hd), eps).reshape(x.shape) * w + b
+        out = y.copy()
+        out[:, :, :32] = o.rope_ex(np.ascontiguousarray(y[:, :, :32]), pos, 2, 32)
+        return O.f32_to_f16_bits(out)
+    table = lib.pi_rope_table_create_ex(512, 32, 32, 10000.0, 1.0, 1)
+    q16, kc, vc = U.Dev(nbytes=2 * n_tok * n_embd), U.Dev(np.zeros(n_ctx * n_embd, np.uint16)), U.Dev(np.zeros(n_ctx * n_embd, np.uint16))
+    xd, pd = U.Dev(qkv), U.Dev(pos)
+    wd = [U.Dev(a) for a in (qw, qb, kw, kb)]
+    L.check(lib.pi_op_persimmon_qkv_store(xd.ptr, n_head, hd, wd[0].ptr, wd[1].ptr, wd[2].ptr, wd[3].ptr, eps, pd.ptr, table, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
+    assert np.array_equal(q16.get(np.uint16, (n_tok, n_head, hd)), want(qkv[:, :, 0], qw, qb))
+    assert np.array_equal(kc.get(np.uint16, (n_ctx, n_head, hd))[kv_head:kv_head + n_tok], want(qkv[:, :, 1], kw, kb))
+    assert np.array_equal(vc.get(np.uint16, (n_ctx, n_head, hd))[kv_head:kv_head + n_tok], O.f32_to_f16_bits(qkv[:, :, 2]))
+    lib.pi_rope_table_free(table)
+    n = 1024
+    g = np.stack([signal(n, 30 + s0) for s0 in range(3)])
+    gd = U.Dev(g)
+    q8 = U.Dev(nbytes=lib.pi_q8_nbytes(O.Q8_K, n, 3))
+    L.check(lib.pi_op_act_quantize(gd.ptr, None, 2, n, 3, O.Q8_K, q8.ptr, None))
+    h = np.maximum(g, np.float32(0.0)); h = h * h
+    got = U.q8_as_ref_blocks(O.Q8_K, *U.q8_planes(lib, O.Q8_K, n, 3, q8))
+    for t in range(3):
+        assert np.array_equal(got[t], o.quantize_act(O.Q8_K, h[t]))
