@@ -578,12 +578,14 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
 }
 // coalescing contexts: the feeder does not run ahead of the GPU across passes, and before it composes the next pass it gives the caller the chance to react to the one
 // that has just finished — cancel what it invalidates, start what follows from it — so that those runs travel together.  Ends at once when the caller is blocked waiting
-// for a run, when it has finished a run of that pass and called start / iprobe since, or after PIPEINFER_REACTION_US (3 ms: a drafted tree of three steps).
+// for a run, when it has finished a run of that pass and called start / iprobe since, or after PIPEINFER_REACTION_US (10 ms).
+// Measured (tools_dev/reaction_sweep.sh): a window about as long as ONE draft step cuts the caller off in the middle of its reaction — 3 ms gave 97 tok/s on 70B + TinyLlama (2.5 ms
+// per draft step) against 102 from 6 ms up, and 65 against 76 on Falcon-40B + Falcon-7B (4.6 ms per step); beyond two steps the other conditions end the wait first, 7B is indifferent.
 static void wait_for_reaction(llama_context * ctx) {
     if (!ctx->pass_pending) return;
     (void) hipEventSynchronize(ctx->pass_event);
     ctx->pass_pending = false;
-    static const int64_t tmo = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 3000;
+    static const int64_t tmo = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
     const int64_t t0 = time_us();
     for (int spin = 0; ; spin++) {
         if (ctx->waiters.load() > 0) return;
