@@ -34,7 +34,7 @@ LLAMA_API int  pipeinfer_context_set_segments(struct llama_context * ctx, int la
  * — up to max_tokens tokens — into ONE forward pass.  A pass streams the stage's weights once whatever its width, so two queued runs cost ~1.4x one instead of 2x; every
  * token's logits and KV entries are the bits it would get alone (the kernels are exact at every batch width; a token attends to the cells of its own run's mask; a later
  * run's reads of an earlier run's cells are satisfied inside the pass, like causal attention inside any batch).  The feeder then does not run ahead of the GPU across
- * passes and waits up to PIPEINFER_REACTION_US (3000) for the caller to react to a finished pass before it composes the next one.  For one GPU that serves both models:
+ * passes and waits up to PIPEINFER_REACTION_US (10000 = 10 ms) for the caller to react to a finished pass before it composes the next one.  For one GPU that serves both models:
  * the PipeInfer driver keeps a non-speculative and one or more speculative runs queued behind the run in flight (speculative.cpp:1182-1275). */
 LLAMA_API int  pipeinfer_context_set_coalescing(struct llama_context * ctx, int max_tokens);
 /* 0: launch the decode kernels one by one instead of replaying the captured HIP graph (profiling / per-kernel event timing) */

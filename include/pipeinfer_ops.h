@@ -65,6 +65,9 @@ PI_API size_t  pi_weight_nbytes(const pi_weight * w);  /* HBM bytes == ggml_nbyt
 PI_API size_t  pi_weight_copy_nbytes(const pi_weight * w); /* HBM bytes of the second, tile-major copy the matrix-core kernel reads (0 without one) */
 /* uploads of the calling thread from now on do (1, default) / do not (0) make that copy: a context that never decodes more than two tokens at once has no use for it */
 PI_API void    pi_weight_set_mq_copies(int on);
+/* gives a weight that was uploaded without the copy its tile-major copy now, from the same GGUF bytes (no-op when it has one or its type has no matrix-core kernel); 0 ok
+   (also when HBM is short: the weight then stays on the VALU kernel), < 0 on a failed copy */
+PI_API int     pi_weight_ensure_mq_copy(pi_weight * w, const void * host_blocks, void * stream);
 PI_API const void * pi_weight_data(const pi_weight * w); /* device address of the (repacked) tensor bytes */
 /* reads [p, p + bytes) once with up to `workgroups` workgroups (0: as many as the bytes need): warms the memory-side Infinity Cache */
 PI_API int     pi_op_prefetch(const void * p, size_t bytes, int workgroups, void * stream);

@@ -71,7 +71,8 @@ bool context_prepare(llama_context * ctx, std::string & err) {
     // that thread exists: captured lazily they would be recorded by the feeder in the middle of a generation, beside the caller's own HIP calls (the draft's first runs,
     // pinned allocations, cancels) — the combination behind this runtime's rare capture failures, and (seen once in 36 repetitions of the segmented-target tests) a stall.
     // Prompt-sized passes are still captured on first use: the caller is then blocked in llama_decode on that very run.
-    if (ctx->seg_layers > 0 && !context_precapture(ctx, 8)) { ctx->last_error = "graph capture of the narrow pass widths failed: " + ctx->last_error; err = ctx->last_error; return false; }
+    // (pipeinfer_context_set_coalescing called BEFORE the first decode: its pass widths are captured here too, not by the feeder in mid-generation)
+    if (ctx->seg_layers > 0 && !context_precapture(ctx, std::max(8, ctx->coalesce_max.load()))) { ctx->last_error = "graph capture of the narrow pass widths failed: " + ctx->last_error; err = ctx->last_error; return false; }
     return true;
 }
 static bool context_prepare_impl(llama_context * ctx, std::string & err) {
@@ -419,7 +420,7 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
                 }
                 if (ok) ok = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) == hipSuccess;
                 if (graph) (void) hipGraphDestroy(graph);
-                if (!ok) { ge.exec = nullptr; fprintf(stderr, "llama_decode: graph capture of %d token(s), segment %d, attempt %d failed (%s): %s\n", n_tokens, seg, attempt, hipGetErrorString(hipGetLastError()), ctx->last_error.c_str()); }
+                if (!ok) { ge.exec = nullptr; fprintf(stderr, "llama_decode: graph capture of %d token(s), segment %d, attempt %d failed (%s): %s\n", n_tokens, seg, attempt, hipGetErrorString(hipGetLastError()), ctx->last_error.str().c_str()); }
             }
             if (!ok) ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error;
         }
@@ -477,10 +478,11 @@ static bool yield_to_urgent(const llama_context * ctx) {                      //
 }
 
 // ---- feeder thread of a segmented context ---------------------------------------------------------------------------------------------------
-static bool pass_cancelled(const pi_pass & p) {
-    for (const pi_run * r : p.runs) if (!r->canceled && !r->cancel_req.load()) return false;
+static bool runs_cancelled(const std::vector<pi_run *> & runs) {
+    for (const pi_run * r : runs) if (!r->canceled && !r->cancel_req.load()) return false;
     return true;
 }
+static bool pass_cancelled(const pi_pass & p) { return runs_cancelled(p.runs); }    // (callers hold fmu: finished members leave p.runs under it)
 // May run q join a pass whose members (all started before q) are `members`?  Inside a pass every token's K/V of a layer are stored before that layer's attention, so a
 // member's reads of an EARLIER member's cells see what they would see one run after the other.  What a pass cannot reproduce is a cell that changes hands inside it: q
 // writing a cell that a member also writes, or that a member attends to expecting older content — e.g. the PipeInfer driver frees the cell of a speculative run's first
@@ -511,8 +513,8 @@ static bool pass_conflict(const llama_context * ctx, const std::vector<pi_run *>
 
 // one input block for a pass of several runs: their tokens, positions and mask rows one after the other, the cell of every token, n_kv = the widest run's
 // (cells past a run's own n_kv are masked for its tokens and contribute exact zeros, like every masked cell inside it)
-static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
-    const int n = pass.n_tokens, words = (ctx->n_ctx + 31) / 32;
+static const void * compose_pass(llama_context * ctx, const std::vector<pi_run *> & members, int n_tokens) {
+    const int n = n_tokens, words = (ctx->n_ctx + 31) / 32;
     const size_t need = (size_t) n * 8 + 16 + (size_t) n * 8 + (size_t) n * words * 4;
     if (need > ctx->pass_host_cap) {
         const size_t cap = std::max(need, (size_t) std::max(ctx->coalesce_max.load(), 1) * (16 + (size_t) words * 4) + 16);
@@ -524,7 +526,7 @@ static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
     uint8_t * blk = ctx->pass_host[ctx->pass_slot++ & 3];
     int32_t * tok = (int32_t *) blk, * pos = tok + n, * dyn = pos + n, * cell = dyn + 4, * nkv = cell + n; uint32_t * mask = (uint32_t *) (nkv + n);
     int at = 0, n_kv = 0;
-    for (const pi_run * r : pass.runs) {
+    for (const pi_run * r : members) {
         const int m = r->n_tokens;
         const int32_t * rt = (const int32_t *) r->meta_host, * rp = rt + m, * rd = rp + m; const uint32_t * rm = (const uint32_t *) (rd + 4);
         memcpy(tok + at, rt, (size_t) 4 * m); memcpy(pos + at, rp, (size_t) 4 * m);
@@ -538,14 +540,17 @@ static const void * compose_pass(llama_context * ctx, const pi_pass & pass) {
 }
 // enqueues one pass (one run, or several runs the feeder took together) on the context's stream; every member's events and state are final afterwards
 static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass) {
-    const std::vector<pi_run *> & runs = pass->runs;
+    // the members as they are NOW: once a member reaches state 2 the caller may finish it, which erases it from pass->runs (under fmu) and recycles the object —
+    // the loops below walk this copy, and the last thing the feeder does with a member is that very store
+    std::vector<pi_run *> runs;
+    { std::lock_guard<std::mutex> lk(ctx->fmu); runs = pass->runs; }
     for (pi_run * r : runs) r->state.store(1);
     bool ok = true, full = false;
     for (pi_run * r : runs) ok = hipEventRecord(r->begin, ctx->stream) == hipSuccess && ok;
     hipEvent_t seg_done[2] = { ctx->seg_events[0], ctx->seg_events[1] };
     const int n = pass->n_tokens;
-    if (!pass_cancelled(*pass)) {
-        const void * meta = runs.size() == 1 ? (const void *) runs[0]->meta_host : compose_pass(ctx, *pass);
+    if (!runs_cancelled(runs)) {
+        const void * meta = runs.size() == 1 ? (const void *) runs[0]->meta_host : compose_pass(ctx, runs, pass->n_tokens);
         ok = ok && meta != nullptr;
         const int nseg = n_segments(ctx), kv_head = ok ? ((const int32_t *) meta)[2 * n] : 0;
         if (ok) ok = launch_inputs(ctx, n, meta, nullptr);
@@ -553,7 +558,7 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
         for (; ok && seg < nseg; seg++) {
             if (seg >= 2) (void) hipEventSynchronize(seg_done[seg & 1]);       // at most two segments ahead of the GPU
             (void) yield_to_urgent(ctx);
-            if (pass_cancelled(*pass)) break;                                   // llama_cancel_run reached every run of the pass while it was in flight
+            if (runs_cancelled(runs)) break;                                    // llama_cancel_run reached every run of the pass while it was in flight
             ok = launch_abort_begin(ctx, pass->id);
             if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink, runs.size() > 1);
             if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
@@ -571,8 +576,7 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
     if (ctx->coalesce_max.load() > 1 && ctx->pass_event && hipEventRecord(ctx->pass_event, ctx->stream) == hipSuccess) { ctx->pass_pending = true; ctx->pass_first_id = runs[0]->run_id; }
     if (!ok) {                                                                 // NOT the same thing as a cancelled run: finish reports it (the driver ends the generation)
         for (pi_run * r : runs) r->failed = true;
-        std::lock_guard<std::mutex> lk(ctx->fmu);
-        fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.c_str());
+        fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.str().c_str());
     }
     for (pi_run * r : runs) r->state.store(2);
 }
@@ -695,7 +699,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
             run->launched = ok;
             ctx->stat_calls++;
         }
-        if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str()); give_back(); ctx->pool.push_back(run); return nullptr; }
+        if (!ok) { fprintf(stderr, "llama_decode: %s\n", ctx->last_error.str().c_str()); give_back(); ctx->pool.push_back(run); return nullptr; }
         ctx->inflight.push_back(run);
         rc = 0;
         return run;
@@ -725,7 +729,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     run->state.store(2);
     if (!ok) {
         // the cells find_slot handed to this run go back: nothing was (or will be) written to them
-        fprintf(stderr, "llama_decode: %s\n", ctx->last_error.c_str());
+        fprintf(stderr, "llama_decode: %s\n", ctx->last_error.str().c_str());
         give_back();
         urgent_end(ctx);
         ctx->pool.push_back(run);
@@ -769,10 +773,14 @@ void context_cancel_run(llama_context * ctx, pi_run * r) {
         fprintf(stderr, "llama_cancel_run: %s\n", pi_last_error());
 }
 
-void stage_abort_current(llama_context * ctx) {
-    const int32_t rid = ctx->stage_run_id.load();
-    if (rid == 0 || !ctx->abort_host || !ctx->abort_dev || !ctx->ctl_stream || ctx->abort_host[rid & 255]) return;
-    ctx->abort_host[rid & 255] = 1;                                            // picked up by the run's next pi_op_abort_begin ...
+// Stops run `rid` of this stage — and only that run.  Everything below is keyed by the id: the host flag is the slot of THAT id, the compare-and-swap on the device word
+// hits only while THAT run is the one executing, so a call that arrives after the serve loop has moved on to the next run changes nothing for it.
+void stage_abort_run(llama_context * ctx, int32_t rid) {
+    if (rid == 0 || ctx->stage_run_id.load(std::memory_order_acquire) != rid) return;
+    if (!ctx->abort_host || !ctx->abort_dev || !ctx->ctl_stream) return;
+    volatile int32_t * flag = ctx->abort_host + (rid & 255);
+    if (*flag) return;
+    *flag = 1;                                                                 // picked up by the run's next pi_op_abort_begin ...
     (void) pi_op_abort_cancel(ctx->abort_dev, rid, ctx->ctl_stream);           // ... and hits the kernels already enqueued (only if that run is still the one executing)
 }
 
@@ -807,7 +815,7 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     (void) hipEventCreate(&e0); (void) hipEventCreate(&e1); (void) hipEventCreate(&ec);
     (void) hipEventRecord(e0, s);
     // the run's identity on the device: its kernels carry the context's abort word, so a cancel that reaches this process while the stage is inside the run
-    // (stage_abort_current, called by the transport's watcher) stops it at the next KERNEL, not at the next segment (llama.cpp:5665-5687 polls between graph nodes)
+    // (stage_abort_run, called by the transport's watcher) stops it at the next KERNEL, not at the next segment (llama.cpp:5665-5687 polls between graph nodes)
     const int32_t rid = (++ctx->run_counter) & 0x3fffffff;
     if (ctx->abort_host) ctx->abort_host[rid & 255] = 0;
     ctx->stage_run_id.store(rid);
@@ -884,7 +892,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
         if (run->failed) {
             // a launch of this run failed (graph capture, a kernel launch, a copy): that is an error, not a cancelled run — the caller gets -1, the cells
             // find_slot allotted go back (nothing valid was written to them) and the run leaves the queue
-            { std::lock_guard<std::mutex> lk(ctx->fmu); if (ctx->last_error.empty()) ctx->last_error = "a launch of the run failed"; }
+            if (ctx->last_error.empty()) ctx->last_error = "a launch of the run failed";
             ctx->cells->release_cells(run->kv_head, run->n_tokens);
             ctx->last_n_tokens = 0;
             if (run->pass) { std::lock_guard<std::mutex> lk(ctx->fmu); auto & v = run->pass->runs; v.erase(std::remove(v.begin(), v.end(), run), v.end()); run->pass.reset(); }

@@ -59,6 +59,7 @@ struct pi_layer {
     float * bqkv = nullptr, * bo = nullptr, * ffn_up_b = nullptr, * ffn_down_b = nullptr;       // biases of the projections (StarCoder, Bloom, Persimmon)
     float * attn_q_norm = nullptr, * attn_q_norm_b = nullptr, * attn_k_norm = nullptr, * attn_k_norm_b = nullptr;   // Persimmon's per-head LayerNorm of Q and K (64 values)
     bool loaded = false;
+    bool has_mq = false;                      // its matrices carry the tile-major copies of the matrix-core kernel (made when a context whose passes can be >= 3 tokens wide loads the layer)
 };
 
 struct llama_model {
@@ -73,6 +74,9 @@ struct llama_model {
     float * alibi_slopes = nullptr;                                                              // f32 [n_head] on the device when block.alibi > 0
     std::vector<pi_layer> layers;
     std::vector<void *> f32_allocs;
+    struct matrix_ref { pi_weight * w; const void * host; int layer; };                           // every uploaded matrix with its GGUF bytes (layer -1: embeddings / output head)
+    std::vector<matrix_ref> matrices;
+    bool output_has_mq = false;
     size_t hbm_bytes = 0;                     // bytes resident in HBM for this process's stage(s)
     size_t hbm_copy_bytes = 0;                // ... plus the tile-major copies the matrix-core kernel reads (pi_weight::mq)
 
@@ -116,6 +120,21 @@ struct pi_run {                                // one llama_start_async_decode .
     int kv_head = 0;                        // first cell find_slot allotted (released again when the run failed)
 };
 
+// The context's error text is written by the caller's thread AND by the feeder thread of a segmented context (a failed launch inside a pass): every access locks.
+// Behaves like the std::string it replaces where the engine assigns, tests for emptiness and concatenates.
+class pi_error_text {
+    mutable std::mutex mu; std::string s;
+public:
+    pi_error_text & operator=(const std::string & v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
+    pi_error_text & operator=(const char * v) { std::lock_guard<std::mutex> lk(mu); s = v; return *this; }
+    pi_error_text & operator=(const pi_error_text & o) { if (this != &o) { const std::string v = o.str(); std::lock_guard<std::mutex> lk(mu); s = v; } return *this; }
+    bool empty() const { std::lock_guard<std::mutex> lk(mu); return s.empty(); }
+    std::string str() const { std::lock_guard<std::mutex> lk(mu); return s; }
+    operator std::string() const { return str(); }
+};
+inline std::string operator+(const std::string & a, const pi_error_text & b) { return a + b.str(); }
+inline std::string operator+(const char * a, const pi_error_text & b) { return std::string(a) + b.str(); }
+
 struct llama_context {
     llama_model * model = nullptr;
     llama_context_params cparams;
@@ -151,7 +170,7 @@ struct llama_context {
     int seg_layers = 0;                      // 0: the whole stage is one graph, launched by the caller (no feeder)
     std::thread feeder; std::mutex fmu; std::condition_variable fcv; std::deque<pi_run *> fqueue; bool fstop = false;
     int urgent_pending = 0;                 // runs of this (priority) context counted in the device arbiter and not finished yet (caller's thread only)
-    uint64_t stat_segments = 0, stat_segments_skipped = 0;
+    std::atomic<uint64_t> stat_segments{0}, stat_segments_skipped{0};     // written by the feeder thread (or the stage loop), read by the caller: atomics
     hipEvent_t seg_events[2] = { nullptr, nullptr };
     // Kernel-granular early cancellation (reference: abort callback between graph nodes, ggml.c:15748-15811; llama.cpp:5614-5628, 5665-5687, 9981-9993):
     // every kernel of this context reads abort_dev = (id of the run whose kernels are executing << 1 | aborted) on entry.  A run's launches are preceded, in
@@ -168,7 +187,7 @@ struct llama_context {
     std::atomic<int32_t> last_finished_id{0}; std::atomic<uint64_t> epoch_after_finish{0};
     hipEvent_t pass_event = nullptr; bool pass_pending = false; int32_t pass_first_id = 0;      // feeder thread only
     uint8_t * pass_host[4] = { nullptr, nullptr, nullptr, nullptr }; size_t pass_host_cap = 0; int pass_slot = 0;   // pinned staging blocks of composed passes
-    uint64_t stat_passes = 0, stat_pass_runs = 0, stat_pass_tokens = 0, stat_coalesced_passes = 0;
+    std::atomic<uint64_t> stat_passes{0}, stat_pass_runs{0}, stat_pass_tokens{0}, stat_coalesced_passes{0};     // feeder thread writes, caller reads
     int32_t * abort_dev = nullptr; int32_t * abort_host = nullptr; hipStream_t ctl_stream = nullptr; int32_t run_counter = 0;
     std::atomic<int32_t> stage_run_id{0};    // pipeline stages (stage_run): id of the run being computed, 0 between runs (read by the transport's cancel watcher)
     double stat_hop_ms = 0.0;                // pipeline stages: GPU time of the in-stream store of the activations into the next stage's ring
@@ -191,7 +210,7 @@ struct llama_context {
     uint64_t stat_calls_1 = 0; double stat_gpu_ms_1 = 0.0; uint64_t stat_alg_bytes_1 = 0;      // single-token calls only (the decode rate)
 
     std::mt19937 rng;                          // llama_set_rng_seed / llama_sample_token (llama.cpp:1488)
-    std::string last_error;
+    pi_error_text last_error;                 // (caller and feeder thread: see pi_error_text)
     ~llama_context();
 };
 
@@ -208,6 +227,6 @@ bool context_wait(llama_context * ctx, pi_run * run);                    // bloc
 int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
                int (*should_abort)(void *) = nullptr, void * abort_user = nullptr);        // 0 done, 1 cut short by should_abort, < 0 error
-void stage_abort_current(llama_context * ctx);                             // any thread: the run stage_run is computing right now returns from every kernel on entry from now on
+void stage_abort_run(llama_context * ctx, int32_t run_id);                  // any thread: run `run_id` (ctx->stage_run_id while stage_run computes it) returns from every kernel on entry from now on; no effect on any other run
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

@@ -335,7 +335,11 @@ extern "C" int pipeinfer_context_prepare(struct llama_context * ctx) {
     if (!pi::context_prepare(ctx, err)) { ctx->last_error = err; return -1; }
     return 0;
 }
-extern "C" const char * pipeinfer_context_error(struct llama_context * ctx) { return ctx->last_error.c_str(); }
+extern "C" const char * pipeinfer_context_error(struct llama_context * ctx) {
+    static thread_local std::string text;                                      // a copy taken under the text's lock: the feeder thread may be writing a new one
+    text = ctx->last_error.str();
+    return text.c_str();
+}
 
 extern "C" int pipeinfer_get_topk(struct llama_context * ctx, int32_t i, llama_token * ids, float * logits, float * sumexp) {
     if (i < 0 || i >= ctx->last_n_tokens) return -1;

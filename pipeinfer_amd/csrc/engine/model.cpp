@@ -20,7 +20,7 @@ llama_model::~llama_model() {
     for (void * p : f32_allocs) pi_free(p);
 }
 
-static pi_weight * upload_matrix(llama_model & m, const std::string & name, int64_t ne0, int64_t ne1, std::string & err) {
+static pi_weight * upload_matrix(llama_model & m, const std::string & name, int64_t ne0, int64_t ne1, std::string & err, int layer = -1) {
     const pi::gguf_tensor * t = m.file.tensor(name);
     if (!t) { err = "missing tensor " + name; return nullptr; }
     if (t->ne[0] != ne0 || t->ne[1] != ne1) {
@@ -31,6 +31,7 @@ static pi_weight * upload_matrix(llama_model & m, const std::string & name, int6
     if (!w) { err = std::string("upload of ") + name + " failed: " + pi_last_error(); return nullptr; }
     m.hbm_bytes += pi_weight_nbytes(w);
     m.hbm_copy_bytes += pi_weight_copy_nbytes(w);
+    m.matrices.push_back({ w, t->data, layer });
     return w;
 }
 
@@ -69,18 +70,31 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
     pi_weight_set_mq_copies(want_mq ? 1 : 0);
     for (int il = l0; il < l1; il++) {
         pi_layer & L = layers[il];
-        if (L.loaded) continue;
+        if (L.loaded) {
+            // loaded by a context whose passes never reach the matrix-core kernel, and now a context with wide passes (prompts, verify batches, coalesced runs) prepares:
+            // make the copies now — without them every wide pass of this context would silently stay on the VALU kernel (same bits, 2-4x the time)
+            if (want_mq && !L.has_mq) {
+                for (const matrix_ref & r : matrices)
+                    if (r.layer == il) {
+                        const size_t before = pi_weight_copy_nbytes(r.w);
+                        if (pi_weight_ensure_mq_copy(r.w, r.host, nullptr) != 0) { err = std::string("tile-major copy of layer ") + std::to_string(il) + " failed: " + pi_last_error(); return false; }
+                        hbm_copy_bytes += pi_weight_copy_nbytes(r.w) - before;
+                    }
+                L.has_mq = true;
+            }
+            continue;
+        }
         const std::string p = "blk." + std::to_string(il) + ".";
         if (hp.arch == PI_ARCH_LLAMA) {
             if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
-            if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err))) return false;
-            if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err))) return false;
-            if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err))) return false;
-            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
+            if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err, il))) return false;
+            if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err, il))) return false;
+            if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err, il))) return false;
+            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err, il))) return false;
             if (!(L.ffn_norm = upload_f32(*this, p + "ffn_norm.weight", n_embd, true, err))) return false;
-            if (!(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err))) return false;
-            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
-            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+            if (!(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err, il))) return false;
+            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err, il))) return false;
+            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err, il))) return false;
         } else if (hp.generic()) {
             // tensor sets of llama.cpp:2825-2890 (baichuan; refact shares llama's, :2756-2824), :2969-3047 (starcoder), :3116-3197 (bloom), :3198-3264 (mpt), :3265-3345 (stablelm)
             const bool norm_b = hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM || hp.arch == PI_ARCH_PERSIMMON;
@@ -88,25 +102,25 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
             if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
             if (norm_b && !(L.attn_norm_b = upload_f32(*this, p + "attn_norm.bias", n_embd, true, err))) return false;
             if (hp.block.fused_qkv) {
-                if (!(L.wqkv = upload_matrix(*this, p + "attn_qkv.weight", n_embd, n_embd + 2 * n_gqa, err))) return false;
+                if (!(L.wqkv = upload_matrix(*this, p + "attn_qkv.weight", n_embd, n_embd + 2 * n_gqa, err, il))) return false;
                 if (proj_b && !(L.bqkv = upload_f32(*this, p + "attn_qkv.bias", n_embd + 2 * n_gqa, true, err))) return false;
             } else {
-                if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err))) return false;
-                if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err))) return false;
-                if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err))) return false;
+                if (!(L.wq = upload_matrix(*this, p + "attn_q.weight", n_embd, n_embd, err, il))) return false;
+                if (!(L.wk = upload_matrix(*this, p + "attn_k.weight", n_embd, n_gqa, err, il))) return false;
+                if (!(L.wv = upload_matrix(*this, p + "attn_v.weight", n_embd, n_gqa, err, il))) return false;
             }
             if (hp.block.qk_norm) {                                                       // llama.cpp:3105-3108: four vectors of 64
                 if (!(L.attn_q_norm = upload_f32(*this, p + "attn_q_norm.weight", 64, true, err)) || !(L.attn_q_norm_b = upload_f32(*this, p + "attn_q_norm.bias", 64, true, err))) return false;
                 if (!(L.attn_k_norm = upload_f32(*this, p + "attn_k_norm.weight", 64, true, err)) || !(L.attn_k_norm_b = upload_f32(*this, p + "attn_k_norm.bias", 64, true, err))) return false;
             }
-            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
+            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err, il))) return false;
             if (proj_b && !(L.bo = upload_f32(*this, p + "attn_output.bias", n_embd, true, err))) return false;
             if (!(L.ffn_norm = upload_f32(*this, p + "ffn_norm.weight", n_embd, true, err))) return false;
             if (norm_b && !(L.ffn_norm_b = upload_f32(*this, p + "ffn_norm.bias", n_embd, true, err))) return false;
-            if (hp.block.gated && !(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err))) return false;
-            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
+            if (hp.block.gated && !(L.ffn_gate = upload_matrix(*this, p + "ffn_gate.weight", n_embd, n_ff, err, il))) return false;
+            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err, il))) return false;
             if (proj_b && !(L.ffn_down_b = upload_f32(*this, p + "ffn_down.bias", n_embd, true, err))) return false;
-            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err, il))) return false;
             if (proj_b && !(L.ffn_up_b = upload_f32(*this, p + "ffn_up.bias", n_ff, true, err))) return false;
         } else {
             if (!(L.attn_norm = upload_f32(*this, p + "attn_norm.weight", n_embd, true, err))) return false;
@@ -115,18 +129,28 @@ bool llama_model::ensure_loaded(int l0, int l1, bool first, bool last, bool want
                 if (!(L.attn_norm_2 = upload_f32(*this, p + "attn_norm_2.weight", n_embd, true, err))) return false;
                 if (!(L.attn_norm_2_b = upload_f32(*this, p + "attn_norm_2.bias", n_embd, true, err))) return false;
             }
-            if (!(L.wqkv = upload_matrix(*this, p + "attn_qkv.weight", n_embd, n_embd + 2 * n_gqa, err))) return false;
-            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err))) return false;
-            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err))) return false;
-            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err))) return false;
+            if (!(L.wqkv = upload_matrix(*this, p + "attn_qkv.weight", n_embd, n_embd + 2 * n_gqa, err, il))) return false;
+            if (!(L.wo = upload_matrix(*this, p + "attn_output.weight", n_embd, n_embd, err, il))) return false;
+            if (!(L.ffn_down = upload_matrix(*this, p + "ffn_down.weight", n_ff, n_embd, err, il))) return false;
+            if (!(L.ffn_up = upload_matrix(*this, p + "ffn_up.weight", n_embd, n_ff, err, il))) return false;
         }
         L.loaded = true;
+        L.has_mq = want_mq;
     }
     if (last && !output) {
         if (!(output_norm = upload_f32(*this, "output_norm.weight", n_embd, true, err))) return false;
         const bool out_b = hp.arch == PI_ARCH_FALCON || hp.arch == PI_ARCH_STARCODER || hp.arch == PI_ARCH_BLOOM || hp.arch == PI_ARCH_STABLELM || hp.arch == PI_ARCH_PERSIMMON;
         if (out_b && !(output_norm_b = upload_f32(*this, "output_norm.bias", n_embd, true, err))) return false;
         if (!(output = upload_matrix(*this, "output.weight", n_embd, hp.n_vocab, err))) return false;
+        output_has_mq = want_mq;
+    } else if (last && want_mq && !output_has_mq) {
+        for (const matrix_ref & r : matrices)
+            if (r.w == output) {
+                const size_t before = pi_weight_copy_nbytes(r.w);
+                if (pi_weight_ensure_mq_copy(r.w, r.host, nullptr) != 0) { err = std::string("tile-major copy of the output head failed: ") + pi_last_error(); return false; }
+                hbm_copy_bytes += pi_weight_copy_nbytes(r.w) - before;
+            }
+        output_has_mq = true;
     }
     return true;
 }

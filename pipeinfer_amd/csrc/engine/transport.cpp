@@ -388,8 +388,11 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
         while (!watch_stop.load(std::memory_order_relaxed)) {
             const uint64_t n = L->n_cancel.load(std::memory_order_acquire);
             for (; cursor < n; cursor++) seen.insert(L->cancel[cursor % TP_CANCEL_CAP].load(std::memory_order_relaxed));
+            // (key, run id) must belong together: the serve loop publishes the key before stage_run takes a fresh id and withdraws it after stage_run has zeroed
+            // the id again, and ids never repeat — the same non-zero id on both sides of the key load means the key was that run's throughout
+            const int32_t rid = ctx->stage_run_id.load(std::memory_order_acquire);
             const uint64_t key = watch_key.load(std::memory_order_acquire);
-            if (key != ~0ull && seen.count(key)) pi::stage_abort_current(ctx);
+            if (rid != 0 && key != ~0ull && ctx->stage_run_id.load(std::memory_order_acquire) == rid && seen.count(key)) pi::stage_abort_run(ctx, rid);
             std::this_thread::sleep_for(std::chrono::microseconds(key != ~0ull ? 30 : 200));
         }
     });

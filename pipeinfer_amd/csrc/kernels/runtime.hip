@@ -298,6 +298,29 @@ __global__ void k_repack_legacy(const uint8_t * __restrict__ src, int type, uint
         qs[((row * ng + g) * 4 + c) * 4 + bi] = (uint32_t) q[4 * c] | (uint32_t) q[4 * c + 1] << 8 | (uint32_t) q[4 * c + 2] << 16 | (uint32_t) q[4 * c + 3] << 24;
 }
 
+// the tile-major copy the matrix-core kernel reads (mmq_mfma.hip), from the tensor's GGUF bytes in `staging` (device); enqueued on `stream`.  Without HBM for it the weight
+// simply has none: mul_mat then takes the (bit-identical) VALU kernel at every width — a model that fits without the copies must still load
+static void make_mq_copy(pi_weight * w, const uint8_t * staging, hipStream_t stream) {
+    static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
+    const int type = w->type;
+    if (!mq_on || w->mq || !(type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) return;
+    const int threads = 256;
+    const int64_t n_rg = (w->ne1 + 15) / 16;
+    const size_t tile_sz = type == PI_Q6_K ? PI_MQ_TILE_Q6 : type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
+    const size_t mq_bytes = (size_t) n_rg * w->nb * tile_sz + 512;
+    if (hipMalloc(&w->mq_base, mq_bytes) != hipSuccess) {
+        (void) hipGetLastError();
+        w->mq_base = nullptr;
+        static bool said = false;
+        if (!said) { said = true; fprintf(stderr, "pi_weight_upload: no HBM left for the tile-major copies of the matrix-core kernel (%zu bytes asked): batches fall back to the VALU kernel\n", mq_bytes); }
+        return;
+    }
+    w->mq = (const uint8_t *) w->mq_base; w->mq_nbytes = mq_bytes;
+    const dim3 mgrid((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads));
+    if (type == PI_Q6_K) hipLaunchKernelGGL(k_repack_mq_q6_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, w->ne1, w->nb);
+    else hipLaunchKernelGGL(k_repack_mq_q45_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, w->ne1, w->nb, type == PI_Q5_K ? 1 : 0);
+}
+
 extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host, void * stream_) {
     hipStream_t stream = (hipStream_t) stream_;
     const int blck = pi_type_blck(type), tsz = pi_type_size(type);
@@ -346,28 +369,25 @@ extern "C" pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, cons
         else                 hipLaunchKernelGGL(k_repack_q8_0, dim3(grid), dim3(threads), 0, stream, staging, (uint32_t *) base, (uint16_t *) w->p1, ne1, w->nb, w->ng);
     }
     w->mq = nullptr; w->mq_base = nullptr; w->mq_nbytes = 0;
-    static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
-    if (mq_on && g_mq_copies && (type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) {
-        const int64_t n_rg = (ne1 + 15) / 16;
-        const size_t tile_sz = type == PI_Q6_K ? PI_MQ_TILE_Q6 : type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
-        const size_t mq_bytes = (size_t) n_rg * w->nb * tile_sz + 512;
-        if (hipMalloc(&w->mq_base, mq_bytes) != hipSuccess) {
-            // the copy only serves the matrix-core kernel; without it mul_mat takes the (bit-identical) VALU kernel for every width: a model that fits without the copies must still load
-            (void) hipGetLastError();
-            w->mq_base = nullptr;
-            static bool said = false;
-            if (!said) { said = true; fprintf(stderr, "pi_weight_upload: no HBM left for the tile-major copies of the matrix-core kernel (%zu bytes asked): batches fall back to the VALU kernel\n", mq_bytes); }
-        } else {
-            w->mq = (const uint8_t *) w->mq_base; w->mq_nbytes = mq_bytes;
-            const dim3 mgrid((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads));
-            if (type == PI_Q6_K) hipLaunchKernelGGL(k_repack_mq_q6_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb);
-            else hipLaunchKernelGGL(k_repack_mq_q45_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, ne1, w->nb, type == PI_Q5_K ? 1 : 0);
-        }
-    }
+    if (g_mq_copies) make_mq_copy(w, staging, stream);
     const hipError_t e = hipStreamSynchronize(stream);
     (void) hipFree(staging);
     if (e != hipSuccess) { if (w->mq_base) (void) hipFree(w->mq_base); return fail(hipGetErrorString(e)); }
     return w;
+}
+
+// a weight uploaded without its tile-major copy (pi_weight_set_mq_copies(0): no pass of its first context was wide enough) gets it now, from the same GGUF bytes
+extern "C" int pi_weight_ensure_mq_copy(pi_weight * w, const void * host, void * stream_) {
+    hipStream_t stream = (hipStream_t) stream_;
+    if (!w || !host) { pi_set_error("pi_weight_ensure_mq_copy: null argument"); return -1; }
+    if (w->mq || !(w->type == PI_Q4_K || w->type == PI_Q5_K || w->type == PI_Q6_K)) return 0;
+    uint8_t * staging = nullptr;
+    if (hipMalloc((void **) &staging, w->nbytes) != hipSuccess) { (void) hipGetLastError(); pi_set_error("pi_weight_ensure_mq_copy: staging hipMalloc(%zu) failed", w->nbytes); return -1; }
+    hipError_t e = hipMemcpyAsync(staging, host, w->nbytes, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) { make_mq_copy(w, staging, stream); e = hipStreamSynchronize(stream); }
+    (void) hipFree(staging);
+    if (e != hipSuccess) { if (w->mq_base) { (void) hipFree(w->mq_base); w->mq_base = nullptr; w->mq = nullptr; w->mq_nbytes = 0; } pi_set_error("pi_weight_ensure_mq_copy: %s", hipGetErrorString(e)); return -1; }
+    return 0;
 }
 
 extern "C" void pi_weight_free(pi_weight * w) { if (w) { (void) hipFree(w->base); if (w->mq_base) (void) hipFree(w->mq_base); delete w; } }
