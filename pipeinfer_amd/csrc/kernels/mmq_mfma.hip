@@ -333,7 +333,12 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 #pragma unroll
         for (int j = 0; j < 2 * NB; j++) {
             const int T = T0 + j;
-            if (T < ntile) {
+            // One chunk: LEAVE at the first tile past the end instead of skipping it — a tile is then only ever entered from the tile before it, and the wait-count pass sees
+            // every refill that tile issued.  With `if (T < ntile) { ... }` it assumed the path that skipped the tile and waited for all but ~3 blocks of the 8-block ring
+            // (vmcnt(12..14) in front of a block's first use instead of vmcnt(28..31)): half the ring was never in flight.  Two chunks keep the skip form: without the join the
+            // scheduler pipelines across their one-block tiles and runs out of registers (256 + spills).
+            if constexpr (NC == 1) { if (T >= ntile) goto tiles_done; }
+            if (NC == 1 || T < ntile) {
                 dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
                 const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
 #pragma unroll
@@ -351,6 +356,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
             }
         }
     }
+tiles_done:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (no DMA may still be writing LDS when the fold reuses it)
     __syncthreads();
 

@@ -15,7 +15,7 @@ for t, rows, k in shapes:
     rng = np.random.default_rng(1)
     blocks = synth.random_blocks(t, rows * k, rng, 0.05)
     # rotate over enough copies to exceed the 256 MB infinity cache: decode streams the whole model, it never re-reads
-    ncopy = max(1, int(400e6 // blocks.nbytes) + 1)
+    ncopy = int(os.environ["NCOPY"]) if os.environ.get("NCOPY") else max(1, int(400e6 // blocks.nbytes) + 1)
     ws = [lib.pi_weight_upload(t, k, rows, blocks.ctypes.data_as(C.c_void_p), None) for _ in range(ncopy)]
     w = ws[0]
     for nt in nts:
