@@ -79,17 +79,17 @@ def kernel_source_sha():
 def committed_traffic(workload, kernel_key):
     """HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): bench.py cannot
     run the profiler on itself.  The file is only quoted if it was measured on THIS kernel source (sha) and workload."""
-    name = f"r03_pmc_fetch_size_{workload}.json"
+    name = f"r04_pmc_fetch_size_{workload}.json"
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None, f"no committed PMC pass for workload {workload} (profiles/{name})"
     if pmc.get("kernel_src_sha16") != kernel_source_sha():
         return None, f"profiles/{name} was measured on kernel sources {pmc.get('kernel_src_sha16')}, these are {kernel_source_sha()}: not quoted"
-    k = pmc.get("kernels", {}).get(kernel_key)
+    k = pmc.get("families", {}).get(kernel_key)
     if not k:
         return None, f"profiles/{name} has no entry for {kernel_key}"
-    return k["avg_fetch_bytes_per_launch"], f"profiles/{name}"
+    return k, f"profiles/{name}"
 
 
 def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):
@@ -187,17 +187,82 @@ def summarize(results):
             "draft_paused_tokens": sum(r["n_draft_paused"] for r in results), "draft_catchups": sum(r["n_draft_catchups"] for r in results)}
 
 
-def kernel_timing_table(lib):
-    """per (weight type, batch width) statistics of the sampled mat-vec / mat-mat launches: (type, nt, avg us, avg bytes, sampled, launches)"""
-    rows = []
-    for t in TYPE_NAMES:
-        for nt in range(1, 9):
-            us, by, ns, nl = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
-            lib.pi_kernel_timing_report(t, nt, C.byref(us), C.byref(by), C.byref(ns), C.byref(nl))
-            if ns.value:
-                rows.append({"type": TYPE_NAMES[t], "n_tok": nt if nt < 8 else "8+", "avg_us": round(us.value, 3), "alg_bytes": round(by.value), "sampled": int(ns.value),
-                             "launches": int(nl.value), "GBps": round(by.value / (us.value * 1e-6) / 1e9, 1), "gpu_ms_total": round(us.value * nl.value * 1e-3, 3)})
-    return rows
+FAMILIES = {0: "matvec", 1: "matrix_cores", 2: "norm_quant", 3: "quantize", 4: "act_quant", 5: "attention", 6: "other"}
+FAMILY_KERNELS = {"matvec_nt1": "k_mmvq_kq / k_mmvq_kq2 / k_mmvq_q0r (VALU mat-vec, one token)", "matvec_multi": "k_mmvq_* (VALU mat-vec, 2..8 tokens)",
+                  "matrix_cores": "k_mmq_kq (matrix-core mat-mat, 3..32 tokens per pass)", "norm_quant": "k_norm_quant", "quantize": "k_quantize_q8_K / _q8_0",
+                  "act_quant": "k_act_quant", "attention": "k_attention", "other": "k_get_rows, k_rope_kv, k_topk1/2, k_norm, k_add, ..."}
+
+
+class KtRow(C.Structure):          # struct pi_kt_row (include/pipeinfer_ops.h)
+    _fields_ = [("family", C.c_int32), ("type", C.c_int32), ("n_tok", C.c_int32), ("pad_", C.c_int32), ("shape_bytes", C.c_uint64), ("launches", C.c_uint64),
+                ("bytes_total", C.c_double), ("sampled", C.c_uint64), ("avg_us", C.c_double), ("avg_sampled_bytes", C.c_double)]
+
+
+def _rows(buf, n):
+    return [{"family": r.family, "type": r.type, "n_tok": r.n_tok, "shape_bytes": int(r.shape_bytes), "launches": int(r.launches), "bytes_total": float(r.bytes_total),
+             "sampled": int(r.sampled), "avg_us": float(r.avg_us), "avg_sampled_bytes": float(r.avg_sampled_bytes)} for r in buf[:n]]
+
+
+def timing_rows(lib):
+    """eager launches of the open timing window: counts, algorithmic bytes and the sampled durations (call after a device sync)"""
+    buf = (KtRow * 4096)()
+    return _rows(buf, lib.pi_kernel_timing_rows(buf, 4096))
+
+
+def launch_rows(lib, ctx):
+    """launches of a context's captured graphs since its reset_stats(): graph contents x replays (counts and algorithmic bytes; no durations)"""
+    lib.pipeinfer_get_launch_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.pipeinfer_get_launch_rows.restype = C.c_int
+    buf = (KtRow * 4096)()
+    return _rows(buf, lib.pipeinfer_get_launch_rows(ctx.h, buf, 4096))
+
+
+def family_of(r):
+    f = FAMILIES.get(r["family"], "other")
+    return ("matvec_nt1" if r["n_tok"] == 1 else "matvec_multi") if f == "matvec" else f
+
+
+def roofline_tables(counts, samples):
+    """counts: the launches of the TIMED region (graph contents x replays + eager launches); samples: per-instance durations of the graphs-off replay of the same schedule.
+    An instance = (family, weight type, tokens of the launch, launch shape).  Estimated GPU time of an instance in the timed region = its launches there x the replay's
+    average duration of the same instance (the nearest width of the same launch shape when that exact width did not occur in the replay)."""
+    by_key = {}
+    for r in samples:
+        if r["sampled"]:
+            by_key[(r["family"], r["type"], r["n_tok"], r["shape_bytes"])] = r
+    inst, fam = [], {}
+    for c in counts:
+        if not c["launches"]:
+            continue
+        k = (c["family"], c["type"], c["n_tok"], c["shape_bytes"])
+        smp = by_key.get(k)
+        how = "same instance"
+        if smp is None:                                  # nearest sampled width of the same kernel family / type / launch shape
+            near = [v for kk, v in by_key.items() if kk[0] == k[0] and kk[1] == k[1] and kk[3] == k[3]]
+            if not near and k[0] >= 2:                  # families without a launch shape: nearest width of the family
+                near = [v for kk, v in by_key.items() if kk[0] == k[0]]
+            if near:
+                smp = min(near, key=lambda v: abs(v["n_tok"] - c["n_tok"])); how = f"nearest sampled width ({smp['n_tok']} tokens)"
+        avg_us = smp["avg_us"] if smp else None
+        # attention: a captured graph is launched with n_kv = n_ctx and reads the real n_kv on the device: price it with the bytes of the sampled (eager) launches
+        bytes_per = (smp["avg_sampled_bytes"] if (smp and c["family"] == 5) else c["bytes_total"] / c["launches"])
+        row = {"family": family_of(c), "type": TYPE_NAMES.get(c["type"], "-") if c["family"] <= 1 else "-", "n_tok": c["n_tok"], "launch_MB": round(c["shape_bytes"] / 1e6, 2) if c["shape_bytes"] else None,
+               "launches": c["launches"], "alg_bytes_per_launch": round(bytes_per), "avg_us": round(avg_us, 3) if avg_us else None, "duration_from": how if smp else "not sampled",
+               "GBps": round(bytes_per / (avg_us * 1e-6) / 1e9, 1) if avg_us else None, "est_gpu_ms": round(c["launches"] * avg_us * 1e-3, 3) if avg_us else None}
+        inst.append(row)
+        f = fam.setdefault(row["family"], {"launches": 0, "launches_priced": 0, "alg_bytes": 0.0, "est_gpu_ms": 0.0})
+        f["launches"] += c["launches"]
+        if avg_us:
+            f["launches_priced"] += c["launches"]; f["alg_bytes"] += bytes_per * c["launches"]; f["est_gpu_ms"] += c["launches"] * avg_us * 1e-3
+    total_ms = sum(f["est_gpu_ms"] for f in fam.values()) or 1.0
+    out = {}
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["est_gpu_ms"]):
+        gbps = f["alg_bytes"] / max(1e-12, f["est_gpu_ms"] * 1e-3) / 1e9
+        out[name] = {"kernels": FAMILY_KERNELS.get(name, name), "launches": f["launches"], "launches_priced": f["launches_priced"], "est_gpu_ms": round(f["est_gpu_ms"], 2),
+                     "share_of_gpu_time": round(f["est_gpu_ms"] / total_ms, 4), "alg_bytes_per_launch": round(f["alg_bytes"] / max(1, f["launches_priced"])),
+                     "avg_launch_us": round(1e3 * f["est_gpu_ms"] / max(1, f["launches_priced"]), 3), "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4)}
+    inst.sort(key=lambda r: -(r["est_gpu_ms"] or 0.0))
+    return out, inst
 
 
 def launch_ranks(n):
@@ -317,6 +382,9 @@ def main():
 
     ct.reset_stats(); cd.reset_stats()
     L.check(lib.pi_device_sync())
+    # launch accounting of the timed region: graphs count themselves (contents x replays, read back below); eager launches (PI_NO_GRAPHS=1 runs under the profiler) are
+    # counted by an open window that times next to nothing (every 2^30th launch of an instance)
+    lib.pi_kernel_timing(1, 1 << 30)
     t_start = time.time()
     results = []
     for i in range(args.steps):
@@ -324,6 +392,9 @@ def main():
         results.append(r)
     L.check(lib.pi_device_sync())
     t_total = time.time() - t_start
+    timed_counts = launch_rows(lib, ct) + [r for r in timing_rows(lib)]            # target graphs + whatever ran eagerly (both contexts when graphs are off)
+    draft_counts = launch_rows(lib, cd)
+    lib.pi_kernel_timing(0, 8)
     st_t, st_d = ct.stats(), cd.stats()                 # per-call GPU time and bytes of the timed steps only
     main_sum = summarize(results)
 
@@ -349,21 +420,32 @@ def main():
     # every 5th launch of each (type, width) instance goes through hipExtLaunchKernelGGL whose events carry the kernel's own timestamps.
     ct.set_graphs(0)
     lib.pi_kernel_timing(1, 5)          # 5 is coprime to the 3- and 4-launch periods of a layer: every launch shape gets sampled
-    generation(1 + args.warmup, n_predict=min(32, args.n_predict))
+    generation(1 + args.warmup, n_predict=min(48, args.n_predict))
     L.check(lib.pi_device_sync())
     ct.set_graphs(1)
-    table = kernel_timing_table(lib)
+    samples = timing_rows(lib)
     lib.pi_kernel_timing(0, 8)
-    q4 = [r for r in table if r["type"] == "Q4_K"]
-    dom = max(q4 or table, key=lambda r: r["gpu_ms_total"]) if table else None
-    if dom:
-        kname = f"k_mmvq_kq<Q4_K,NT=1>" if dom["n_tok"] == 1 else f"k_mmq_kq<{dom['type']}> (matrix cores, {dom['n_tok']} tokens)"
-        traffic, traffic_src = committed_traffic(args.workload, f"{dom['type']}_nt{dom['n_tok']}")
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel_src_sha16": kernel_source_sha(),
-                    "avg_launch_us": dom["avg_us"], "alg_bytes_per_launch": dom["alg_bytes"], "launches": dom["launches"], "sampled": dom["sampled"]}
+    # the kernel FAMILY the timed region spent most GPU time in: its launches there (counts) x the replay's per-instance durations
+    by_family, table = roofline_tables(timed_counts, samples)
+    dom_name = next(iter(by_family), None)
+    if dom_name:
+        dom = by_family[dom_name]
+        tr, traffic_src = committed_traffic(args.workload, dom_name)
+        # traffic per launch: the committed PMC pass measured FETCH_SIZE per launch of this family AND (same run, same accounting as here) its algorithmic bytes per
+        # launch; their ratio (bytes fetched per algorithmic byte) applied to this run's algorithmic bytes per launch
+        traffic = round(tr["fetch_over_alg"] * dom["alg_bytes_per_launch"]) if tr else None
+        roofline = {"bound": "hbm", "kernel": dom["kernels"], "family": dom_name, "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                    "traffic": traffic, "traffic_fetch_over_alg": tr["fetch_over_alg"] if tr else None, "traffic_source": traffic_src, "kernel_src_sha16": kernel_source_sha(),
+                    "avg_launch_us": dom["avg_launch_us"], "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "launches": dom["launches"],
+                    "share_of_gpu_time": dom["share_of_gpu_time"],
+                    "how": "launch counts and algorithmic bytes: the timed region's own (captured graphs x replays); durations: HIP-event samples of a graphs-off replay of the same schedule, per instance"}
     else:
         roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
+    roofline["by_family"] = by_family
+    for name, f in by_family.items():                                                # PMC traffic of every family the committed pass has
+        tr, _ = committed_traffic(args.workload, name)
+        f["traffic_fetch_over_alg"] = tr["fetch_over_alg"] if tr else None
+    roofline["draft_launches"] = sum(r["launches"] for r in draft_counts)
     roofline["per_instance"] = table
     # whole decode calls of the timed steps (prompt batches excluded): GPU time between the call's first and last event
     roofline["target_decode_call"] = {"calls": st_t["n_calls_1"], "gpu_ms_per_call": round(st_t["gpu_ms_1"] / max(1, st_t["n_calls_1"]), 4),

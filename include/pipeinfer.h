@@ -43,6 +43,15 @@ LLAMA_API const char * pipeinfer_context_error(struct llama_context * ctx);
 LLAMA_API int32_t pipeinfer_model_n_layer(const struct llama_model * model);
 /* first KV cell find_slot allotted to a run in flight (ticket of llama_start_async_decode); tests */
 LLAMA_API int32_t pipeinfer_run_first_cell(const struct ggml_cgraph * ticket);
+/* launches of this context's captured graphs since pipeinfer_reset_stats — graph contents x replays, one row per instance (struct pi_kt_row, pipeinfer_ops.h; durations
+ * are not part of it: `sampled`, `avg_us` are 0) — i.e. the launch counts and algorithmic bytes of exactly what ran in between.  Returns the number of rows. */
+struct pi_kt_row;
+LLAMA_API int pipeinfer_get_launch_rows(struct llama_context * ctx, struct pi_kt_row * out, int cap);
+/* Run tap (tests: per-run oracle comparison of whatever schedule the context runs — segments, feeder, coalesced passes).  Called on the CALLER's thread, twice per run:
+ * from llama_start_async_decode with logits == NULL, and from llama_finish_async_decode with the run's rows [n_tokens][n_vocab] (NULL again when the run produced none:
+ * cancelled before or after its start, or a failed launch).  meta = the run's own metadata block (tokens | pos | {kv_head, n_kv, n_tokens, 0} | mask rows), valid during the call. */
+typedef void (*pipeinfer_run_tap_fn)(void * user, int32_t run_id, int32_t batch_id, int32_t n_tokens, const void * meta, size_t meta_bytes, const float * logits);
+LLAMA_API void pipeinfer_context_set_run_tap(struct llama_context * ctx, pipeinfer_run_tap_fn fn, void * user);
 
 /* device-side top-8 of row i of the last finished run: ids/logits sorted (logit desc, id asc), sumexp = sum_j expf(l_j - max) */
 /* ---- multi-process pipeline (one process per GPU) -------------------------------------------------------------------------

@@ -54,9 +54,15 @@ PI_API void    pi_set_abort_word(const int32_t * word_dev);
 PI_API int     pi_op_abort_begin(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, void * stream);
 PI_API int     pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * stream);
 
-/* sampled per-launch timing of the quantised mat-vec kernels (HIP events on the launch stream around every Nth launch) */
+/* Launch accounting for the roofline report.  An instance = (family, weight type, tokens of the launch); families: 0 VALU mat-vec (k_mmvq_*), 1 matrix-core mat-mat
+ * (k_mmq_kq), 2 norm + quantise, 3 quantise, 4 activation + quantise, 5 attention, 6 everything else (get_rows, RoPE + KV store, norms, adds, top-k).
+ * pi_kernel_timing(1, N) opens a window: every eager launch is counted with its algorithmic bytes and every Nth launch of an instance is timed (HIP events of
+ * hipExtLaunchKernelGGL = the kernel's own begin / end timestamps); pi_kernel_timing_rows reads the window after a device sync.  Launches captured into a HIP graph are
+ * counted per graph instead (pipeinfer_get_launch_rows in pipeinfer.h: graph contents x replays). */
+struct pi_kt_row { int32_t family, type, n_tok, pad_; uint64_t shape_bytes; /* mat launches: algorithmic bytes of this launch shape (0 for the other families) */
+                   uint64_t launches; double bytes_total; uint64_t sampled; double avg_us, avg_sampled_bytes; };
 PI_API void    pi_kernel_timing(int on, int sample_every);
-PI_API int     pi_kernel_timing_report(int weight_type, int n_tok, double * avg_us, double * avg_bytes, uint64_t * n_sampled, uint64_t * n_launches);
+PI_API int     pi_kernel_timing_rows(struct pi_kt_row * out, int cap);
 
 /* host_blocks: ne1 rows of ne0 elements in the GGUF/ggml block format of `type` (row-major, rows contiguous) */
 PI_API pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host_blocks, void * stream);

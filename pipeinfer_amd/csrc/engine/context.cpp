@@ -404,14 +404,13 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
             // captures — and every launch then fails with "previous error during capture".  Nothing has run at that point: end the capture and record it again.
             static std::mutex capture_mu;
             std::lock_guard<std::mutex> lk(capture_mu);
-            ge.sink.every = 16;
             for (int attempt = 0; attempt < 8 && !ge.exec; attempt++) {
                 hipGraph_t graph = nullptr;
                 if (attempt) { (void) hipGetLastError(); std::this_thread::sleep_for(std::chrono::microseconds(300 * attempt)); }
                 ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
                     pi_kt_set_sink(&ge.sink);                      // launch counts are part of the graph; they are only read while timing is on
-                    if (attempt) { ge.sink.samples.clear(); ge.sink.launches.clear(); }
+                    if (attempt) ge.sink.launches.clear();
                     pi_set_abort_word(abort_checks_on() ? ctx->abort_dev : nullptr);      // the captured kernels carry the context's abort word
                     const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail, multi);
                     pi_set_abort_word(nullptr);
@@ -424,7 +423,7 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
             }
             if (!ok) ctx->last_error = "HIP graph capture of the forward pass failed: " + ctx->last_error;
         }
-        if (ok && !capture_only) ok = hipGraphLaunch(ge.exec, s) == hipSuccess;
+        if (ok && !capture_only) { ok = hipGraphLaunch(ge.exec, s) == hipSuccess; if (ok) ge.replays.fetch_add(1, std::memory_order_relaxed); }
         if (ok && sink_out && seg == 0) *sink_out = &ge.sink;
         return ok;
     }
@@ -688,6 +687,8 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     ctx->cells->build_mask(n_kv, n_tokens, pos, n_seq_id, seq_id, h_mask, words);
     ctx->cells->post_decode(n_tokens);
 
+    run->meta_bytes = meta_bytes;
+    if (ctx->run_tap) ctx->run_tap(ctx->run_tap_user, run->run_id, run->batch_id, n_tokens, run->meta_host, meta_bytes, nullptr);
     run->canceled = ctx->canceled_batches.count(run->batch_id) > 0;
     if (ctx->abort_host) ctx->abort_host[run->run_id & 255] = run->canceled ? 1 : 0;
     bool ok = true;
@@ -914,6 +915,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
     }
     const size_t nv = ctx->model->hparams.n_vocab;
     const int n = run->n_tokens;
+    if (ctx->run_tap) ctx->run_tap(ctx->run_tap_user, run->run_id, run->batch_id, n, run->meta_host, run->meta_bytes, run->launched && ctx->is_last && !run->canceled ? run->logits_host : nullptr);
     if (ctx->is_last) {
         ctx->logits.resize(run->last_only ? nv : (size_t) n * nv);             // llama.cpp:5734-5743
         if (run->launched) {
@@ -942,7 +944,6 @@ int context_finish(llama_context * ctx, pi_run * run) {
         v.erase(std::remove(v.begin(), v.end(), run), v.end());
         run->pass.reset();
     }
-    if (run->launched && run->sink && pi_kt_enabled()) pi_kt_accumulate(run->sink, 1);
     const int64_t dt = time_us() - run->t_start_us;
     if (n == 1) { ctx->t_eval_us += dt; ctx->n_eval++; } else { ctx->t_p_eval_us += dt; ctx->n_p_eval += n; }     // llama.cpp:5807-5815
     for (auto it = ctx->inflight.begin(); it != ctx->inflight.end(); ++it) if (*it == run) { ctx->inflight.erase(it); break; }

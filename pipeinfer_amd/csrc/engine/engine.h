@@ -118,6 +118,7 @@ struct pi_run {                                // one llama_start_async_decode .
     int32_t run_id = 0;                     // per-context counter: the identity the device-side abort word carries (pi_op_abort_begin / _cancel)
     bool failed = false;                    // a launch of this run failed (distinct from cancelled / cut short): finish reports -1 and gives the cells back
     int kv_head = 0;                        // first cell find_slot allotted (released again when the run failed)
+    size_t meta_bytes = 0;                  // size of the run's own metadata block in meta_host
 };
 
 // The context's error text is written by the caller's thread AND by the feeder thread of a segmented context (a failed launch inside a pass): every access locks.
@@ -158,7 +159,7 @@ struct llama_context {
     uint16_t * q16 = nullptr;
     void * q8a = nullptr, * q8b = nullptr, * q8c = nullptr;
     int32_t * tokens_dev = nullptr, * pos_dev = nullptr, * dyn_dev = nullptr; uint32_t * mask_dev = nullptr;
-    struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; };
+    struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; std::atomic<uint64_t> replays{0}; };     // sink: what the graph launches (kernel_timing.h); replays since the last reset_stats
     std::map<std::pair<int, int>, graph_entry> graphs;   // one captured graph per (n_tokens, segment) (kv_head / n_kv come from dyn_dev)
     bool use_graphs = true;
     // Segmented launch (pipeinfer_context_set_segments): the stage's layers are captured as segments of `seg_layers` layers and a feeder
@@ -209,6 +210,7 @@ struct llama_context {
     uint64_t stat_calls = 0; double stat_gpu_ms = 0.0; uint64_t stat_alg_bytes = 0;
     uint64_t stat_calls_1 = 0; double stat_gpu_ms_1 = 0.0; uint64_t stat_alg_bytes_1 = 0;      // single-token calls only (the decode rate)
 
+    pipeinfer_run_tap_fn run_tap = nullptr; void * run_tap_user = nullptr;      // tests: every run's metadata at its start and its rows at its finish (caller's thread)
     std::mt19937 rng;                          // llama_set_rng_seed / llama_sample_token (llama.cpp:1488)
     pi_error_text last_error;                 // (caller and feeder thread: see pi_error_text)
     ~llama_context();

@@ -1,6 +1,9 @@
 // The extern "C" surface declared in include/llama.h and include/pipeinfer.h.
 #include "engine.h"
 
+#include <map>
+#include <tuple>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -282,6 +285,27 @@ extern "C" int pipeinfer_context_set_coalescing(struct llama_context * ctx, int 
     if (max_tokens > 1 && !pi::context_precapture(ctx, std::min(max_tokens, ctx->n_batch))) { ctx->coalesce_max.store(0); return -1; }
     return 0;
 }
+// launches of this context's captured graphs since pipeinfer_reset_stats: graph contents x replays, one row per instance (family, type, tokens, launch shape)
+extern "C" int pipeinfer_get_launch_rows(struct llama_context * ctx, struct pi_kt_row * out, int cap) {
+    std::map<std::tuple<int, int, int, uint64_t>, std::pair<uint64_t, double>> tab;
+    for (auto & kv : ctx->graphs) {
+        const uint64_t rep = kv.second.replays.load(std::memory_order_relaxed);
+        if (!rep) continue;
+        for (const pi_kt_count & c : kv.second.sink.launches) {
+            auto & e = tab[std::make_tuple(c.fam, c.type, c.nt, c.fam <= PI_KT_MMQ ? (uint64_t) c.bytes : 0)];
+            e.first += c.count * rep; e.second += c.bytes_sum * (double) rep;
+        }
+    }
+    int n = 0;
+    for (auto & kv : tab) {
+        if (n >= cap) break;
+        pi_kt_row & r = out[n++];
+        r.family = std::get<0>(kv.first); r.type = std::get<1>(kv.first); r.n_tok = std::get<2>(kv.first); r.pad_ = 0; r.shape_bytes = std::get<3>(kv.first);
+        r.launches = kv.second.first; r.bytes_total = kv.second.second; r.sampled = 0; r.avg_us = 0.0; r.avg_sampled_bytes = 0.0;
+    }
+    return n;
+}
+extern "C" void pipeinfer_context_set_run_tap(struct llama_context * ctx, pipeinfer_run_tap_fn fn, void * user) { ctx->run_tap = fn; ctx->run_tap_user = user; }
 extern "C" int32_t pipeinfer_model_n_layer(const struct llama_model * model) { return model ? model->hparams.n_layer : 0; }
 extern "C" int32_t pipeinfer_run_first_cell(const struct ggml_cgraph * ticket) { return ticket ? ((const pi_run *) ticket)->kv_head : -1; }
 extern "C" void pipeinfer_context_set_graphs(struct llama_context * ctx, int enable) { ctx->use_graphs = enable != 0 && getenv("PI_NO_GRAPHS") == nullptr; }
@@ -359,7 +383,7 @@ extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer
     out->n_passes = ctx->stat_passes; out->n_pass_runs = ctx->stat_pass_runs; out->n_pass_tokens = ctx->stat_pass_tokens; out->n_coalesced_passes = ctx->stat_coalesced_passes;
     out->weight_copy_bytes = ctx->model->hbm_copy_bytes;
 }
-extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0; }
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0; for (auto & kv : ctx->graphs) kv.second.replays.store(0); }
 
 // ---- stand-alone KV-cell table (host logic tests) ---------------------------------------------------------------------------------
 struct pi_kvcells { pi::kv_cells cells; explicit pi_kvcells(int n) : cells(n) {} };

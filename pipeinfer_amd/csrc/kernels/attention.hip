@@ -21,6 +21,7 @@
 //   phase 3  lane (l, ev) owns cells c % 8 == l and dims 8ev..8ev+7: four accumulator sets j = (c / 8) % 4 per row, folded
 //            in the reference's order with lane shuffles; tail cells in double by lane l == 0
 #include "ops_common.h"
+#include "kernel_timing.h"
 
 #include <cstdlib>
 
@@ -340,20 +341,24 @@ template <int HD>
 static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream) {
     const dim3 grid(g.n_head_kv, (rows + rw - 1) / rw);
     const size_t lds = (size_t) rw * (g.n_kv + g.mask_words) * sizeof(float);
+    // algorithmic bytes: K and V of n_kv cells (f16) + the query rows + the fp32 output.  (A captured graph is launched with n_kv = n_ctx and reads the real
+    // n_kv from device memory: its count carries the upper bound, bench.py prices attention from the call statistics instead.)
+    const int nt = g.n_tok > 0 ? g.n_tok : 1;
+    const double bytes = (double) g.n_kv * g.n_head_kv * HD * 2 * 2 + (double) nt * g.n_head * HD * (2 + 4);
     if (g.alibi_m) {
         switch (rw) {
-            case 1: hipLaunchKernelGGL((k_attention<HD, 1, true>), grid, dim3(256), lds, stream, g); break;
-            case 2: hipLaunchKernelGGL((k_attention<HD, 2, true>), grid, dim3(256), lds, stream, g); break;
-            case 4: hipLaunchKernelGGL((k_attention<HD, 4, true>), grid, dim3(256), lds, stream, g); break;
-            default: hipLaunchKernelGGL((k_attention<HD, 8, true>), grid, dim3(256), lds, stream, g); break;
+            case 1: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 1, true>), grid, dim3(256), lds, stream, g); break;
+            case 2: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 2, true>), grid, dim3(256), lds, stream, g); break;
+            case 4: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 4, true>), grid, dim3(256), lds, stream, g); break;
+            default: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 8, true>), grid, dim3(256), lds, stream, g); break;
         }
         return;
     }
     switch (rw) {
-        case 1: hipLaunchKernelGGL((k_attention<HD, 1>), grid, dim3(256), lds, stream, g); break;
-        case 2: hipLaunchKernelGGL((k_attention<HD, 2>), grid, dim3(256), lds, stream, g); break;
-        case 4: hipLaunchKernelGGL((k_attention<HD, 4>), grid, dim3(256), lds, stream, g); break;
-        default: hipLaunchKernelGGL((k_attention<HD, 8>), grid, dim3(256), lds, stream, g); break;
+        case 1: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 1>), grid, dim3(256), lds, stream, g); break;
+        case 2: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 2>), grid, dim3(256), lds, stream, g); break;
+        case 4: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 4>), grid, dim3(256), lds, stream, g); break;
+        default: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 8>), grid, dim3(256), lds, stream, g); break;
     }
 }
 

@@ -2,6 +2,7 @@
 // Every rounding point follows the reference CPU path (see include/pipeinfer_ops.h for file:line); this file is
 // compiled with -ffp-contract=off so a*b+c is never fused where the reference rounds twice.
 #include "ops_common.h"
+#include "kernel_timing.h"
 
 #include <cmath>
 #include <vector>
@@ -89,7 +90,7 @@ __global__ void k_get_rows(pi_weight w, const int32_t * __restrict__ tokens, flo
 
 extern "C" int pi_op_get_rows(const pi_weight * w, const int32_t * tokens, int n_tok, float * out, void * stream) {
     if (n_tok <= 0) return 0;
-    hipLaunchKernelGGL(k_get_rows, dim3((unsigned) ((w->ne0 + 255) / 256), n_tok), dim3(256), 0, (hipStream_t) stream, *w, tokens, out, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, (double) n_tok * ((double) w->nbytes / (double) w->ne1 + 4.0 * w->ne0), k_get_rows, dim3((unsigned) ((w->ne0 + 255) / 256), n_tok), dim3(256), 0, (hipStream_t) stream, *w, tokens, out, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256) k_norm(const float * __restrict__ x, cons
 
 extern "C" int pi_op_norm(const float * x, const float * w, const float * b, float * y, int n, int n_tok, float eps, int rms, void * stream) {
     if (n_tok <= 0) return 0;
-    hipLaunchKernelGGL(k_norm, dim3(n_tok), dim3(256), 0, (hipStream_t) stream, x, w, b, y, n, eps, rms, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, (double) n_tok * n * 8 + (double) n * (w ? 4 : 0) + (double) n * (b ? 4 : 0), k_norm, dim3(n_tok), dim3(256), 0, (hipStream_t) stream, x, w, b, y, n, eps, rms, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -165,6 +166,9 @@ static __device__ __forceinline__ void wave_emit_frags(const q8k_frags & F, cons
     // s4: sum of the 16-group lane/4 (valid in every lane of the quad)
     if ((lane & 3) == 0) *(uint16_t *) (F.aux + cb * 1024 + 64 + (tl + 16 * (lane >> 4)) * 8 + ((lane >> 2) & 3) * 2) = __half_as_ushort(__float2half_rn((float) s4));
     if (lane == 0) *(float *) (F.aux + cb * 1024 + tl * 4) = d;
+    // 16 bytes of zeros behind the block sums (bytes 576..591 of the 1 KB image): the operand of the matrix-core kernel's idle token rows in its packed <= 8-token form
+    // (mmq_mfma.hip: k_mmq_g2) — every token of the chunk writes the same zeros
+    if (lane == 1) *(uint4 *) (F.aux + cb * 1024 + 576) = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
@@ -352,7 +356,9 @@ extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float
     const int64_t ng = (n / 32 + 3) / 4;
     const int chunks = (int) ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const int threads = 64 * (chunks < 16 ? chunks : 16);
-    hipLaunchKernelGGL(k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
+    // algorithmic bytes: the row in (fp32), weight (+ bias), the quantised planes out (Q8_K: 292 B per 256 values; 32-blocks: 34 / 40 B per 32)
+    const double qb = vdt == PI_Q8_K ? (double) n / 256 * 292 : (double) n / 32 * (vdt == PI_Q8_1 ? 40 : 34);
+    PI_KT_LAUNCH(PI_KT_NORMQ, 0, n_tok, (double) n_tok * (4.0 * n + qb + (y_f32 ? 4.0 * n : 0.0)) + 4.0 * n * ((w ? 1 : 0) + (b ? 1 : 0)), k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -390,8 +396,9 @@ extern "C" int pi_op_act_quantize(const float * gate, const float * up, int whic
     const int64_t ng = (n / 32 + 3) / 4;
     const int64_t chunks = ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const pi_tables & tb = pi_get_tables();
-    hipLaunchKernelGGL(k_act_quant, dim3((unsigned) ((chunks + 3) / 4), n_tok), dim3(256), 0, (hipStream_t) stream, gate, up, which, n, vdt, ng,
-                       which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
+    const double qb = vdt == PI_Q8_K ? (double) n / 256 * 292 : (double) n / 32 * (vdt == PI_Q8_1 ? 40 : 34);
+    PI_KT_LAUNCH(PI_KT_ACTQ, 0, n_tok, (double) n_tok * (4.0 * n * (which == 0 ? 2 : 1) + qb), k_act_quant, dim3((unsigned) ((chunks + 3) / 4), n_tok), dim3(256), 0, (hipStream_t) stream, gate, up, which, n, vdt, ng,
+                 which == 0 ? tb.silu_f16 : tb.gelu_f16, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -403,12 +410,12 @@ extern "C" int pi_op_quantize(int vdt, const float * x, int64_t k, int n_tok, vo
     uint8_t * base = (uint8_t *) q8;
     if (vdt == PI_Q8_K) {
         if (k % 256) { pi_set_error("pi_op_quantize: Q8_K needs k %% 256 == 0 (k=%lld)", (long long) k); return -1; }
-        hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob), frags_of(vdt, k, n_tok, base), pi_abort_word());
+        PI_KT_LAUNCH(PI_KT_QUANT, 0, n_tok, (double) n_tok * (4.0 * k + (double) k / 256 * 292), k_quantize_q8_K, dim3((unsigned) (k / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, (int8_t *) (base + oq), (float *) (base + od), (int16_t *) (base + ob), frags_of(vdt, k, n_tok, base), pi_abort_word());
     } else if (vdt == PI_Q8_0 || vdt == PI_Q8_1) {
         if (k % 32) { pi_set_error("pi_op_quantize: Q8_0 / Q8_1 need k %% 32 == 0 (k=%lld)", (long long) k); return -1; }
         const int64_t ng = (k / 32 + 3) / 4;
-        hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((ng * 128 + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, ng, (uint32_t *) (base + oq), (uint16_t *) (base + od),
-                           vdt == PI_Q8_1 ? (float *) (base + ob) : nullptr, pi_abort_word());
+        PI_KT_LAUNCH(PI_KT_QUANT, 0, n_tok, (double) n_tok * (4.0 * k + (double) k / 32 * (vdt == PI_Q8_1 ? 40 : 34)), k_quantize_q8_0, dim3((unsigned) ((ng * 128 + 255) / 256), n_tok), dim3(64), 0, (hipStream_t) stream, x, k, ng, (uint32_t *) (base + oq), (uint16_t *) (base + od),
+                     vdt == PI_Q8_1 ? (float *) (base + ob) : nullptr, pi_abort_word());
     } else { pi_set_error("pi_op_quantize: unsupported activation type %d", vdt); return -1; }
     PI_CHECK_LAUNCH();
     return 0;
@@ -520,7 +527,7 @@ extern "C" int pi_op_persimmon_qkv_store(const float * qkv, int n_head, int hd, 
     if (n_tok <= 0) return 0;
     const pi_rope_table * t = (const pi_rope_table *) table_;
     if (hd != 64 || t->head_dim != 32 || t->n_rot != 32) { pi_set_error("pi_op_persimmon_qkv_store: head width %d (the reference fixes 64, llama.cpp:3105-3108) with a rope table of %d/%d (needs 32/32)", hd, t->head_dim, t->n_rot); return -1; }
-    hipLaunchKernelGGL(k_persimmon_qkv, dim3(n_tok, n_head), dim3(64), 0, (hipStream_t) stream, qkv, n_head, qw, qb, kw, kb, eps, pos, t->cs, kv_head, dyn_dev, q16, kc, vc, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, (double) n_tok * n_head * hd * 3 * 6, k_persimmon_qkv, dim3(n_tok, n_head), dim3(64), 0, (hipStream_t) stream, qkv, n_head, qw, qb, kw, kb, eps, pos, t->cs, kv_head, dyn_dev, q16, kc, vc, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -532,7 +539,7 @@ extern "C" int pi_op_rope_kv_store(const float * q, const float * k, const float
     if (n_tok <= 0) return 0;
     const pi_rope_table * t = (const pi_rope_table *) table_;
     if (t->head_dim != hd) { pi_set_error("pi_op_rope_kv_store: table head_dim %d != %d", t->head_dim, hd); return -1; }
-    hipLaunchKernelGGL(k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, (double) n_tok * (n_head + 2 * n_head_kv) * hd * 6, k_rope_kv, dim3(n_tok, n_head + 2 * n_head_kv), dim3(hd / 2), 0, (hipStream_t) stream,
                        q, k, v, q_stride, k_stride, v_stride, pos, t->cs, neox, t->n_rot, hd, n_head, n_head_kv, kv_head, q16, kc, vc, dyn_dev, pi_abort_word());
     PI_CHECK_LAUNCH();
     return 0;
@@ -571,27 +578,27 @@ __global__ void k_clamp(float * __restrict__ x, float lo, float hi, int64_t n, c
 extern "C" int pi_op_add_bias(float * x, const float * b, int64_t n, int n_tok, void * stream) {
     const int64_t total = n * n_tok;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_add_bias, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, b, n, total, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, 8.0 * total + 4.0 * n, k_add_bias, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, b, n, total, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 extern "C" int pi_op_clamp(float * x, float lo, float hi, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_clamp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, lo, hi, n, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, 1, 8.0 * n, k_clamp, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, lo, hi, n, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 extern "C" int pi_op_silu_mul(const float * g, const float * u, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, g, u, o, n, pi_get_tables().silu_f16, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, 1, 12.0 * n, k_silu_mul, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, g, u, o, n, pi_get_tables().silu_f16, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 extern "C" int pi_op_gelu(const float * x, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_gelu, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, o, n, pi_get_tables().gelu_f16, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, 1, 8.0 * n, k_gelu, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, x, o, n, pi_get_tables().gelu_f16, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 extern "C" int pi_op_add(const float * a, const float * b, float * o, int64_t n, void * stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_add, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a, b, o, n, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, 1, 12.0 * n, k_add, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, a, b, o, n, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }
 
@@ -699,7 +706,7 @@ extern "C" int pi_op_topk(const float * logits, int n_vocab, int n_tok, int k, i
     if (!scratch) { pi_set_error("pi_op_topk: scratch is NULL (needs pi_op_topk_scratch_bytes(n_tok) bytes)"); return -1; }
     int32_t * cid = (int32_t *) scratch; float * cval = (float *) (cid + (size_t) n_tok * TOPK_NCH * k);
     float * cmax = cval + (size_t) n_tok * TOPK_NCH * k, * csum = cmax + (size_t) n_tok * TOPK_NCH;
-    hipLaunchKernelGGL(k_topk1, dim3(n_tok, TOPK_NCH), dim3(256), 0, (hipStream_t) stream, logits, n_vocab, k, cid, cval, cmax, csum, pi_abort_word());
-    hipLaunchKernelGGL(k_topk2, dim3(n_tok), dim3(64), 0, (hipStream_t) stream, k, cid, cval, cmax, csum, ids, vals, sumexp, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, 4.0 * n_tok * n_vocab, k_topk1, dim3(n_tok, TOPK_NCH), dim3(256), 0, (hipStream_t) stream, logits, n_vocab, k, cid, cval, cmax, csum, pi_abort_word());
+    PI_KT_LAUNCH(PI_KT_OTHER, 0, n_tok, 0.0, k_topk2, dim3(n_tok), dim3(64), 0, (hipStream_t) stream, k, cid, cval, cmax, csum, ids, vals, sumexp, pi_abort_word());
     PI_CHECK_LAUNCH(); return 0;
 }

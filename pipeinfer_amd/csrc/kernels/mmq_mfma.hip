@@ -89,8 +89,10 @@ template <int TYPE, int S> struct mq_w { uint32_t dd, rec, rec2; mq_q<S> q; mq_q
 
 // NC: chunks of 16 tokens per pass over the weights (prompt batches: NC = 2 walks 32 tokens with ONE weight stream — the operand of a (block, lane k) is built once and
 // fed to one MFMA per chunk; every chunk keeps its own chains, so each token's bits are those of a 16-token pass)
-template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1>
+// PIPE (S >= 2, one chunk, Q4_K / Q5_K): the block step as a two-stage software pipeline — see "pipelined form" below
+template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
+    static_assert(!PIPE || (NC == 1 && S >= 2 && TYPE != PI_Q6_K), "pipelined form: one chunk, split row groups, Q4_K / Q5_K");
     static_assert(NC == 1 || (NC == 2 && !NT8), "two chunks only for full 16-token chunks");
     static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
     constexpr bool Q5 = TYPE == PI_Q5_K, Q6 = TYPE == PI_Q6_K;
@@ -310,6 +312,81 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
         }
     };
 
+    // ---- pipelined form.  A short matrix has few row groups, so its waves are few (two per SIMD) and a wave's block step is one chain of latencies: LDS reads -> operand
+    //      build -> MFMA -> result latency (s_nop) -> chain fma, per accumulator lane.  Here the step is cut in two stages that overlap across blocks inside ONE basic block:
+    //      the fragments / d / block sums of block b+1 are read from LDS while block b is computed (same tile: they have landed), and the chain updates of block b are issued
+    //      behind the MFMAs of block b+1 (they only need block b's MFMA results, kept in registers).  The chains still run in block order, one fma per block: same bits.
+    //      Blocks past the end of the row (the last tile's padding) run on the clamped last block with d = dmin = 0: fma(+-0, c, acc) leaves acc as it is (acc is never -0:
+    //      it starts at +0, and x + (-x) is +0), so they need no branch — a branch would split the basic block and with it the overlap. ----
+    struct mq_act { uint4 af[KS]; float4 dy; uint2 bs; };
+    struct mq_pend { pi_f32x4 c[KS]; pi_f32x4 cm[CS]; float d[4], nd[4]; };
+    auto fetch = [&](const uint8_t * blk, mq_act & A) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) A.af[kk] = *(const uint4 *) (blk + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));
+        A.dy = *(const float4 *) (blk + 8 * FRAG + 16 * gq);
+        A.bs = *(const uint2 *) (blk + 8 * FRAG + 64 + (NT8 ? (gq * 16 + (r & 7)) : lane) * 8);
+    };
+    auto front = [&](const mq_w<TYPE, S> & W, const mq_act & A, bool live, mq_pend & P) __attribute__((always_inline)) {
+        const uint32_t ddl = live ? W.dd : 0u;
+        const float dx = pi_h2f((uint16_t) (ddl & 0xffff)), dminx = pi_h2f((uint16_t) (ddl >> 16));
+        const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);
+        const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);
+        const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);
+        const float dy[4] = { A.dy.x, A.dy.y, A.dy.z, A.dy.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) { P.d[i] = dy[i] * dx; P.nd[i] = -dy[i] * dminx; }
+        const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+            const uint32_t q = qdword(W, kk), qh = q >> 8;
+            uint4 bw;
+            if constexpr (Q5) {
+                const uint32_t t = hdword(W, kk) >> (2 * gq), th = t >> 8;
+                bw.x = pk_fma((q & 0x000F000Fu) | magic | ((t & 0x00010001u) << 4), S1, C1);
+                bw.y = pk_fma((qh & 0x000F000Fu) | magic | ((th & 0x00010001u) << 4), S1, C1);
+                bw.z = pk_fma((q & 0x00F000F0u) | magic | ((t & 0x00020002u) << 7), S2, C2);
+                bw.w = pk_fma((qh & 0x00F000F0u) | magic | ((th & 0x00020002u) << 7), S2, C2);
+            } else {
+                bw.x = pk_fma((q & 0x000F000Fu) | magic, S1, C1);
+                bw.y = pk_fma((qh & 0x000F000Fu) | magic, S1, C1);
+                bw.z = pk_fma((q & 0x00F000F0u) | magic, S2, C2);
+                bw.w = pk_fma((qh & 0x00F000F0u) | magic, S2, C2);
+            }
+            P.c[kk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, A.af[kk]), __builtin_bit_cast(pi_half8, bw), z, 0, 0, 0);
+        }
+        const uint32_t M0 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04020402u), 0xE400E400u);
+        const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);
+        const uint4 am = make_uint4(A.bs.x, A.bs.y, 0u, 0u);
+        if constexpr (Q5) {
+            if (s == 0) {
+                const uint4 bm = make_uint4(M0, M1, 0u, 0u);
+                P.cm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+            } else P.cm[0] = z;
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < CS; cc++) {
+                const int c = s * CS + cc;
+                const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);
+                P.cm[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+            }
+        }
+    };
+    auto back = [&](const mq_pend & P) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[0][kk][i] = fmaf(P.d[i], P.c[kk][i], acc[0][kk][i]);
+        if constexpr (Q5) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const float prod = P.nd[i] * P.cm[0][i]; accm[0][0][i] = accm[0][0][i] + prod; }      // (waves s != 0 add nd * 0: their accm is not read)
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < CS; cc++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) accm[0][cc][i] = fmaf(P.nd[i], P.cm[cc][i], accm[0][cc][i]);
+        }
+    };
+
     // ---- main loop: NB LDS buffers in rotation, the activations of tile T + NB - 1 are requested while tile T is computed (an LDS-DMA takes
     //      about 1.1 us from issue to landing — longer than a tile of two or three blocks computes, so one tile of look-ahead stalls every
     //      tile); ring slot u is refilled for block b + D right after block b is consumed ----
@@ -329,6 +406,51 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     // 2 NB tiles per trip: buffer (T % NB) and ring half (T % 2) are compile-time.  The uniform branches around a tile and around a block's
     // compute are deliberate: they are basic-block boundaries for the scheduler, which otherwise interleaves several blocks, doubles the
     // registers in use and spills (measured: 90 -> 124 VGPRs at S = 4, 170 -> 256 + 340 bytes of scratch at S = 1 without them)
+    if constexpr (PIPE) {
+        static_assert(TB % 2 == 0, "the pending sets alternate with the block parity");
+        mq_act A0, A1;
+        mq_pend P0, P1;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) P1.c[kk] = pi_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int cc = 0; cc < CS; cc++) P1.cm[cc] = pi_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int i = 0; i < 4; i++) { P1.d[i] = 0.0f; P1.nd[i] = 0.0f; }
+        for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
+#pragma unroll
+            for (int j = 0; j < 2 * NB; j++) {
+                const int T = T0 + j;
+                if (T >= ntile) goto pipe_done;
+                dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
+                const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
+                fetch(buf, A0);                                            // (the tile landed before the barrier that ended the previous tile)
+#pragma unroll
+                for (int u = 0; u < TB; u++) {
+                    const int b = T * TB + u;
+                    mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
+                    mq_act & Ac = (u & 1) ? A1 : A0;
+                    mq_act & An = (u & 1) ? A0 : A1;
+                    if (u + 1 < TB) fetch(buf + (u + 1) * MQ_BLK_LDS, An);
+                    // (the uniform branch is deliberate, as in the plain form: a basic-block boundary per block step — without it the steps of a tile are one scheduling
+                    //  region, the scheduler overlaps them all and spills.  b == nb still enters: it retires block nb - 1 beside a dead block.)
+                    // (two pending sets used alternately — TB is even, so a block's parity is its u's — instead of a copy per block)
+                    mq_pend & Pc = (u & 1) ? P1 : P0;
+                    mq_pend & Pp = (u & 1) ? P0 : P1;
+                    if (b <= nb) {
+                        front(W, Ac, b < nb, Pc);
+                        back(Pp);
+                    }
+                    load_w(b + D, W);
+                }
+                if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);
+                wg_barrier();
+            }
+        }
+pipe_done:
+        // the last block's chains: block step nb retired them when the row's last tile had room for it (what is pending then is a dead set); a row of whole tiles ends on an
+        // odd block, whose set is still pending
+        if (nb % TB == 0) back(P1);
+    } else
     for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
 #pragma unroll
         for (int j = 0; j < 2 * NB; j++) {
@@ -423,17 +545,244 @@ tiles_done:
     }
 }
 
+// =================================================================================================================
+// k_mmq_g2<R, TB>: Q4_K, <= 8 tokens, tall launches (the fused up + gate of a layer: 3 584 row groups = 14 per CU) — two row groups per wave, packed accumulators.
+//
+// Why: the counters (tools_dev/exp_mmq_pmc.sh) show k_mmq_kq's one-wave row groups at two waves per SIMD issuing in 32 % of their cycles, parked on a wait in 42 % and
+// stalled on a dependency in 26 %: the VALU is busy 40-50 % of the time while the one-token kernel, with MORE vector instructions for the same matrix, finishes 25 % earlier
+// at seven waves per SIMD.  The kernel is latency-bound; 208 VGPRs leave no room for a third wave, and 3 584 row groups on 2 048 wave slots are two rounds.
+// Here a wave walks TWO row groups at once: their block steps are independent instruction streams inside one basic block (the scheduler fills one row group's MFMA and LDS
+// latencies with the other's operand build), the activation fragments are read from LDS once for both, and seven such waves per CU take the launch in ONE round.
+//
+// Packed accumulators make the registers fit: with <= 8 tokens only rows 0..7 of the 16-token MFMA tile are real.  Accumulator lanes k and k + 4 share one tile — the A
+// operand of the first MFMA holds the tokens' fragment of lane k in rows 0..7 and ZEROS in rows 8..15, the second (accumulating) MFMA holds zeros in rows 0..7 and the
+// fragment of lane k + 4 in rows 8..15 — so C rows 0..7 are lane k's integer sums and rows 8..15 lane k + 4's, each exact (the other product adds exact zeros), and one chain
+// fma per tile register extends both chains: 16 + 8 chain registers per row group instead of 32 + 16, half the chain fmas.  The zero rows come from a 16-byte zero slot in the
+// block's LDS image (bytes 576..591 of the aux piece, written by the quantisers): per-lane LDS addresses pick the fragment or the slot, no VALU.  The mins use ONE MFMA per
+// pair of chains (c, c + 2): A rows 0..7 carry the block sums only in K-slice c, rows 8..15 only in K-slice c + 2, B carries the mins of both slices.
+// The fold needs no LDS: all eight chains of a (row, token) sit in two lanes 32 apart (v_permlane32_swap), summed in hsum_float_8's order.
+// Same bits as k_mmq_kq, the VALU kernel and the reference (test_mul_mat_vs_oracle runs every shape through it).
+// =================================================================================================================
+typedef uint32_t pi_u32x4 __attribute__((ext_vector_type(4)));
+struct g2_w { uint32_t dd, rec; pi_u32x4 q0, q1; };      // one lane's share of one Q4_K block of one row group: (d, dmin), its scales / mins record, 8 quant dwords
+template <int R, int TB>
+__global__ void __launch_bounds__(64 * R) k_mmq_g2(const mmvq_args g, const int n_groups) {
+    constexpr uint32_t TILE = PI_MQ_TILE, QOFF = 320;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if (pi_aborted(g.abort_w)) return;
+    constexpr int NW = R, D = 2 * TB, LW = 4, NB = 3;
+    constexpr int FRAG = 512, MQ_BLK_LDS = 8 * FRAG + 1024, NP = 5, ZSLOT = 8 * FRAG + 576;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    const int nb = g.nb, nt = g.nt, ntile = (nb + TB - 1) / TB;
+    // the wave's two row groups (the second may not exist: it then walks the launch's last row group again and stores nothing)
+    const int rg0 = ((int) blockIdx.x * R + wave) * 2;
+    uint32_t magic = 0x64006400u;
+    asm volatile("" : "+v"(magic));
+
+    struct rowgroup { const uint8_t * wbase; const mmvq_seg * sg; int64_t row0; int rows; bool active; };
+    rowgroup G[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        const int raw = rg0 + x;
+        G[x].active = raw < n_groups;
+        const int rg = G[x].active ? raw : n_groups - 1;
+        const int si = (rg >= g.seg[1].wave0) + (rg >= g.seg[2].wave0);
+        const mmvq_seg & sg = g.seg[si];
+        G[x].sg = &sg;
+        G[x].row0 = (int64_t) (rg - sg.wave0) * 16;
+        G[x].rows = sg.M - G[x].row0 < 16 ? (int) (sg.M - G[x].row0) : 16;
+        G[x].wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * TILE;
+    }
+    // The weight ring is loaded and waited for by hand.  With compiler-visible loads the wait-count pass meets, behind `if (b < nb) compute`, a path on which a slot's pending
+    // load was never waited for, and drains the ring in front of the slot's refill (vmcnt(8) with 32 loads in flight); without the branch the block steps of a tile become one
+    // scheduling region and spill.  Loads the compiler cannot see leave the counting to us: a block's four loads per row group are issued by one asm statement, every block is
+    // consumed behind `s_waitcnt vmcnt(G2_WAIT)` naming the slot's registers (consumers cannot be scheduled above it; the slot stays live — unused by anything else — from its
+    // load to that wait on EVERY path), and the ring is drained the same way before the fold reuses its registers.  vmcnt retires in order; LDS-DMAs issued in between only
+    // make the wait more conservative.
+    const uint32_t dd_off = 4 * r, rec_off = 64 + 4 * lane, q_off = QOFF + 16 * lane;
+    auto load_w = [&](int x, int b, g2_w & W) __attribute__((always_inline)) {
+        const uint8_t * wb = G[x].wbase + (size_t) (b < nb ? b : nb - 1) * TILE;          // wave-uniform: an SGPR pair
+        asm volatile("global_load_dword %0, %4, %7\n\tglobal_load_dword %1, %5, %7\n\tglobal_load_dwordx4 %2, %6, %7\n\tglobal_load_dwordx4 %3, %6, %7 offset:1024"
+                     : "=&v"(W.dd), "=&v"(W.rec), "=&v"(W.q0), "=&v"(W.q1) : "v"(dd_off), "v"(rec_off), "v"(q_off), "s"(wb));
+    };
+    // the loads of slot pair (Wa, Wb) have landed when at most `N` younger vector-memory operations are outstanding
+    #define G2_LANDED(N, Wa, Wb) asm volatile("s_waitcnt vmcnt(%8) ; landed: %0 %1 %2 %3 %4 %5 %6 %7" : "+v"((Wa).dd), "+v"((Wa).rec), "+v"((Wa).q0), "+v"((Wa).q1), "+v"((Wb).dd), "+v"((Wb).rec), "+v"((Wb).q0), "+v"((Wb).q1) : "n"(N))
+    auto dma_tile = [&](int T, uint32_t buf) __attribute__((always_inline)) {
+        if (T < ntile) {
+#pragma unroll
+            for (int i = 0; i < (NP * TB + NW - 1) / NW; i++) {
+                const int piece = i * NW + wave;
+                if (piece < NP * TB) {
+                    const int u = piece / NP, part = piece % NP;
+                    const int b = T * TB + u < nb ? T * TB + u : nb - 1;
+                    const uint8_t * src;
+                    if (part == NP - 1) src = g.aux + (size_t) b * 1024 + lane * 16;
+                    else src = g.frag + (((size_t) b * 8 + 2 * part + (lane >> 5)) * 64 + (lane & 7) + 16 * ((lane & 31) >> 3)) * 16;       // two fragments per piece, tokens 0..7 only
+                    const uint32_t dst = buf + u * MQ_BLK_LDS + part * 1024;
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
+            }
+        }
+    };
+    auto wg_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // per-lane LDS offsets inside a block image.  Pair p = accumulator lanes (p, p + 4): operand 1 = lane p's fragment in token rows 0..7, the zero slot in rows 8..15;
+    // operand 2 = the zero slot in rows 0..7, lane p + 4's fragment (token r - 8) in rows 8..15.  Mins pair m = chains (m, m + 2): the block sums of K-slice m in rows 0..7,
+    // of K-slice m + 2 in rows 8..15, zeros elsewhere.
+    const bool lo = r < 8;
+    const uint32_t fr_off = (uint32_t) (gq * 8 + (r & 7)) * 16;
+    uint32_t a1[4], a2[4], am_off[2];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { a1[p] = lo ? (uint32_t) p * FRAG + fr_off : (uint32_t) ZSLOT; a2[p] = lo ? (uint32_t) ZSLOT : (uint32_t) (p + 4) * FRAG + fr_off; }
+#pragma unroll
+    for (int m = 0; m < 2; m++) am_off[m] = (lo ? gq == m : gq == m + 2) ? (uint32_t) (8 * FRAG + 64 + (gq * 16 + (r & 7)) * 8) : (uint32_t) ZSLOT;
+    const uint32_t dy_off = 8 * FRAG + 16 * (gq & 1);                                     // d of tokens 4 (gq & 1) .. + 3: the tokens of this lane's tile registers in both halves
+    const uint32_t pairmask[2] = { (gq == 0 || gq == 2) ? 0xffffffffu : 0u, (gq == 1 || gq == 3) ? 0xffffffffu : 0u };
+
+    float acc[2][4][4], accm[2][2][4];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[x][p][i] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) accm[x][m][i] = 0.0f;
+    }
+
+    // one block of both row groups: the fragments are read once; per row group the block scalars, 8 operands, 8 + 2 MFMAs and 16 + 8 chain fmas
+    auto compute2 = [&](const g2_w & Wa, const g2_w & Wb, const uint8_t * blk) __attribute__((always_inline)) {
+        const float4 dy4 = *(const float4 *) (blk + dy_off);
+        const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
+        uint4 A1[4], A2[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) { A1[p] = *(const uint4 *) (blk + a1[p]); A2[p] = *(const uint4 *) (blk + a2[p]); }
+        uint2 AM[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) AM[m] = *(const uint2 *) (blk + am_off[m]);
+        const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const g2_w & W = x ? Wb : Wa;
+            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff)), dminx = pi_h2f((uint16_t) (W.dd >> 16));
+            const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);
+            const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);
+            const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);
+            float d[4], nd[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { d[i] = dy[i] * dx; nd[i] = -dy[i] * dminx; }
+            auto operand = [&](uint32_t q) __attribute__((always_inline)) -> uint4 {
+                const uint32_t qh = q >> 8;
+                uint4 bw;
+                bw.x = pk_fma((q & 0x000F000Fu) | magic, S1, C1);
+                bw.y = pk_fma((qh & 0x000F000Fu) | magic, S1, C1);
+                bw.z = pk_fma((q & 0x00F000F0u) | magic, S2, C2);
+                bw.w = pk_fma((qh & 0x00F000F0u) | magic, S2, C2);
+                return bw;
+            };
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint32_t qa = W.q0[p], qb = W.q1[p];                                            // accumulator lanes p and p + 4
+                const uint4 ba = operand(qa), bb = operand(qb);
+                pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, A1[p]), __builtin_bit_cast(pi_half8, ba), z, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, A2[p]), __builtin_bit_cast(pi_half8, bb), c, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[x][p][i] = fmaf(d[i], c[i], acc[x][p][i]);
+            }
+            const uint32_t M0 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04020402u), 0xE400E400u);
+            const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const uint4 am = make_uint4(AM[m].x, AM[m].y, 0u, 0u);
+                const uint4 bm = make_uint4(M0 & pairmask[m], M1 & pairmask[m], 0u, 0u);
+                const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) accm[x][m][i] = fmaf(nd[i], cm[i], accm[x][m][i]);
+            }
+        }
+    };
+
+    static_assert(D == 2 * TB, "ring = two tiles");
+    g2_w ring[2][D];
+#pragma unroll
+    for (int u = 0; u < D; u++) { load_w(0, u, ring[0][u]); load_w(1, u, ring[1][u]); }
+    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
+#pragma unroll
+    for (int j = 0; j < NB - 1; j++) dma_tile(j, lds0 + j * TB * MQ_BLK_LDS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    constexpr int DMA_MIN = (NP * TB) / NW, WAIT_N = (NB - 1) * TB * 2 * LW + (NB - 2) * DMA_MIN;
+    for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
+#pragma unroll
+        for (int j = 0; j < 2 * NB; j++) {
+            const int T = T0 + j;
+            if (T >= ntile) goto tiles_done;                   // (leave, do not skip: see k_mmq_kq)
+            dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
+            const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int b = T * TB + u;
+                g2_w & Wa = ring[0][(j % 2) * TB + u];
+                g2_w & Wb = ring[1][(j % 2) * TB + u];
+                G2_LANDED((D - 1) * 2 * LW, Wa, Wb);          // (the D - 1 younger blocks' loads may stay in flight)
+                if (b < nb) compute2(Wa, Wb, buf + u * MQ_BLK_LDS);
+                load_w(0, b + D, Wa); load_w(1, b + D, Wb);
+            }
+            if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * 2 * LW);
+            wg_barrier();
+        }
+    }
+tiles_done:
+    // (the refills past the end of the row are still in flight: their registers must not be reused before they have landed)
+#pragma unroll
+    for (int u = 0; u < D; u++) G2_LANDED(0, ring[0][u], ring[1][u]);
+    #undef G2_LANDED
+    // ---- fold in registers.  Lane (r, gq < 2) holds chains p of (row r, token 4 gq + i), lane (r, gq + 2) the chains p + 4 of the same row and token: hsum_float_8 =
+    //      ((a0 + a4) + (a2 + a6)) + ((a1 + a5) + (a3 + a7)) with a_p + a_{p+4} = own + the lane 32 further (the same sum in both lanes: fp addition commutes);
+    //      mins ((m0 + m2) + (m1 + m3)) likewise: pair m holds chain m in the low half and chain m + 2 in the high half ----
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        if (!G[x].active) continue;
+        const mmvq_seg & sg = *G[x].sg;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float sp[4], sm[2];
+#pragma unroll
+            for (int p = 0; p < 4; p++) sp[p] = acc[x][p][i] + pi_partner<32>(acc[x][p][i]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) sm[m] = accm[x][m][i] + pi_partner<32>(accm[x][m][i]);
+            float v = (sp[0] + sp[2]) + (sp[1] + sp[3]);
+            v = v + (sm[0] + sm[1]);
+            const int t = 4 * gq + i;
+            if (gq < 2 && r < G[x].rows && t < nt) {
+                const int64_t o = (int64_t) t * sg.M + G[x].row0 + r;
+                sg.out[o] = sg.res ? sg.res[o] + v : v;
+            }
+        }
+    }
+}
+
 #include <hip/hip_ext.h>
 
-template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1>
+// PI_MMQ_PIPE=0 keeps every launch on the plain block step (A/B measurements)
+static bool mmq_pipe_on() { static const bool on = !(getenv("PI_MMQ_PIPE") && atoi(getenv("PI_MMQ_PIPE")) == 0); return on; }
+template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
 static void mmq_go2(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     constexpr size_t tiles = (size_t) 3 * TB * NC * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
     static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
-    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB, NT8, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
+    // the pipelined block step pays at 9..16 tokens (same-box A/B, us per launch: 8192 x 8192 18.70 -> 17.66, 8192 x 28672 53.7 -> 50.2) and is a wash at <= 8 (17.02 / 17.17, 44.7 / 44.4)
+    if constexpr (!PIPE && NC == 1 && S >= 2 && TYPE != PI_Q6_K && !NT8) {
+        if (!g.frag || mmq_pipe_on()) { mmq_go2<TYPE, S, R, TB, NT8, NC, true>(g, groups, stream, ea, eb); if (g.frag) return; }      // (reserve: both forms set their attribute)
+    }
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB, NT8, NC, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
     const unsigned grid = (unsigned) ((groups + R - 1) / R);
-    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8, NC>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
-    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8, NC>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8, NC, PIPE>), dim3(grid), dim3(64 * S * R), lds, stream, ea, eb, 0, g, groups);
+    else    hipLaunchKernelGGL((k_mmq_kq<TYPE, S, R, TB, NT8, NC, PIPE>), dim3(grid), dim3(64 * S * R), lds, stream, g, groups);
 }
 // batches of <= 8 tokens stage half the fragment bytes and take twice the blocks per tile (TB8) in the same LDS; 17..32 tokens are two chunks over one weight
 // stream, one block per tile (the three tiles of two chunks are 54 KB)
@@ -457,6 +806,33 @@ static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t
         case 41: mmq_go<TYPE, 4, 1, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
         case 43: mmq_go<TYPE, 4, 3, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
         default: mmq_go<TYPE, 4, 2, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
+    }
+}
+// two row groups per wave (k_mmq_g2): R waves per workgroup so that the launch is ONE round of <= 256 workgroups
+template <int R>
+static void mmq_g2_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int TB = 2;
+    constexpr size_t lds = (size_t) 3 * TB * (8 * 512 + 1024);
+    const unsigned grid = (unsigned) ((groups + 2 * R - 1) / (2 * R));
+    if (ea) hipExtLaunchKernelGGL((k_mmq_g2<R, TB>), dim3(grid), dim3(64 * R), lds, stream, ea, eb, 0, g, groups);
+    else    hipLaunchKernelGGL((k_mmq_g2<R, TB>), dim3(grid), dim3(64 * R), lds, stream, g, groups);
+}
+// Q4_K, <= 8 tokens, plain fp32 output (no RoPE / KV-store epilogue), enough row groups for >= 5 two-group waves per CU.  PI_MMQ_G2=0 switches it off, PI_MMQ_G2_MIN moves the bound.
+static bool mmq_g2_wants(int type, const mmvq_args & g, int nseg, int groups) {
+    static const bool on = !(getenv("PI_MMQ_G2") && atoi(getenv("PI_MMQ_G2")) == 0);
+    static const int min_groups = getenv("PI_MMQ_G2_MIN") ? atoi(getenv("PI_MMQ_G2_MIN")) : 2304;
+    if (!on || type != PI_Q4_K || g.nt > 8 || groups < min_groups || groups > 8 * 2 * 256) return false;
+    for (int i = 0; i < nseg; i++) if (g.seg[i].store) return false;
+    return true;
+}
+static void mmq_g2_dispatch(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    const int rr = (groups + 511) / 512;                       // waves per workgroup that put the launch into one round of 256 workgroups
+    switch (rr < 4 ? 4 : rr) {
+        case 4: mmq_g2_go<4>(g, groups, stream, ea, eb); break;
+        case 5: mmq_g2_go<5>(g, groups, stream, ea, eb); break;
+        case 6: mmq_g2_go<6>(g, groups, stream, ea, eb); break;
+        case 7: mmq_g2_go<7>(g, groups, stream, ea, eb); break;
+        default: mmq_g2_go<8>(g, groups, stream, ea, eb); break;
     }
 }
 static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
@@ -499,6 +875,7 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
     else if (groups >= 384) cfg = 42;
     else cfg = 41;
     if (cfg_env) cfg = cfg_env;
+    if (!cfg_env && mmq_g2_wants(type, g, L.nseg, groups)) { mmq_g2_dispatch(g, groups, stream, ea, eb); PI_CHECK_LAUNCH(); return 0; }
     mmq_dispatch(type, g, groups, cfg, stream, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;

@@ -745,85 +745,16 @@ __global__ void __launch_bounds__(256) k_mmvq_leg(const mmvq_args g) {
     }
 }
 
-// ---- sampled per-launch timing for the roofline report (bench.py): HIP events on the launch stream around every Nth
-//      launch of each kernel instantiation.  Eager launches: samples resolved by pi_kernel_timing_report after a sync.
-//      Captured launches (HIP graphs): the event pair becomes part of the graph and is re-recorded by every replay; the
-//      engine owns the samples of a graph (pi_kt_sink) and folds their elapsed times in after each replay has finished. ----
-#include <hip/hip_ext.h>
-#include <mutex>
-#include <vector>
+// ---- launch accounting (kernel_timing.h; implementation in runtime.hip) ----
 #include "kernel_timing.h"
-namespace {
-std::mutex g_kt_mu;
-bool g_kt_on = false; int g_kt_every = 8;
-std::vector<pi_kt_sample> g_kt;                      // eager samples
-uint64_t g_kt_launches[16][9];
-double g_kt_us[16][9], g_kt_bytes[16][9]; uint64_t g_kt_n[16][9];
-std::vector<hipEvent_t> g_kt_pool;
-thread_local pi_kt_sink * g_kt_sink = nullptr;
-hipEvent_t kt_event() {
-    if (!g_kt_pool.empty()) { hipEvent_t e = g_kt_pool.back(); g_kt_pool.pop_back(); return e; }
-    hipEvent_t e = nullptr; (void) hipEventCreate(&e); return e;
-}
-void kt_fold(const pi_kt_sample & s) {
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) return;
-    const int t = s.type & 15, n = s.nt <= 8 ? s.nt : 8;
-    g_kt_us[t][n] += 1e3 * ms; g_kt_bytes[t][n] += s.bytes; g_kt_n[t][n]++;
-}
-}
-void pi_kt_set_sink(pi_kt_sink * sink) { g_kt_sink = sink; }
-bool pi_kt_enabled() { return g_kt_on; }
-void pi_kt_accumulate(pi_kt_sink * sink, uint64_t replays_launches) {
-    std::lock_guard<std::mutex> lk(g_kt_mu);
-    if (!g_kt_on) return;
-    for (auto & s : sink->samples) kt_fold(s);
-    for (auto & c : sink->launches) g_kt_launches[c.type & 15][c.nt <= 8 ? c.nt : 8] += c.count * replays_launches;
-}
-extern "C" void pi_kernel_timing(int on, int sample_every) {
-    std::lock_guard<std::mutex> lk(g_kt_mu);
-    g_kt_on = on != 0; g_kt_every = sample_every > 0 ? sample_every : 1;
-    for (auto & s : g_kt) { g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b); }
-    g_kt.clear();
-    memset(g_kt_launches, 0, sizeof g_kt_launches); memset(g_kt_us, 0, sizeof g_kt_us); memset(g_kt_bytes, 0, sizeof g_kt_bytes); memset(g_kt_n, 0, sizeof g_kt_n);
-}
-// mean duration (us) and mean algorithmic bytes of the sampled launches of k_mmvq<type, nt>; call after a device sync
-extern "C" int pi_kernel_timing_report(int type, int nt, double * avg_us, double * avg_bytes, uint64_t * n_sampled, uint64_t * n_launches) {
-    std::lock_guard<std::mutex> lk(g_kt_mu);
-    for (auto & s : g_kt) { kt_fold(s); g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b); }
-    g_kt.clear();
-    const int t = type & 15, n = nt <= 8 ? nt : 8;
-    *avg_us = g_kt_n[t][n] ? g_kt_us[t][n] / g_kt_n[t][n] : 0.0; *avg_bytes = g_kt_n[t][n] ? g_kt_bytes[t][n] / g_kt_n[t][n] : 0.0;
-    *n_sampled = g_kt_n[t][n]; *n_launches = g_kt_launches[t][n];
-    return 0;
-}
-
-
-// decides whether this launch of instance (type, nt) is one of the sampled ones; hands out its event pair
-static bool kt_begin(int type, int nt, hipEvent_t & ea, hipEvent_t & eb) {
-    bool sample = false;
-    const int ntc = nt <= 8 ? nt : 8;                      // (statistics keep one bucket for all wider batches)
-    pi_kt_sink * sink = g_kt_sink;
-    if (sink) {                                            // being captured into a graph: count per graph, no sampling (events of a graph cannot be read back)
-        bool found = false;
-        for (auto & c : sink->launches) if (c.type == type && c.nt == ntc) { c.count++; found = true; break; }
-        if (!found) sink->launches.push_back(pi_kt_count{ type, ntc, 1 });
-        return false;
-    }
-    if (g_kt_on) {
-        std::lock_guard<std::mutex> lk(g_kt_mu);
-        sample = (g_kt_launches[type & 15][ntc]++ % g_kt_every) == 0;
-        if (sample) { ea = kt_event(); eb = kt_event(); }
-    }
-    return sample;
-}
-// algorithmic bytes of a sampled launch: the weight matrices once + quantised activations + fp32 output (+ residual)
-static void kt_end(int type, int nt, const mmvq_launch & L, hipEvent_t ea, hipEvent_t eb) {
+// algorithmic bytes of a mat-vec / mat-mat launch: the weight matrices once + quantised activations + fp32 output (+ residual)
+static double kt_bytes(int type, int nt, const mmvq_launch & L) {
     const double abytes = (double) nt * ((type == PI_Q4_1 || type == PI_Q5_1) ? (double) L.g.K / 32 * 40 : (type == PI_Q4_0 || type == PI_Q8_0 || type == PI_Q5_0) ? (double) L.g.K / 32 * 34 : (double) L.g.K / 256 * 292);
     const double obytes = (double) nt * L.m_total * 4 * (L.any_res ? 2 : 1);
-    std::lock_guard<std::mutex> lk(g_kt_mu);
-    g_kt.push_back(pi_kt_sample{ ea, eb, type, nt <= 8 ? nt : 8, L.wbytes + abytes + obytes });
+    return L.wbytes + abytes + obytes;
 }
+static bool kt_begin(int type, int nt, const mmvq_launch & L, hipEvent_t & ea, hipEvent_t & eb, int fam = PI_KT_MATVEC) { return pi_kt_begin(fam, type, nt, kt_bytes(type, nt, L), ea, eb); }
+static void kt_end(int type, int nt, const mmvq_launch & L, hipEvent_t ea, hipEvent_t eb, int fam = PI_KT_MATVEC) { pi_kt_end(fam, type, nt, kt_bytes(type, nt, L), ea, eb); }
 
 template <int TYPE, int NT>
 static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
@@ -831,7 +762,7 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
     // sampled launches go through hipExtLaunchKernelGGL: its start/stop events carry the kernel's own begin/end timestamps (what
     // rocprofv3 reports as the duration); events recorded around a launch would add the dispatch gap (~3 us) to every sample
     hipEvent_t ea = nullptr, eb = nullptr;
-    const bool sample = kt_begin(TYPE, NT, ea, eb);
+    const bool sample = kt_begin(TYPE, L.g.nt, L, ea, eb);
     if constexpr (TYPE == PI_Q4_1 || TYPE == PI_Q5_0 || TYPE == PI_Q5_1) {
         const int64_t M = g.seg[0].M;
         int wpb = 1;
@@ -916,7 +847,7 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
         };
         if (R == 1) go(std::integral_constant<int, 1>{}); else if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
     }
-    if (sample) kt_end(TYPE, NT, L, ea, eb);
+    if (sample) kt_end(TYPE, L.g.nt, L, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -930,7 +861,7 @@ template <int TB, int NT>
 static int launch_mmvq2(mmvq_launch & L, hipStream_t stream) {
     mmvq_args & g = L.g;
     hipEvent_t ea = nullptr, eb = nullptr;
-    const bool sample = kt_begin(PI_Q4_K, NT, ea, eb);                      // (statistics: counted with the Q4_K launches, all bytes of the launch)
+    const bool sample = kt_begin(PI_Q4_K, L.g.nt, L, ea, eb);                 // (statistics: counted with the Q4_K launches, all bytes of the launch)
     int R = g.K >= 8192 ? 4 : 2;
     while (R > 1 && L.m_total / R < 2048) R >>= 1;
     if (R < 2) R = 2;                                                       // (the RoPE epilogue needs both rows of a pair in one wave)
@@ -955,7 +886,7 @@ static int launch_mmvq2(mmvq_launch & L, hipStream_t stream) {
         }
     };
     if (R == 2) go(std::integral_constant<int, 2>{}); else go(std::integral_constant<int, 4>{});
-    if (sample) kt_end(PI_Q4_K, NT, L, ea, eb);
+    if (sample) kt_end(PI_Q4_K, L.g.nt, L, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -1058,9 +989,9 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             L.g.aux = base + oax + (size_t) (t0 / 16) * nbq * 1024;
             L.g.nt = nt;
             hipEvent_t ea = nullptr, eb = nullptr;
-            const bool sample = kt_begin(w0->type, nt, ea, eb);
+            const bool sample = kt_begin(w0->type, nt, L, ea, eb, PI_KT_MMQ);
             rc = pi_mmq_launch(w0->type, L, stream, ea, eb);
-            if (sample) kt_end(w0->type, nt, L, ea, eb);
+            if (sample) kt_end(w0->type, nt, L, ea, eb, PI_KT_MMQ);
             if (rc) return rc;
             continue;
         }

@@ -478,3 +478,77 @@ extern "C" size_t pi_q8_nbytes(int vdt, int64_t k, int n_tok) {
     pi_q8_frag_layout(k, n_tok, nullptr, nullptr, &oa);
     return oa + (size_t) ((n_tok + 15) / 16) * (size_t) (k / 256) * 1024;
 }
+
+// =================================================================================================================
+// launch accounting (kernel_timing.h): per-instance launch counts + algorithmic bytes, sampled durations of eager launches
+// =================================================================================================================
+#include "kernel_timing.h"
+#include <map>
+#include <mutex>
+#include <tuple>
+namespace {
+struct kt_stat { uint64_t launches = 0; double bytes = 0.0; uint64_t sampled = 0; double us = 0.0, sampled_bytes = 0.0; };
+std::mutex g_kt_mu;
+bool g_kt_on = false; int g_kt_every = 8;
+std::map<std::tuple<int, int, int, uint64_t>, kt_stat> g_kt_tab;       // (family, type, tokens, launch shape) -> eager launches
+uint64_t kt_shape(int fam, double bytes) { return fam <= PI_KT_MMQ ? (uint64_t) bytes : 0; }   // mat launches: one row per distinct launch (its algorithmic bytes name it: wo, q+k, up+gate, ...)
+std::vector<pi_kt_sample> g_kt_pending;                      // timed launches whose events have not been read yet
+std::vector<hipEvent_t> g_kt_pool;
+thread_local pi_kt_sink * g_kt_sink = nullptr;
+int kt_nt(int nt) { return nt < 1 ? 1 : nt < PI_KT_MAXNT ? nt : PI_KT_MAXNT - 1; }
+hipEvent_t kt_event() {
+    if (!g_kt_pool.empty()) { hipEvent_t e = g_kt_pool.back(); g_kt_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void) hipEventCreate(&e); return e;
+}
+void kt_fold_pending() {                                     // (caller holds g_kt_mu; the device has been synchronised)
+    for (auto & s : g_kt_pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { kt_stat & st = g_kt_tab[std::make_tuple(s.fam, s.type, s.nt, kt_shape(s.fam, s.bytes))]; st.sampled++; st.us += 1e3 * ms; st.sampled_bytes += s.bytes; }
+        g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b);
+    }
+    g_kt_pending.clear();
+}
+}
+void pi_kt_set_sink(pi_kt_sink * sink) { g_kt_sink = sink; }
+bool pi_kt_enabled() { return g_kt_on; }
+bool pi_kt_begin(int fam, int type, int nt, double bytes, hipEvent_t & ea, hipEvent_t & eb) {
+    const int ntc = kt_nt(nt);
+    if (pi_kt_sink * sink = g_kt_sink) {                     // being captured: the graph's own list (the engine multiplies by its replays); nothing is timed
+        for (auto & c : sink->launches) if (c.fam == fam && c.type == type && c.nt == ntc && kt_shape(fam, c.bytes) == kt_shape(fam, bytes)) { c.count++; c.bytes_sum += bytes; return false; }
+        sink->launches.push_back(pi_kt_count{ fam, type, ntc, 1, bytes, bytes });
+        return false;
+    }
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    if (!g_kt_on) return false;                              // (eager launches outside a timing window are not counted: the table belongs to the window)
+    kt_stat & st = g_kt_tab[std::make_tuple(fam, type, ntc, kt_shape(fam, bytes))];
+    const bool sample = (st.launches % (uint64_t) g_kt_every) == 0;
+    st.launches++; st.bytes += bytes;
+    if (sample) { ea = kt_event(); eb = kt_event(); }
+    return sample;
+}
+void pi_kt_end(int fam, int type, int nt, double bytes, hipEvent_t ea, hipEvent_t eb) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    g_kt_pending.push_back(pi_kt_sample{ ea, eb, fam, type, kt_nt(nt), bytes });
+}
+extern "C" void pi_kernel_timing(int on, int sample_every) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    g_kt_on = on != 0; g_kt_every = sample_every > 0 ? sample_every : 1;
+    for (auto & s : g_kt_pending) { g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b); }
+    g_kt_pending.clear();
+    g_kt_tab.clear();
+}
+// one row per instance launched since pi_kernel_timing(1, N): call after a device sync.  Returns the number of rows (<= cap)
+extern "C" int pi_kernel_timing_rows(struct pi_kt_row * out, int cap) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    kt_fold_pending();
+    int n = 0;
+    for (auto & kv : g_kt_tab) {
+        if (n >= cap) break;
+        const kt_stat & st = kv.second;
+        pi_kt_row & r = out[n++];
+        r.family = std::get<0>(kv.first); r.type = std::get<1>(kv.first); r.n_tok = std::get<2>(kv.first); r.shape_bytes = std::get<3>(kv.first);
+        r.launches = st.launches; r.bytes_total = st.bytes; r.sampled = st.sampled;
+        r.avg_us = st.sampled ? st.us / (double) st.sampled : 0.0; r.avg_sampled_bytes = st.sampled ? st.sampled_bytes / (double) st.sampled : 0.0;
+    }
+    return n;
+}

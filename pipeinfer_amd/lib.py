@@ -84,7 +84,8 @@ def _declare(lib):
     lib.pi_op_abort_begin.argtypes = [vp, i32, vp, vp]
     lib.pi_op_abort_cancel.argtypes = [vp, i32, vp]
     lib.pi_kernel_timing.argtypes = [i32, i32]
-    lib.pi_kernel_timing_report.argtypes = [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.pi_kernel_timing_rows.argtypes = [vp, i32]
+    lib.pi_kernel_timing_rows.restype = i32
     lib.pi_weight_upload.restype = vp
     lib.pi_weight_upload.argtypes = [i32, i64, i64, vp, vp]
     lib.pi_weight_free.argtypes = [vp]

@@ -216,6 +216,20 @@ class Context:
         if self.lib.pipeinfer_context_set_coalescing(self.h, int(max_tokens)) != 0:
             raise L.PipeInferError(self.lib.pipeinfer_context_error(self.h).decode())
 
+    def set_run_tap(self, fn):
+        """fn(run_id, batch_id, n_tokens, meta int32 array (a copy), logits [n_tokens][n_vocab] (a copy) or None): at every start (logits None) and finish of a run"""
+        TAP = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_float))
+        nv = self.n_vocab
+
+        def _tap(user, run_id, batch_id, n, meta, nbytes, logits):
+            block = np.frombuffer(C.string_at(meta, (nbytes + 3) // 4 * 4), dtype=np.int32).copy()
+            rows = np.ctypeslib.as_array(logits, shape=(n, nv)).copy() if logits else None
+            fn(run_id, batch_id, n, block, rows)
+        self._tap = TAP(_tap) if fn else None                                   # (kept alive with the context)
+        self.lib.pipeinfer_context_set_run_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.pipeinfer_context_set_run_tap.restype = None
+        self.lib.pipeinfer_context_set_run_tap(self.h, C.cast(self._tap, C.c_void_p) if fn else None, None)
+
     def set_graphs(self, enable):
         self.lib.pipeinfer_context_set_graphs.argtypes = [C.c_void_p, C.c_int]
         self.lib.pipeinfer_context_set_graphs.restype = None

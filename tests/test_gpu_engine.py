@@ -641,6 +641,9 @@ def _coalescing_scenario(LL, model_path, n_ctx, n_batch, seg_layers, rng):
     c.set_segments(seg_layers)
     c.prepare(); ref.prepare()
     c.set_coalescing(16)
+    from tests.oracle_follow import RunLog
+    log = RunLog()
+    c.set_run_tap(log.tap)                                                                 # ... and every run of the coalescing context against the ORACLE (below)
     nv = m.n_vocab
     prompt = [int(x) for x in rng.integers(3, nv, 12)]
     a = c.decode(prompt, list(range(12)), [[0, 1, 2, 3]] * 12); b = ref.decode(prompt, list(range(12)), [[0, 1, 2, 3]] * 12)
@@ -688,12 +691,23 @@ def _coalescing_scenario(LL, model_path, n_ctx, n_batch, seg_layers, rng):
         coalesced = c.stats()["n_coalesced_passes"]
     st = c.stats()
     c.free(); ref.free(); m.free()
+    # the coalescing context's runs — most of them carried by a pass shared with other runs (compose_pass, per-token n_kv and cell table in the attention launches, the
+    # same-computation hand-over of round 3, the member cancelled inside its pass) — replayed ONE BY ONE through the oracle on the same cells (tests/oracle_follow.py)
+    from tests import oracle_lib as O
+    o = O.oracle()
+    o.o_set_threads(int(os.environ.get("ORACLE_THREADS", "32")))
+    oh = o.o_model_load(model_path.encode(), n_ctx, 8)
+    assert oh
+    compared, bad = log.replay(o, oh, n_ctx, nv)
+    o.o_model_free(oh)
+    assert compared >= 6 * 5 and not bad, (compared, bad[:5])
+    st["oracle_runs_compared"] = compared
     return st
 
 
 def test_coalesced_runs_equal_runs_decoded_one_by_one(LL):
     st = _coalescing_scenario(LL, os.path.join(GOLD, "tiny_llama_b_q4_k_m.gguf"), 256, 64, 1, np.random.default_rng(3))
-    print("tiny:", {k: st[k] for k in ("n_passes", "n_pass_runs", "n_pass_tokens", "n_coalesced_passes", "n_cancel_runs")})
+    print("tiny:", {k: st[k] for k in ("n_passes", "n_pass_runs", "n_pass_tokens", "n_coalesced_passes", "n_cancel_runs", "oracle_runs_compared")})
     assert st["n_coalesced_passes"] >= 3 and st["n_pass_runs"] > st["n_passes"]
 
 
@@ -707,6 +721,19 @@ def test_coalesced_runs_equal_single_runs_at_full_size_shapes(LL, workload):
     st = _coalescing_scenario(LL, path, 512, 64, 2, np.random.default_rng(5))
     print(workload, {k: st[k] for k in ("n_passes", "n_pass_runs", "n_pass_tokens", "n_coalesced_passes")})
     assert st["n_coalesced_passes"] >= 3
+
+
+@pytest.mark.parametrize("workload,n_predict", [("70b-l4", 48), ("7b", 40)])
+def test_headline_schedule_equals_the_oracle_run_by_run(workload, n_predict):
+    """bench.py's `value` configuration itself — PipeInfer driver, target segmented behind its feeder with run coalescing 16, priority draft, one GPU — with every run of the
+    generation (prompt passes, single tokens, speculative batches; most of them members of a pass shared with other runs, some cancelled inside one) replayed one by one through
+    the oracle on the cells, n_kv and visibility rows the run was given (tests/headline_trace_worker.py; llama.cpp:1593-1644, 5200-5240, speculative.cpp:1252-1255): bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "headline_trace_worker.py"), workload, str(n_predict)], capture_output=True, text=True, timeout=1500, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-3000:])
+    assert "HEADLINE-TRACE OK" in r.stdout, r.stdout[-2000:]
+    print(r.stdout[-600:])
 
 
 @pytest.mark.parametrize("tgt,dft", [("tiny_llama_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m"), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0"), ("tiny_llama_q3_k_m", "tiny_llama_q4_0")])

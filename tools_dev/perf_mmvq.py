@@ -26,7 +26,7 @@ for t, rows, k in shapes:
         for _ in range(5):
             lib.pi_op_mul_mat(w, q8.ptr, nt, out.ptr, None, None)
         lib.pi_device_sync()
-        n = 200
+        n = int(os.environ.get("NLAUNCH", "200"))
         t0 = time.perf_counter()
         for i in range(n):
             lib.pi_op_mul_mat(ws[i % ncopy], q8.ptr, nt, out.ptr, None, None)
