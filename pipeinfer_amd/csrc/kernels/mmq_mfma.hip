@@ -775,6 +775,8 @@ static void mmq_go2(const mmvq_args & g, int groups, hipStream_t stream, hipEven
     constexpr size_t tiles = (size_t) 3 * TB * NC * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
     static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
+    // (Two blocks per scheduling region — the block-axis analogue of k_mmq_g2's two row groups — was built and measured too: no gain on any split-row-group shape,
+    //  Q6_K 8192 x 28672 62.7 -> 67.5 us; removed.)
     // the pipelined block step pays at 9..16 tokens (same-box A/B, us per launch: 8192 x 8192 18.70 -> 17.66, 8192 x 28672 53.7 -> 50.2) and is a wash at <= 8 (17.02 / 17.17, 44.7 / 44.4)
     if constexpr (!PIPE && NC == 1 && S >= 2 && TYPE != PI_Q6_K && !NT8) {
         if (!g.frag || mmq_pipe_on()) { mmq_go2<TYPE, S, R, TB, NT8, NC, true>(g, groups, stream, ea, eb); if (g.frag) return; }      // (reserve: both forms set their attribute)
@@ -817,10 +819,14 @@ static void mmq_g2_go(const mmvq_args & g, int groups, hipStream_t stream, hipEv
     if (ea) hipExtLaunchKernelGGL((k_mmq_g2<R, TB>), dim3(grid), dim3(64 * R), lds, stream, ea, eb, 0, g, groups);
     else    hipLaunchKernelGGL((k_mmq_g2<R, TB>), dim3(grid), dim3(64 * R), lds, stream, g, groups);
 }
-// Q4_K, <= 8 tokens, plain fp32 output (no RoPE / KV-store epilogue), enough row groups for >= 5 two-group waves per CU.  PI_MMQ_G2=0 switches it off, PI_MMQ_G2_MIN moves the bound.
+// Q4_K, <= 8 tokens, plain fp32 output (no RoPE / KV-store epilogue), tall launches.  PI_MMQ_G2=0 switches it off, PI_MMQ_G2_MIN moves the bound.
 static bool mmq_g2_wants(int type, const mmvq_args & g, int nseg, int groups) {
     static const bool on = !(getenv("PI_MMQ_G2") && atoi(getenv("PI_MMQ_G2")) == 0);
-    static const int min_groups = getenv("PI_MMQ_G2_MIN") ? atoi(getenv("PI_MMQ_G2_MIN")) : 2304;
+    // every launch of the one-wave-per-row-group range (> 1152 row groups).  Same-box A/B against k_mmq_kq, us per launch at 4 / 6 / 8 tokens: 57344 x 8192 (the 70B up + gate,
+    // 3 584 row groups: two rounds before, one now) 71.5 / 71.8 / 71.8 -> 55.1 / 55.5 / 55.9 (one token: 52.8); 44032 x 4096 (7B up + gate) 42.2 -> 27.9; the
+    // launches that were one round already gain little: 28672 x 8192 39.0 / 37.1 / 37.7 -> 38.4 / 37.1 / 36.8, 32768 x 8192 41.4 / 39.4 / 39.9 -> 39.9 / 38.3 / 38.4,
+    // 22016 x 4096 22.4 / 21.8 / 21.9 -> 21.5 / 21.3 / 21.2
+    static const int min_groups = getenv("PI_MMQ_G2_MIN") ? atoi(getenv("PI_MMQ_G2_MIN")) : 1153;
     if (!on || type != PI_Q4_K || g.nt > 8 || groups < min_groups || groups > 8 * 2 * 256) return false;
     for (int i = 0; i < nseg; i++) if (g.seg[i].store) return false;
     return true;
