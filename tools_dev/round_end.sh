@@ -1,0 +1,25 @@
+#!/bin/bash
+# end of a round on the GPU box: full GPU suite, the profile round (rocprofv3 kernel stats of the default and the target-only schedule + the PMC FETCH_SIZE pass), and the
+# bench lines of BASELINE's configurations.   tools_dev/round_end.sh <round tag, e.g. r04> [skip-tests]
+#   -> gpurun_out/<tag>z/*; then (here) copy what is to be judged into profiles/: tools_dev/round_end.sh prints the cp lines
+cd "$(dirname "$0")/.."
+tag=${1:-r04}; out=gpurun_out/${tag}z; mkdir -p $out
+if [ "$2" != "skip-tests" ]; then
+    timeout 2700 python3 -m pytest tests -m gpu -q --durations=5 > $out/gpu_tests.log 2>&1; tail -6 $out/gpu_tests.log
+fi
+bash tools_dev/profile_round.sh ${tag}prof > $out/profile_round.log 2>&1; tail -3 $out/profile_round.log | cut -c1-300
+line() { # name, bench args...
+    local name=$1; shift
+    timeout 1500 python3 bench.py "$@" > $out/bench_$name.json 2> $out/bench_$name.err || tail -3 $out/bench_$name.err
+    python3 -c "
+import json,sys; d=json.loads([l for l in open('$out/bench_$name.json') if l.startswith('{')][-1]); r=d['roofline']
+print('$name', d['value'], d['lossless_vs_target_only'], {k:(v['tokens_per_s'], v['lossless_vs_target_only']) for k,v in d['other_schedules'].items()}, r['family'], r['frac'], r['traffic'], r['target_decode_call'], r['draft_decode_call'], d.get('cpu_baseline', {}).get('value'))"
+}
+line 70b_n1 --steps 10 --warmup 2
+line 7b_n1 --workload 7b --steps 5 --warmup 1
+line falcon40b_n1 --workload falcon40b --steps 3 --warmup 1 --no-cpu-baseline
+line goliath_n1 --workload goliath --n-draft 8 --steps 3 --warmup 1 --no-cpu-baseline
+echo "copy (in the build container):"
+echo "  cp gpurun_out/${tag}prof/pmc_fetch_size.json profiles/${tag}_pmc_fetch_size_70b.json"
+echo "  for f in 70b_n1 7b_n1 falcon40b_n1 goliath_n1; do cp $out/bench_\$f.json profiles/${tag}_bench_\$f.json; done"
+echo "  cp gpurun_out/${tag}prof/stats/*kernel_stats.csv profiles/${tag}_bench_70b_default_eager_kernel_stats.csv; cp gpurun_out/${tag}prof/stats_t/*kernel_stats.csv profiles/${tag}_bench_70b_target_only_eager_kernel_stats.csv"
