@@ -346,6 +346,9 @@ def main():
     ct, cd = LL.Context(mt, n_ctx=args.n_ctx, n_batch=512), LL.Context(md, n_ctx=args.n_ctx, n_batch=512)
     cd.set_priority(int(os.environ.get("PIPEINFER_DRAFT_PRIORITY", "1")))
     ct.set_priority(int(os.environ.get("PIPEINFER_TARGET_PRIORITY", "0")))
+    draft_cus = int(os.environ.get("PIPEINFER_DRAFT_CUS", "0"))
+    if draft_cus > 0:                                  # disjoint CU masks: the draft's stream on the first `draft_cus` compute units, the target's on the rest
+        cd.set_cu_range(0, draft_cus); ct.set_cu_range(draft_cus, 256)
     # one GPU: the target's stage graphs are launched segment by segment by a feeder thread, so that a cancelled speculative run stops at the
     # next segment boundary and the (high-priority) draft is served between segments instead of behind whole target runs
     # Segment size = how often the draft gets the GPU (between segments the feeder lets the priority context go first) and how much of a run is enqueued ahead of the GPU.

@@ -109,6 +109,10 @@ struct pipeinfer_transport_stats {
     double   wait_out_ms;                              /* stage: back-pressure — waiting for a free slot in the next stage's ring (or the result ring) before a run */
     double   hop_gpu_ms;                               /* stage: GPU time of the in-stream store of the activations into the next stage's ring (last stage: of the logits into the result slot) */
     int32_t  peer_access;                              /* stage: what hipDeviceCanAccessPeer said for (this device -> next stage's device); -1: not asked (same device, host rings, last stage) */
+    int32_t  device_flags;                             /* stage: 1 = runs cross the stage boundaries on device-side arrival flags (announced early, enqueued behind a device wait); 0 = headers published by the host after the run */
+    uint64_t flag_runs;                                /* stage: runs that waited for their activations on the device */
+    double   flag_wait_gpu_ms;                         /* stage: GPU time those runs' wait kernels spent waiting for their input (pipeline fill + the upstream stage's compute) */
+    double   flag_seen_us;                             /* stage: sum over those runs of (flag seen by the waiting kernel - flag stamped by the producing stream), device clock: valid between stages on ONE device */
 };
 /* stage compute behind the transport when it is not a llama_context of this library (the CPU tests plug the oracle in here):
  * 0 = computed, 1 = dropped, < 0 error; x_in / x_out are host pointers when the transport runs on host rings */

@@ -51,8 +51,19 @@ PI_API int     pi_device_sync(void);
  *   pi_op_abort_begin   (in stream order, ahead of a run's kernels)  word = run_id << 1 | (*host_flag != 0); host_flag: pinned host memory, nullable
  *   pi_op_abort_cancel  (any stream, any time)                        if word == run_id << 1 then word |= 1: only the run that is executing NOW is hit */
 PI_API void    pi_set_abort_word(const int32_t * word_dev);
+/* launches of the calling thread from now on go to a stream restricted to `n` compute units (hipExtStreamCreateWithCUMask): the launchers size "one round of workgroups" for it (0 / 256: the whole chip) */
+PI_API void    pi_set_cu_count(int n);
 PI_API int     pi_op_abort_begin(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, void * stream);
 PI_API int     pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * stream);
+/* Arrival flags of the stage transport (reference: the blocking MPI_Recv of the activations, ggml-mpi.c:451-487): a 16-byte record {ticket << 1 | aborted, -, realtime stamp}
+ * in page-locked host memory mapped by the producing and the consuming process.
+ *   pi_op_flag_publish      (producer's stream, behind its peer store)  flag = ticket << 1 | (abort word & 1 | force_abort), stamped with the device's 100 MHz clock
+ *   pi_op_abort_begin_wait  (consumer's stream, ahead of the run)       polls the flag from the device until it carries `ticket` (at most timeout_us: then the run is marked
+ *                           aborted and *timeout_flag_dev = 1), then arms the abort word like pi_op_abort_begin, with the producer's abort bit or-ed in;
+ *                           hop_ticks_dev (nullable) accumulates {flag written -> seen, time waited, runs} in 10 ns ticks */
+PI_API int     pi_op_flag_publish(void * flag_dev, uint32_t ticket, const int32_t * abort_word_dev, int force_abort, void * stream);
+PI_API int     pi_op_abort_begin_wait(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, const void * flag_dev, uint32_t ticket, int64_t timeout_us,
+                                      int32_t * timeout_flag_dev, uint64_t * hop_ticks_dev, void * stream);
 
 /* Launch accounting for the roofline report.  An instance = (family, weight type, tokens of the launch); families: 0 VALU mat-vec (k_mmvq_*), 1 matrix-core mat-mat
  * (k_mmq_kq), 2 norm + quantise, 3 quantise, 4 activation + quantise, 5 attention, 6 everything else (get_rows, RoPE + KV store, norms, adds, top-k).

@@ -37,6 +37,8 @@ llama_context::~llama_context() {
     for (uint8_t * b : pass_host) if (b) (void) hipHostFree(b);
     if (ctl_stream) { (void) hipStreamSynchronize(ctl_stream); (void) hipStreamDestroy(ctl_stream); }
     if (abort_host) (void) hipHostFree(abort_host);
+    if (hop_host) (void) hipHostFree(hop_host);
+    pi_free(hop_dev);
     pi_free(abort_dev);
     void * bufs[] = { k_cache, v_cache, x, x2, nx, nx2, qkv, att, up, gate, logits_dev, q16, q8a, q8b, q8c, tokens_dev, pos_dev, dyn_dev, mask_dev, topk_ids_dev, topk_vals_dev, topk_sum_dev, topk_scratch_dev };
     for (void * b : bufs) pi_free(b);
@@ -390,6 +392,7 @@ static bool launch_abort_begin(llama_context * ctx, int32_t run_id) {
 // launch_inputs refreshed, so replaying the captured graph IS this call's segment
 static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out, bool multi = false, bool capture_only = false) {
     const bool tracing = trace_enabled();
+    pi_set_cu_count(ctx->cu_hi > ctx->cu_lo ? ctx->cu_hi - ctx->cu_lo : 0);     // (thread-local: the launchers of this thread size their grids for the CUs this context's stream may use)
     const int nseg = n_segments(ctx);
     const int la = ctx->seg_layers > 0 ? ctx->l0 + seg * ctx->seg_layers : ctx->l0;
     const int lb = ctx->seg_layers > 0 ? std::min(ctx->l1, la + ctx->seg_layers) : ctx->l1;
@@ -805,56 +808,82 @@ bool context_wait(llama_context * ctx, pi_run * run) {
 // One run on a pipeline stage (a process that owns layers [l0, l1)).  Mirrors the worker side of llama_decode_internal
 // (llama.cpp:5588-5760): receive activations, compute the local graph, hand the result on; here the transport is the caller's.
 int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
-              float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void *), void * abort_user) {
+              float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void *), void * abort_user, const pi_stage_hop * hop) {
     std::string err;
     if (!context_prepare(ctx, err)) { ctx->last_error = err; return -1; }
     const int words = (ctx->n_ctx + 31) / 32;
     if (n_tokens <= 0 || n_tokens > ctx->n_batch || meta_bytes < (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4) { ctx->last_error = "stage_run: bad metadata block"; return -1; }
     if (!ctx->is_first && !x_in) { ctx->last_error = "stage_run: activations missing"; return -1; }
     hipStream_t s = ctx->stream;
+    const bool flag_in = hop && hop->in_flag && !ctx->is_first && ctx->abort_dev, flag_out = hop && hop->out_flag && !ctx->is_last;
+    if ((flag_in || flag_out) && !ctx->hop_dev) {
+        ctx->hop_dev = (uint8_t *) pi_malloc(64);
+        if (!ctx->hop_dev || hipHostMalloc((void **) &ctx->hop_host, 64, hipHostMallocDefault) != hipSuccess) { ctx->last_error = "stage_run: no memory for the arrival-flag block"; return -1; }
+        pi_memset(ctx->hop_dev, 0, 64, nullptr); memset(ctx->hop_host, 0, 64);
+        if (hipDeviceSynchronize() != hipSuccess) { ctx->last_error = "stage_run: hipDeviceSynchronize failed"; return -1; }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr, ec = nullptr;
     (void) hipEventCreate(&e0); (void) hipEventCreate(&e1); (void) hipEventCreate(&ec);
-    (void) hipEventRecord(e0, s);
     // the run's identity on the device: its kernels carry the context's abort word, so a cancel that reaches this process while the stage is inside the run
     // (stage_abort_run, called by the transport's watcher) stops it at the next KERNEL, not at the next segment (llama.cpp:5665-5687 polls between graph nodes)
     const int32_t rid = (++ctx->run_counter) & 0x3fffffff;
     if (ctx->abort_host) ctx->abort_host[rid & 255] = 0;
     ctx->stage_run_id.store(rid);
+    bool ok = true, cut = false;
+    // Arrival flag: the upstream stage has only ANNOUNCED this run — the kernel below waits, on the device, until its activations have landed in x_in, and arms the abort
+    // word (with the abort the upstream run ended with).  Everything behind it is enqueued now: when the flag arrives no host thread stands between the stages.
+    // (e0 is recorded behind the wait: the GPU time of the run does not include the time it waited for its input.)
+    if (flag_in) {
+        if (pi_op_abort_begin_wait(ctx->abort_dev, rid, ctx->abort_host + (rid & 255), hop->in_flag, hop->in_ticket, hop->wait_timeout_us, (int32_t *) ctx->hop_dev, (uint64_t *) (ctx->hop_dev + 8), s) != 0) {
+            ctx->last_error = std::string("pi_op_abort_begin_wait: ") + pi_last_error(); ok = false;
+        }
+    }
+    (void) hipEventRecord(e0, s);
     // With an abort callback and a segmented context (pipeinfer_context_set_segments) the calling thread plays the feeder: segments go
     // out at most two ahead of the GPU and the callback is asked before each — the unlaunched rest of a cancelled run is never enqueued.
-    bool ok = true, cut = false;
     const int nseg = n_segments(ctx);
     if (should_abort && nseg > 1) {
-        if (!ctx->seg_events[0]) ok = hipEventCreateWithFlags(&ctx->seg_events[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->seg_events[1], hipEventDisableTiming) == hipSuccess;
+        if (!ctx->seg_events[0]) ok = ok && hipEventCreateWithFlags(&ctx->seg_events[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->seg_events[1], hipEventDisableTiming) == hipSuccess;
         const int kv_head = ((const int32_t *) meta)[2 * n_tokens];
         if (ok) ok = launch_inputs(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in);
         int seg = 0;
         for (; ok && seg < nseg; seg++) {
             if (seg >= 2) (void) hipEventSynchronize(ctx->seg_events[seg & 1]);
             if (seg > 0 && should_abort(abort_user)) { cut = true; break; }
-            ok = launch_abort_begin(ctx, rid);
+            if (!(flag_in && seg == 0)) ok = launch_abort_begin(ctx, rid);      // (the wait kernel armed the word for the first segment; later ones keep an abort it carries)
             if (ok) ok = launch_segment(ctx, n_tokens, kv_head, seg, nullptr);
             if (ok) ok = hipEventRecord(ctx->seg_events[seg & 1], s) == hipSuccess;
         }
         ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
     } else {
-        ok = launch_abort_begin(ctx, rid);
+        if (ok && !flag_in) ok = launch_abort_begin(ctx, rid);
         if (ok) ok = launch_forward(ctx, n_tokens, meta, ctx->is_first ? nullptr : x_in, nullptr);
     }
     const size_t nv = ctx->model->hparams.n_vocab;
     (void) hipEventRecord(ec, s);
-    // the hop: the activations are stored by THIS stream straight into the consumer's ring slot (x_out: a peer mapping of the next stage's HBM, or host memory)
+    // the hop: the activations are stored by THIS stream straight into the consumer's ring slot (x_out: a peer mapping of the next stage's HBM, or host memory) ...
     if (ok && !cut && !ctx->is_last) ok = hipMemcpyAsync(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;
+    // ... and the consumer's arrival flag right behind them (with the abort this run ended with: a run cut short here must not be computed downstream either)
+    if (ok && flag_out && pi_op_flag_publish(hop->out_flag, hop->out_ticket, ctx->abort_dev, cut ? 1 : 0, s) != 0) { ctx->last_error = std::string("pi_op_flag_publish: ") + pi_last_error(); ok = false; }
     if (ok && !cut && ctx->is_last)
         ok = hipMemcpyAsync(logits_host, ctx->logits_dev, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipMemcpyAsync(topk_ids, ctx->topk_ids_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipMemcpyAsync(topk_vals, ctx->topk_vals_dev, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipMemcpyAsync(topk_sum, ctx->topk_sum_dev, (size_t) 4 * n_tokens, hipMemcpyDeviceToHost, s) == hipSuccess;
     (void) hipEventRecord(e1, s);
+    if (ok && flag_in)                                                          // what the wait saw (time-out, clock ticks) and the abort word the run ended with
+        ok = hipMemcpyAsync(ctx->hop_host, ctx->hop_dev, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(ctx->hop_host + 32, ctx->abort_dev, 4, hipMemcpyDeviceToHost, s) == hipSuccess;
     if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
     ctx->stage_run_id.store(0);
     // cancelled while its (last) kernels were enqueued: they returned on entry, what the copies above moved is not a result
     if (ok && !cut && ((ctx->abort_host && ctx->abort_host[rid & 255]) || (should_abort && should_abort(abort_user)))) cut = true;
+    if (ok && flag_in) {
+        const int32_t w = *(const int32_t *) (ctx->hop_host + 32);
+        if ((w >> 1) == rid && (w & 1)) cut = true;                            // aborted upstream (or while it waited): the kernels returned on entry
+        if (*(const int32_t *) ctx->hop_host) { ctx->last_error = "stage_run: the run's activations never arrived (arrival flag timed out: the upstream stage is gone)"; ok = false; }
+        const uint64_t * tk = (const uint64_t *) (ctx->hop_host + 8);
+        ctx->stat_flag_seen_us = (double) tk[0] / 100.0; ctx->stat_flag_wait_ms = (double) tk[1] / 1e5; ctx->stat_flag_runs = tk[2];      // (running sums kept on the device)
+    }
     float ms = 0.0f;
     if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { ctx->stat_gpu_ms += ms; if (n_tokens == 1 && !cut) ctx->stat_gpu_ms_1 += ms; }
     if (ok && !cut && hipEventElapsedTime(&ms, ec, e1) == hipSuccess) ctx->stat_hop_ms += ms;

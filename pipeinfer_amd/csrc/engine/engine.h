@@ -192,6 +192,9 @@ struct llama_context {
     int32_t * abort_dev = nullptr; int32_t * abort_host = nullptr; hipStream_t ctl_stream = nullptr; int32_t run_counter = 0;
     std::atomic<int32_t> stage_run_id{0};    // pipeline stages (stage_run): id of the run being computed, 0 between runs (read by the transport's cancel watcher)
     double stat_hop_ms = 0.0;                // pipeline stages: GPU time of the in-stream store of the activations into the next stage's ring
+    // arrival flags (pi_stage_hop): device block {int32 timed_out, -, uint64 ticks[3] = flag written -> seen, waited, runs} and its pinned mirror + the abort word read back after a run
+    uint8_t * hop_dev = nullptr; uint8_t * hop_host = nullptr;
+    double stat_flag_seen_us = 0.0, stat_flag_wait_ms = 0.0; uint64_t stat_flag_runs = 0;        // sums over the runs that waited on a flag
     uint64_t stat_cancel_runs = 0, stat_cancel_runs_started = 0; double stat_cancel_gpu_ms = 0.0;     // cancelled runs: all / handed to the GPU before the cancel / GPU time they still took
     bool prepared = false, prepare_failed = false;      // device state fully allocated / an attempt failed half-way (never retried)
     int32_t * topk_ids_dev = nullptr; float * topk_vals_dev = nullptr, * topk_sum_dev = nullptr; void * topk_scratch_dev = nullptr;
@@ -226,9 +229,12 @@ bool context_precapture(llama_context * ctx, int max_tokens);             // cap
 void context_cancel_run(llama_context * ctx, pi_run * run);              // stops a started run: unlaunched segments are dropped, kernels already enqueued return on entry (abort word)
 void urgent_drop_all(llama_context * ctx);                                  // the context gives up its claim on the device arbiter (destructor, priority change)
 bool context_wait(llama_context * ctx, pi_run * run);                    // blocks until the run's results are in host memory
+// device-side arrival flags of a stage boundary (transport.cpp, runtime.hip: k_flag_publish / k_abort_begin_wait).  in_flag: the run's activations have landed in x_in when it
+// carries in_ticket — the run is enqueued at once and waits for it ON THE DEVICE; out_flag: written behind the store of x_out with out_ticket (and the abort the run ended with)
+struct pi_stage_hop { const void * in_flag = nullptr; uint32_t in_ticket = 0; void * out_flag = nullptr; uint32_t out_ticket = 0; int64_t wait_timeout_us = 10 * 1000 * 1000; };
 int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
-               int (*should_abort)(void *) = nullptr, void * abort_user = nullptr);        // 0 done, 1 cut short by should_abort, < 0 error
+               int (*should_abort)(void *) = nullptr, void * abort_user = nullptr, const pi_stage_hop * hop = nullptr);        // 0 done, 1 cut short (should_abort, a cancel, or upstream), < 0 error
 void stage_abort_run(llama_context * ctx, int32_t run_id);                  // any thread: run `run_id` (ctx->stage_run_id while stage_run computes it) returns from every kernel on entry from now on; no effect on any other run
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

@@ -54,7 +54,8 @@ struct msg_hdr { int32_t kind, run_seq, batch_id, n_tokens, flags, gen, pad0, pa
 struct stage_block {                             // index = rank
     ring_ctl in;                                 // producer: rank - 1 (the head for rank 1); consumer: rank
     msg_hdr slots[TP_IN1_SLOTS];                 // ranks >= 2 use the first TP_X_SLOTS
-    std::atomic<uint32_t> ipc_ready, probe_written, joined, setup_done;
+    struct alignas(16) xflag_t { std::atomic<uint32_t> value; uint32_t pad; uint64_t stamp; } xflag[TP_X_SLOTS];      // arrival flags of this stage's activation slots (runtime.hip: pi_xflag)
+    std::atomic<uint32_t> ipc_ready, probe_written, joined, setup_done, flags_done;
     std::atomic<int32_t> device;                 // HIP device ordinal of the rank's process (-1: none)
     char ipc_handle[64];                         // hipIpcMemHandle_t
 };
@@ -64,6 +65,7 @@ struct shm_layout {
     uint64_t meta_stride, x_slot_bytes, res_slot_bytes, off_meta, off_x, off_res, total;
     std::atomic<int32_t> fatal;                  // any rank sets it: every wait gives up
     std::atomic<int32_t> device_fail;            // the peer-store path is unusable on this node: host rings for everybody
+    std::atomic<int32_t> flags_off;              // some rank cannot use device-side arrival flags: every rank publishes its headers from the host
     std::atomic<uint64_t> n_cancel;
     std::atomic<uint64_t> cancel[TP_CANCEL_CAP]; // (generation << 32) | batch id
     ring_ctl res;
@@ -86,6 +88,9 @@ struct pipeinfer_transport {
     float * peer_ring = nullptr;                 // device mode: the next stage's ring, mapped through hipIpc
     hipStream_t copy_stream = nullptr;
     bool res_registered = false;
+    // device-side arrival flags: the control block of the segment page-locked and mapped into this process's device address space
+    bool flags_on = false, ctl_registered = false; uint8_t * ctl_dev = nullptr;
+    void * flag_dev(int rank_of_consumer, uint64_t k) const { return ctl_dev + ((uint8_t *) &L->st[rank_of_consumer].xflag[k % TP_X_SLOTS] - base); }
     int peer_access = -1;                        // hipDeviceCanAccessPeer(this device, next stage's device); -1: not asked
     // head side
     int32_t gen = 0;
@@ -317,6 +322,20 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
     for (int r = 0; r < tp->world; r++)
         if (!tp->wait_for([&] { return L->st[r].setup_done.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never finished the transport set-up"); pipeinfer_transport_close(tp); return nullptr; }
     tp->device_mode = P->device >= 0 && !L->device_fail.load();
+    // Arrival flags (stage ranks, device mode; PIPEINFER_TRANSPORT_FLAGS=0: the host-published headers of round 3): the segment's control block is page-locked and mapped, so
+    // that the producing stage's stream can write a flag and the consuming stage's stream can poll it.  A rank that cannot map it says so and every rank uses the host path.
+    if (tp->device_mode && tp->rank >= 1 && !(getenv("PIPEINFER_TRANSPORT_FLAGS") && atoi(getenv("PIPEINFER_TRANSPORT_FLAGS")) == 0)) {
+        void * dp = nullptr;
+        if (hipSetDevice(P->device) == hipSuccess && hipHostRegister(tp->base, round_up(sizeof(shm_layout), 4096), hipHostRegisterMapped) == hipSuccess) {
+            tp->ctl_registered = true;
+            if (hipHostGetDevicePointer(&dp, tp->base, 0) == hipSuccess && dp) tp->ctl_dev = (uint8_t *) dp;
+        }
+        if (!tp->ctl_dev) { (void) hipGetLastError(); fprintf(stderr, "[pipeinfer transport, rank %d] the control block cannot be mapped for device access: headers are published by the host\n", tp->rank); L->flags_off.store(1); }
+    } else if (tp->rank >= 1) L->flags_off.store(1);
+    L->st[tp->rank].flags_done.store(1, std::memory_order_release);
+    for (int r = 1; r < tp->world; r++)
+        if (!tp->wait_for([&] { return L->st[r].flags_done.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never finished the flag set-up"); pipeinfer_transport_close(tp); return nullptr; }
+    tp->flags_on = tp->device_mode && tp->ctl_dev && !L->flags_off.load();
     if (P->device >= 0 && tp->rank == tp->world - 1) {                          // the last stage copies D2H straight into the result slots: pin them
         if (hipSetDevice(P->device) == hipSuccess && hipHostRegister(tp->base + L->off_res, L->res_slot_bytes * TP_RES_SLOTS, hipHostRegisterDefault) == hipSuccess) tp->res_registered = true;
         else (void) hipGetLastError();
@@ -327,6 +346,7 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
 extern "C" void pipeinfer_transport_close(pipeinfer_transport * tp) {
     if (!tp) return;
     if (tp->res_registered) (void) hipHostUnregister(tp->base + tp->L->off_res);
+    if (tp->ctl_registered) (void) hipHostUnregister(tp->base);
     if (tp->peer_ring) (void) hipIpcCloseMemHandle(tp->peer_ring);
     if (tp->my_ring) (void) hipFree(tp->my_ring);
     if (tp->copy_stream) (void) hipStreamDestroy(tp->copy_stream);
@@ -436,6 +456,13 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
         const size_t words = (size_t) (tp->n_ctx + 31) / 32, meta_bytes = (size_t) n * 8 + 16 + (size_t) n * words * 4;
         bool skipped = (m.flags & F_SKIPPED) != 0;
         if (!skipped && tp->is_cancelled(m.gen, m.batch_id)) skipped = true;    // the head cancelled it before this stage started on it
+        // Arrival flags (device mode): the header only ANNOUNCES a run — it is passed on at once, before this stage has computed anything, so that every stage behind has the
+        // run enqueued (behind a device-side wait for its activations) by the time they arrive; the activations' arrival is the flag this stage's stream writes behind its
+        // peer store.  A header that says "skipped" still means what it meant: nobody computes it, no flag is written or waited for.  What a header cannot say any more is
+        // that a run was cut short DURING its computation: that travels in the flag's abort bit, from stream to stream.
+        const bool flags = tp->flags_on && ctx && !backend;
+        bool announced = false;
+        if (flags && !is_last) { m.flags = skipped ? F_SKIPPED : 0; publish(m, oh, nullptr); announced = true; }
         if (!skipped) {
             const float * x_in = is_first ? nullptr : (dev ? (const float *) ((uint8_t *) tp->my_ring + (t % TP_X_SLOTS) * xb) : tp->host_x_slot(r, t));
             float * xo = is_last ? nullptr : (dev ? (float *) ((uint8_t *) tp->peer_ring + (oh % TP_X_SLOTS) * xb) : tp->host_x_slot(r + 1, oh));
@@ -444,21 +471,34 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
             t0 = now_us();
             int rc;
             const double hop0 = ctx ? ctx->stat_hop_ms : 0.0;
+            pi::pi_stage_hop hop;
+            if (flags) {
+                if (!is_first) { hop.in_flag = tp->flag_dev(r, t); hop.in_ticket = (uint32_t) (t + 1); }
+                if (!is_last) { hop.out_flag = tp->flag_dev(r + 1, oh); hop.out_ticket = (uint32_t) (oh + 1); }
+                hop.wait_timeout_us = (int64_t) tp->timeout_ms * 1000;
+            }
             if (backend) rc = backend->run(backend->user, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr);
-            else rc = pi::stage_run(ctx, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr, abort_probe, tp);
+            else rc = pi::stage_run(ctx, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr, abort_probe, tp,
+                                    flags ? &hop : nullptr);
             st.compute_ms += (now_us() - t0) / 1e3;
             if (ctx) st.hop_gpu_ms += ctx->stat_hop_ms - hop0;
             watch_key.store(~0ull, std::memory_order_release);
             tp->cur_key = ~0ull;
-            if (rc < 0) { tp->fail(std::string("stage run failed: ") + (ctx ? pipeinfer_context_error(ctx) : "backend error")); rc_all = -1; break; }
+            if (rc < 0) {
+                // (the stage behind may be waiting on the device for this run's flag: release it, marked aborted)
+                if (announced) { L->st[r + 1].xflag[oh % TP_X_SLOTS].stamp = 0; L->st[r + 1].xflag[oh % TP_X_SLOTS].value.store((((uint32_t) (oh + 1) & 0x7fffffffu) << 1) | 1u, std::memory_order_release); }
+                tp->fail(std::string("stage run failed: ") + (ctx ? pipeinfer_context_error(ctx) : "backend error")); rc_all = -1; break;
+            }
             if (rc == 1) { skipped = true; st.cut_short++; }
             else st.runs++;
         }
         if (skipped) st.skipped++;
         t0 = now_us();
         in.tail.store(t + 1, std::memory_order_release);                        // the incoming activation slot is free again
-        m.flags = skipped ? F_SKIPPED : 0;
-        publish(m, oh, rs);                                                     // what the header announces has landed: stage_run returns with its stream idle
+        if (!announced) {
+            m.flags = skipped ? F_SKIPPED : 0;
+            publish(m, oh, rs);                                                 // what the header announces has landed: stage_run returns with its stream idle
+        }
         st.send_ms += (now_us() - t0) / 1e3;
     }
     if (rc_all != 0 && !is_last) {                                              // tell the stages behind this one: nothing else will come
@@ -470,6 +510,8 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
     if (watcher.joinable()) watcher.join();
     if (x_registered) (void) hipHostUnregister(tp->base + L->off_x);
     st.cancel_notes = tp->cancel_cursor;
+    st.device_flags = tp->flags_on && ctx && !backend ? 1 : 0;
+    if (ctx) { st.flag_runs = ctx->stat_flag_runs; st.flag_wait_gpu_ms = ctx->stat_flag_wait_ms; st.flag_seen_us = ctx->stat_flag_seen_us; }
     if (out) *out = st;
     return rc_all;
 }

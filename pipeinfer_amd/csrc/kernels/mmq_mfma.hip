@@ -827,12 +827,13 @@ static bool mmq_g2_wants(int type, const mmvq_args & g, int nseg, int groups) {
     // launches that were one round already gain little: 28672 x 8192 39.0 / 37.1 / 37.7 -> 38.4 / 37.1 / 36.8, 32768 x 8192 41.4 / 39.4 / 39.9 -> 39.9 / 38.3 / 38.4,
     // 22016 x 4096 22.4 / 21.8 / 21.9 -> 21.5 / 21.3 / 21.2
     static const int min_groups = getenv("PI_MMQ_G2_MIN") ? atoi(getenv("PI_MMQ_G2_MIN")) : 1153;
-    if (!on || type != PI_Q4_K || g.nt > 8 || groups < min_groups || groups > 8 * 2 * 256) return false;
+    if (!on || type != PI_Q4_K || g.nt > 8 || (int64_t) groups * 256 < (int64_t) min_groups * pi_cu_count() || groups > 8 * 2 * pi_cu_count()) return false;
     for (int i = 0; i < nseg; i++) if (g.seg[i].store) return false;
     return true;
 }
 static void mmq_g2_dispatch(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    const int rr = (groups + 511) / 512;                       // waves per workgroup that put the launch into one round of 256 workgroups
+    const int ncu = pi_cu_count();
+    const int rr = (groups + 2 * ncu - 1) / (2 * ncu);          // waves per workgroup that put the launch into one round of one workgroup per available CU (256 without a CU mask)
     switch (rr < 4 ? 4 : rr) {
         case 4: mmq_g2_go<4>(g, groups, stream, ea, eb); break;
         case 5: mmq_g2_go<5>(g, groups, stream, ea, eb); break;
@@ -874,6 +875,9 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
     // 8 waves that share the staged activations, while keeping >= 256 workgroups.  PI_MMQ_CFG=SR overrides (tuning), e.g. 42.
     static const int cfg_env = getenv("PI_MMQ_CFG") ? atoi(getenv("PI_MMQ_CFG")) : 0;
     int cfg;
+    // (the bounds below were measured on the whole chip; a context confined to fewer CUs scales them: what matters is row groups per available CU)
+    const int groups_chip = groups;
+    groups = (int) ((int64_t) groups * 256 / pi_cu_count());
     if (groups > 1152) cfg = groups <= 7 * 256 ? 17 : 18;            // (measured crossover against S = 2: 1024 row groups 32.5 vs 34.0 us, 1280: 42.3 vs 36.3, 1376 at K = 4096: 25.5 vs 22.3)           // S = 1: the fewest row groups per workgroup (7 or 8) that still fit the launch into one round of 256 workgroups
     else if (groups > 768) cfg = 24;
     else if (groups > 512) cfg = 43;                                    // 513..768 row groups: three per workgroup keep the launch in ONE round of <= 256 workgroups (two per workgroup: 288-384
@@ -881,6 +885,7 @@ int pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, 
     else if (groups >= 384) cfg = 42;
     else cfg = 41;
     if (cfg_env) cfg = cfg_env;
+    groups = groups_chip;
     if (!cfg_env && mmq_g2_wants(type, g, L.nseg, groups)) { mmq_g2_dispatch(g, groups, stream, ea, eb); PI_CHECK_LAUNCH(); return 0; }
     mmq_dispatch(type, g, groups, cfg, stream, ea, eb);
     PI_CHECK_LAUNCH();

@@ -108,10 +108,55 @@ extern "C" int pi_stream_sync(void * stream) { PI_CHECK_HIP(hipStreamSynchronize
 static thread_local const int32_t * g_abort_word = nullptr;
 const int32_t * pi_abort_word() { return g_abort_word; }
 extern "C" void pi_set_abort_word(const int32_t * word_dev) { g_abort_word = word_dev; }
+static thread_local int g_cu_count = 256;
+int pi_cu_count() { return g_cu_count; }
+extern "C" void pi_set_cu_count(int n) { g_cu_count = n > 0 && n <= 256 ? n : 256; }
 // device-scope atomics only: the exchange at a run's start and the compare-and-swap of a cancel never tear, whichever stream runs first
 __global__ void k_abort_begin(int32_t * word, int32_t run_id, const int32_t * host_flag) {
     const int32_t f = host_flag ? __hip_atomic_load(host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
-    __hip_atomic_exchange(word, (run_id << 1) | (f != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a later segment of the SAME run keeps an abort the word already carries: one inherited from the upstream stage has no host flag behind it)
+    const int32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t keep = (old >> 1) == run_id ? (old & 1) : 0;
+    __hip_atomic_exchange(word, (run_id << 1) | (f != 0) | keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ---- arrival flags of the stage transport (transport.cpp): the activations of a run cross a stage boundary with no host thread on the critical path.
+// A flag lives in page-locked host memory that both processes map: {ticket << 1 | aborted, -, realtime stamp}.  The producing stage's stream writes it right behind its peer
+// store (k_flag_publish); the consuming stage has enqueued its run already, behind k_abort_begin_wait, which polls the flag from the device and arms the run's abort word —
+// with the abort the producer's run ended with, if any, so that a run cut short upstream costs nothing downstream either.  The poll is bounded (a dead producer must not
+// hang the consumer's GPU): on time-out the run is marked aborted and *timeout_flag is raised.
+struct pi_xflag { uint32_t value, pad; unsigned long long stamp; };
+__global__ void k_flag_publish(pi_xflag * flag, uint32_t ticket, const int32_t * abort_word, int force_abort) {
+    const int32_t w = abort_word ? __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    flag->stamp = __builtin_amdgcn_s_memrealtime();
+    __hip_atomic_store(&flag->value, (ticket << 1) | (uint32_t) ((w & 1) | (force_abort != 0)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_abort_begin_wait(int32_t * word, int32_t run_id, const int32_t * host_flag, const pi_xflag * flag, uint32_t ticket, unsigned long long limit_ticks,
+                                   int32_t * timeout_flag, unsigned long long * hop_ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t v = 0; bool timed_out = false;
+    while (true) {
+        v = __hip_atomic_load(&flag->value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((v >> 1) == ticket) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) { timed_out = true; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (timed_out) { if (timeout_flag) *timeout_flag = 1; v = 1; }
+    else if (hop_ticks) { hop_ticks[0] += t1 - flag->stamp; hop_ticks[1] += t1 - t0; hop_ticks[2] += 1; }     // flag written -> seen (one clock: stages on one device); time spent waiting; runs
+    const int32_t f = host_flag ? __hip_atomic_load(host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+    __hip_atomic_exchange(word, (run_id << 1) | (f != 0) | (int32_t) (v & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" int pi_op_flag_publish(void * flag_dev, uint32_t ticket, const int32_t * abort_word_dev, int force_abort, void * stream) {
+    hipLaunchKernelGGL(k_flag_publish, dim3(1), dim3(1), 0, (hipStream_t) stream, (pi_xflag *) flag_dev, ticket & 0x7fffffffu, abort_word_dev, force_abort);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pi_op_abort_begin_wait(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, const void * flag_dev, uint32_t ticket, int64_t timeout_us,
+                                      int32_t * timeout_flag_dev, uint64_t * hop_ticks_dev, void * stream) {
+    hipLaunchKernelGGL(k_abort_begin_wait, dim3(1), dim3(1), 0, (hipStream_t) stream, word_dev, run_id & 0x3fffffff, host_flag, (const pi_xflag *) flag_dev, ticket & 0x7fffffffu,
+                       (unsigned long long) timeout_us * 100ull, timeout_flag_dev, (unsigned long long *) hop_ticks_dev);
+    PI_CHECK_LAUNCH();
+    return 0;
 }
 __global__ void k_abort_cancel(int32_t * word, int32_t run_id) {
     int32_t expect = run_id << 1;

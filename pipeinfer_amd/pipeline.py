@@ -50,7 +50,8 @@ class TransportParams(C.Structure):
 class TransportStats(C.Structure):
     _fields_ = [("runs", C.c_uint64), ("skipped", C.c_uint64), ("cut_short", C.c_uint64), ("cancel_notes", C.c_uint64),
                 ("wait_in_ms", C.c_double), ("compute_ms", C.c_double), ("send_ms", C.c_double),
-                ("received", C.c_uint64), ("wait_out_ms", C.c_double), ("hop_gpu_ms", C.c_double), ("peer_access", C.c_int32)]
+                ("received", C.c_uint64), ("wait_out_ms", C.c_double), ("hop_gpu_ms", C.c_double), ("peer_access", C.c_int32), ("device_flags", C.c_int32),
+                ("flag_runs", C.c_uint64), ("flag_wait_gpu_ms", C.c_double), ("flag_seen_us", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -313,7 +314,8 @@ def bench_main(args, rank, world):
     if rank != 0:
         st = tp.serve(ctx=backend.ctx)
         stats = backend.stats()
-        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"] + st["hop_gpu_ms"], float(st["runs"]), st["wait_out_ms"], float(st["peer_access"])], dtype=torch.float64)    # single-token calls
+        t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"] + st["hop_gpu_ms"], float(st["runs"]), st["wait_out_ms"], float(st["peer_access"]),
+                          float(st["device_flags"]), float(st["flag_runs"]), st["flag_wait_gpu_ms"], st["flag_seen_us"]], dtype=torch.float64)    # single-token calls
         dist.gather(t, None, dst=0)
         dist.barrier()
         tp.close()
@@ -351,8 +353,8 @@ def bench_main(args, rank, world):
     tp.shutdown()
     tp_device_mode = tp.device_mode
     head_stats = tp.stats()
-    gathered = [torch.zeros(11, dtype=torch.float64) for _ in range(world)]
-    dist.gather(torch.zeros(11, dtype=torch.float64), gathered, dst=0)
+    gathered = [torch.zeros(15, dtype=torch.float64) for _ in range(world)]
+    dist.gather(torch.zeros(15, dtype=torch.float64), gathered, dst=0)
     dist.barrier()
     tp.close()
     if not os.environ.get("PIPEINFER_KEEP_STAGE_FILES"):
@@ -368,11 +370,16 @@ def bench_main(args, rank, world):
                     "GBps": round(float(gathered[r][2]) / max(1e-9, float(gathered[r][0]) * 1e-3) / 1e9, 1),
                     "runs_skipped": int(gathered[r][3]), "runs_cut_short": int(gathered[r][4]), "wait_for_input_ms": round(float(gathered[r][5]), 1),
                     "compute_ms": round(float(gathered[r][6]), 1), "hop_ms": round(float(gathered[r][7]), 3), "runs": int(gathered[r][8]),     # hop: GPU time of the in-stream store into the next stage's ring (last stage: logits into the result slot) + host time to publish the header
-                    "wait_for_slot_ms": round(float(gathered[r][9]), 1), "peer_access": int(gathered[r][10])} for r in range(1, world)]
+                    "wait_for_slot_ms": round(float(gathered[r][9]), 1), "peer_access": int(gathered[r][10]),
+                    # device-side arrival flags: runs are announced early and enqueued behind a device wait; flag_seen_us = flag stamped by the producing stream -> seen by
+                    # the waiting kernel (one device clock: meaningful between stages that share a device), wait_for_input_gpu_ms = GPU time spent waiting for input
+                    "device_flags": bool(gathered[r][11]), "flag_runs": int(gathered[r][12]), "wait_for_input_gpu_ms": round(float(gathered[r][13]), 1),
+                    "flag_seen_us_per_run": round(float(gathered[r][14]) / max(1.0, float(gathered[r][12])), 2) if gathered[r][12] > 0 else None} for r in range(1, world)]
     slow = max(stage_stats, key=lambda s: s["gpu_ms_per_call"])
     # dominant kernel = the single-token Q4_K mat-vec of every stage; its HBM traffic comes from the committed single-GPU PMC pass of the same
     # kernel sources (the per-launch traffic of a mat-vec does not depend on which stage launches it)
-    traffic, traffic_src = B.committed_traffic(args.workload, "Q4_K_nt1")
+    tr, traffic_src = B.committed_traffic(args.workload, "matvec_nt1")
+    traffic = tr["avg_fetch_bytes_per_launch"] if tr else None
     sched = {0: "PipeInfer (asynchronous continuous speculation, examples/speculative)", 1: "synchronous tree speculation (examples/speculative_orig)", 2: "target only"}[args.mode]
     out = {"metric": B.METRIC if args.workload == "70b" else f"accepted tokens/sec + acceptance rate, {tspec} {tft} target / {dspec} draft", "value": main_sum["tokens_per_s"], "unit": "tokens/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_total / args.steps, 2), "higher_is_better": True,
@@ -381,6 +388,11 @@ def bench_main(args, rank, world):
            "transport": "peer" if tp_device_mode else "host", "devices_shared": bool(shared_gpu),
            "hop_ms": {str(s_["rank"]): s_["hop_ms"] for s_ in stage_stats}, "hop_us_per_run": {str(s_["rank"]): round(1e3 * s_["hop_ms"] / max(1, s_["runs"]), 2) for s_ in stage_stats},
            "wait_for_input_ms": {str(s_["rank"]): s_["wait_for_input_ms"] for s_ in stage_stats},
+           # how a run crosses a stage boundary: "device flag" = announced early, the consuming stage's run is already enqueued behind a device-side wait when the producing
+           # stream writes the arrival flag behind its peer store (no host thread in between); "host header" = the header is published by the host after the run
+           "hop": "device flag" if all(s_["device_flags"] for s_ in stage_stats) else "host header",
+           "flag_seen_us_per_run": {str(s_["rank"]): s_["flag_seen_us_per_run"] for s_ in stage_stats},
+           "wait_for_input_gpu_ms": {str(s_["rank"]): s_["wait_for_input_gpu_ms"] for s_ in stage_stats},
            "config": {"workload": f"{tspec} {tft} target layer-split over {n_stage} GPU(s) + {dspec} {dft} draft on GPU0", "schedule": sched,
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel, "p_accept": args.p_accept,
                       "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "layer_ranges": [list(r) for r in ranges],

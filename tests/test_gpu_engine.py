@@ -331,6 +331,8 @@ def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
 
 @pytest.mark.parametrize("tgt,dft,seed,ranges,host_rings", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", False), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 11, "0-1,1-2", False),
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", True),
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "host-headers"),   # peer stores, headers published by the host (round 3's hop)
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-2,2-3", False),       # three stages: a middle stage waits AND publishes
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-3", False)])     # --gpus 2: one stage that is first and last
 def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt, dft, seed, ranges, host_rings):
     """head + two HIP stages as three processes on this one GPU (tests/transport_gpu_worker.py): run headers, metadata, results and cancel
@@ -346,8 +348,12 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranges.count(',') + 2}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "transport_gpu_worker.py"), str(out), tgt, dft, str(seed), ranges]
     env = dict(os.environ, PYTHONPATH=root, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    host_headers = host_rings == "host-headers"
+    host_rings = host_rings is True
     if host_rings:
         env["PIPEINFER_TRANSPORT_HOST"] = "1"
+    if host_headers:
+        env["PIPEINFER_TRANSPORT_FLAGS"] = "0"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     v = json.loads(out.read_text())
@@ -370,6 +376,16 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
         print(f"stage {s['rank']}: store of the activations / logits {hop_gpu_us:.1f} us of GPU time per run, header published {hop_host_us:.1f} us after the run; waited {s['wait_out_ms']:.2f} ms in all for a free slot downstream")
         if not host_rings:
             assert hop_gpu_us < 50.0 and hop_host_us < 50.0, s
+    # device-side arrival flags (the default in device mode): every run is announced downstream before it is computed and the consuming stage's run is enqueued behind a
+    # device-side wait; the flag written by the producing stage's STREAM (behind its peer store) is seen by the waiting kernel within microseconds — no host thread on the
+    # critical path of a stage boundary (the reference: blocking MPI_Recv, ggml-mpi.c:451-487)
+    for s in v["stages"]:
+        assert bool(s["device_flags"]) == (not host_rings and not host_headers), s
+        if s["device_flags"] and s["rank"] >= 2:
+            assert s["flag_runs"] > 0, s
+            seen_us = s["flag_seen_us"] / s["flag_runs"]
+            print(f"stage {s['rank']}: arrival flag seen {seen_us:.2f} us after the producing stream stamped it (mean of {s['flag_runs']} runs); {s['flag_wait_gpu_ms']:.1f} ms of GPU time waiting for input")
+            assert seen_us < 15.0, s
 
 
 @pytest.mark.parametrize("tgt,dft,n_layer", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 3), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 2), ("tiny_falcon40_q4_k_m", "tiny_falcon_q4_0", 2),
