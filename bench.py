@@ -349,6 +349,9 @@ def main():
     draft_cus = int(os.environ.get("PIPEINFER_DRAFT_CUS", "0"))
     if draft_cus > 0:                                  # disjoint CU masks: the draft's stream on the first `draft_cus` compute units, the target's on the rest
         cd.set_cu_range(0, draft_cus); ct.set_cu_range(draft_cus, 256)
+    target_cu_lo = int(os.environ.get("PIPEINFER_TARGET_CU_LO", "0"))
+    if target_cu_lo > 0 and not draft_cus:             # only the TARGET is confined (to CUs [lo, 256)): the draft's kernels may start at once on the CUs it leaves free and use the others as they free up
+        ct.set_cu_range(target_cu_lo, 256)
     # one GPU: the target's stage graphs are launched segment by segment by a feeder thread, so that a cancelled speculative run stops at the
     # next segment boundary and the (high-priority) draft is served between segments instead of behind whole target runs
     # Segment size = how often the draft gets the GPU (between segments the feeder lets the priority context go first) and how much of a run is enqueued ahead of the GPU.

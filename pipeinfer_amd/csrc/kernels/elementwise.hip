@@ -5,6 +5,7 @@
 #include "kernel_timing.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 // =================================================================================================================
@@ -337,6 +338,68 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
     }
 }
 
+// The same operator as SEVERAL workgroups per token row (Q8_K, rows of whole 1024-value strips): workgroup g of a row holds, like every other workgroup of the row, the whole row in
+// registers (float4 number tid + 256 i, i < n / 1024: the row is 8-32 KB, read from L2 by all of them), computes the row's statistic itself — every workgroup the same sums in the
+// same order, hence the same scale — and quantises only ITS four 256-value chunks (wave w: chunk w + 4 g, whose values are its i = g loads).  One four-wave barrier instead of two
+// sixteen-wave ones, one chunk per wave instead of two, and the stores of a row spread over n / 1024 CUs: the kernel is a chain of latencies (launch, one round trip for x, the
+// reduction, the quantiser's butterflies, the store drain), and this shortens the last three.  The double sums run in another order than k_norm_quant's (and than the
+// reference's sequential loop, ggml.c:9028-9074): like there, that moves the fp32 scale by at most an ulp in rare cases (the one tolerance of the contract).
+__global__ void __launch_bounds__(256) k_norm_quant_mw(const float * __restrict__ x, const float * __restrict__ w, const float * __restrict__ b, float * __restrict__ yf,
+                                                       int n, float eps, int rms, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
+    __shared__ double sh[4];
+    constexpr int NLMAX = 16;
+    const int t = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = n >> 10;
+    const float * xr = x + (int64_t) t * n;
+    float4 xv[NLMAX];
+#pragma unroll
+    for (int i = 0; i < NLMAX; i++) xv[i] = i < nl ? *(const float4 *) (xr + ((int64_t) tid + 256 * i) * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int64_t e0 = ((int64_t) tid + 256 * g) * 4;                                       // this thread's own four values: chunk wave + 4 g, lane's quad
+    const float4 wv = w ? *(const float4 *) (w + e0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    const float4 bv = b ? *(const float4 *) (b + e0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int aborted = pi_abort_peek(abort_w);                                             // (behind the kernel's own loads, looked at in front of the stores: see k_norm_quant)
+    auto block_sum = [&](double v) {
+        v = pi_wave_sum_f64(v);
+        __syncthreads();
+        if (lane == 0) sh[wave] = v;
+        __syncthreads();
+        return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    };
+    float mean = 0.0f;
+    double acc = 0.0;
+    if (rms) {
+#pragma unroll
+        for (int i = 0; i < NLMAX; i++) if (i < nl) { const float4 v = xv[i]; acc += (double) (v.x * v.x); acc += (double) (v.y * v.y); acc += (double) (v.z * v.z); acc += (double) (v.w * v.w); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NLMAX; i++) if (i < nl) { const float4 v = xv[i]; acc += (double) v.x; acc += (double) v.y; acc += (double) v.z; acc += (double) v.w; }
+        mean = (float) (block_sum(acc) / n);
+        acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < NLMAX; i++) if (i < nl) {
+            const float4 v = xv[i];
+            const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+            acc += (double) (a0 * a0); acc += (double) (a1 * a1); acc += (double) (a2 * a2); acc += (double) (a3 * a3);
+        }
+    }
+    const float var = (float) (block_sum(acc) / n);
+    const float scale = 1.0f / sqrtf(var + eps);
+    if (aborted & 1) return;
+    float4 v = xv[0];
+#pragma unroll
+    for (int i = 1; i < NLMAX; i++) if (g == i) v = xv[i];                                  // (compile-time register indices: a dynamic one would spill)
+    const float xs[4] = { v.x, v.y, v.z, v.w }, ww[4] = { wv.x, wv.y, wv.z, wv.w }, bb[4] = { bv.x, bv.y, bv.z, bv.w };
+    float ys[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float y = (xs[i] - mean) * scale;
+        if (w) y = y * ww[i];
+        if (b) y = y + bb[i];
+        ys[i] = y;
+    }
+    if (yf) *(float4 *) (yf + (int64_t) t * n + e0) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+    wave_quantize_q8_K(ys, lane, t, (int64_t) wave + 4 * g, n >> 8, (int8_t *) qs, (float *) dd, bsums, F);
+}
+
 // where the quantisers put the MFMA operand planes of a Q8_K buffer (null for single-token calls and for Q8_0)
 static q8k_frags frags_of(int vdt, int64_t k, int n_tok, uint8_t * base) {
     q8k_frags F = { nullptr, nullptr, nullptr };
@@ -356,6 +419,15 @@ extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float
     const int64_t ng = (n / 32 + 3) / 4;
     const int chunks = (int) ((vdt == PI_Q8_K ? n : ng * 128) + 255) / 256;
     const int threads = 64 * (chunks < 16 ? chunks : 16);
+    // rows of whole 1024-value strips: n / 1024 four-wave workgroups per row (PI_NORMQ_MW=0: the one-workgroup kernel everywhere)
+    static const bool mw_on = !(getenv("PI_NORMQ_MW") && atoi(getenv("PI_NORMQ_MW")) == 0);
+    if (mw_on && vdt == PI_Q8_K && n % 1024 == 0 && n / 1024 <= 16) {
+        const double qb = (double) n / 256 * 292;
+        PI_KT_LAUNCH(PI_KT_NORMQ, 0, n_tok, (double) n_tok * (4.0 * n + qb + (y_f32 ? 4.0 * n : 0.0)) + 4.0 * n * ((w ? 1 : 0) + (b ? 1 : 0)), k_norm_quant_mw, dim3((unsigned) (n / 1024), n_tok), dim3(256), 0, (hipStream_t) stream,
+                     x, w, b, y_f32, n, eps, rms, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());
+        PI_CHECK_LAUNCH();
+        return 0;
+    }
     // algorithmic bytes: the row in (fp32), weight (+ bias), the quantised planes out (Q8_K: 292 B per 256 values; 32-blocks: 34 / 40 B per 32)
     const double qb = vdt == PI_Q8_K ? (double) n / 256 * 292 : (double) n / 32 * (vdt == PI_Q8_1 ? 40 : 34);
     PI_KT_LAUNCH(PI_KT_NORMQ, 0, n_tok, (double) n_tok * (4.0 * n + qb + (y_f32 ? 4.0 * n : 0.0)) + 4.0 * n * ((w ? 1 : 0) + (b ? 1 : 0)), k_norm_quant, dim3(n_tok), dim3(threads), 0, (hipStream_t) stream, x, w, b, y_f32, n, eps, rms, vdt, ng, base + oq, base + od, (int16_t *) (base + ob), frags_of(vdt, n, n_tok, base), pi_abort_word());

@@ -138,7 +138,7 @@ __global__ void k_abort_begin_wait(int32_t * word, int32_t run_id, const int32_t
         v = __hip_atomic_load(&flag->value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((v >> 1) == ticket) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) { timed_out = true; break; }
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(4);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     if (timed_out) { if (timeout_flag) *timeout_flag = 1; v = 1; }

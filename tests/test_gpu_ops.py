@@ -487,6 +487,59 @@ def test_mul_mat_multi_equals_single_launches(gpu, wtype, n_tok):
         lib.pi_weight_free(w)
 
 
+@pytest.mark.parametrize("k,rows,n_tok", [(512, 20000, 5),       # 1 250 row groups (the smallest launches that take it), 2 blocks: one tile
+                                          (768, 40008, 7),       # 2 501 row groups (odd: the last wave's second row group does not exist), 3 blocks: a last tile with one block
+                                          (256, 65536, 4),       # 4 096 row groups = the most a launch of eight-wave workgroups takes; one block
+                                          (256, 65552, 8),       # ... one more falls back to k_mmq_kq
+                                          (1280, 18450, 3),      # 1 154 row groups, the last with 2 rows; 5 blocks
+                                          (8192, 18464, 6),      # 70B row length (32 blocks: six trips of the unrolled tile loop)
+                                          (2816, 24000, 8)])     # 11 blocks (odd)
+def test_mmq_two_row_groups_per_wave_vs_oracle(gpu, k, rows, n_tok):
+    """k_mmq_g2 (mmq_mfma.hip): Q4_K launches of > 1152 row groups at 3..8 tokens — two row groups per wave, packed accumulators (accumulator lanes k and k + 4 share an MFMA
+    tile through zero token rows), hand-counted weight ring, fold in registers — give the oracle's (= the reference's, ggml-quants.c:5318-5381) fp32 bits"""
+    from pipeinfer_amd.tools import synth
+    lib, U = gpu
+    rng = np.random.default_rng(k + rows + n_tok)
+    blocks = synth.random_blocks(O.Q4_K, rows * k, rng, 0.05).reshape(rows, -1)
+    act = (rng.standard_normal((n_tok, k)) * rng.uniform(0.2, 3.0, (n_tok, 1))).astype(np.float32)
+    res = rng.standard_normal((n_tok, rows)).astype(np.float32)
+    w = upload_weight(lib, O.Q4_K, rows, k, blocks)
+    want = O.Impl("oracle").mul_mat(O.Q4_K, blocks, k, rows, act)
+    got = gpu_mul_mat(lib, U, O.Q4_K, w, k, rows, act)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), float(np.abs(got - want).max())
+    got = gpu_mul_mat(lib, U, O.Q4_K, w, k, rows, act, residual=res)                                    # ffn_down-style launch: residual + product (one fp32 add)
+    assert np.array_equal(got.view(np.uint32), (res + want).view(np.uint32))
+    lib.pi_weight_free(w)
+
+
+@pytest.mark.parametrize("n_tok", [3, 6, 8])
+def test_mmq_two_row_groups_per_wave_fused_up_gate(gpu, n_tok):
+    """the launch the kernel was built for: ffn_up and ffn_gate of a layer as ONE launch (pi_op_mul_mat_multi, two segments; a row group never straddles them) — each
+    segment's output equals its own single launch and the oracle"""
+    import ctypes as C
+    from pipeinfer_amd import lib as L
+    from pipeinfer_amd.tools import synth
+    lib, U = gpu
+    rng = np.random.default_rng(900 + n_tok)
+    k, ms = 1024, [14336, 14344]                                                                         # 896 + 897 row groups (the second segment ends in a half group)
+    ws, bl = [], []
+    for m in ms:
+        b = synth.random_blocks(O.Q4_K, m * k, rng, 0.05).reshape(m, -1)
+        bl.append(b); ws.append(upload_weight(lib, O.Q4_K, m, k, b))
+    act = rng.standard_normal((n_tok, k)).astype(np.float32)
+    q8 = gpu_quantize(lib, U, O.Q8_K, act)
+    outs = [U.Dev(nbytes=4 * n_tok * m) for m in ms]
+    warr = (C.c_void_p * 2)(*ws); oarr = (C.c_void_p * 2)(*[o.ptr for o in outs])
+    L.check(lib.pi_op_mul_mat_multi(2, warr, q8.ptr, n_tok, oarr, None, None))
+    lib.pi_device_sync()
+    for m, b, o in zip(ms, bl, outs):
+        want = O.Impl("oracle").mul_mat(O.Q4_K, b, k, m, act)
+        got = o.get(np.float32, (n_tok, m))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (m, float(np.abs(got - want).max()))
+    for w in ws:
+        lib.pi_weight_free(w)
+
+
 @pytest.mark.parametrize("types", [(O.Q4_K, O.Q4_K, O.Q4_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q5_K, O.Q6_K, O.Q4_K)])
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_tok,kv_head", [(128, 8, 8, 1, 5), (64, 8, 2, 3, 0), (128, 4, 1, 8, 17), (64, 4, 4, 11, 2),
                                                                (128, 64, 8, 1, 3), (128, 64, 8, 2, 9), (128, 64, 8, 4, 1), (128, 40, 40, 1, 0),    # K = 8192 / 5120: the tile-per-wave instance with the RoPE epilogue
