@@ -212,6 +212,12 @@ def timing_rows(lib):
     return _rows(buf, lib.pi_kernel_timing_rows(buf, 4096))
 
 
+def lifetime_rows(lib):
+    """every eager launch of this process so far (counts and algorithmic bytes): under PI_NO_GRAPHS=1 that is every launch — the population a rocprofv3 --pmc pass of the process sees"""
+    buf = (KtRow * 4096)()
+    return _rows(buf, lib.pi_kernel_lifetime_rows(buf, 4096))
+
+
 def launch_rows(lib, ctx):
     """launches of a context's captured graphs since its reset_stats(): graph contents x replays (counts and algorithmic bytes; no durations)"""
     lib.pipeinfer_get_launch_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -455,6 +461,14 @@ def main():
         tr, _ = committed_traffic(args.workload, name)
         f["traffic_fetch_over_alg"] = tr["fetch_over_alg"] if tr else None
     roofline["draft_launches"] = sum(r["launches"] for r in draft_counts)
+    if os.environ.get("PI_NO_GRAPHS"):
+        # profiled runs launch everything eagerly: the launch accounting of the WHOLE process (both contexts, every generation of this run), per family — what
+        # tools_dev/pmc_to_json.py divides the counters' bytes by (same launches, same population)
+        life = {}
+        for r in lifetime_rows(lib):
+            f = life.setdefault(family_of(r), {"launches": 0, "alg_bytes": 0.0})
+            f["launches"] += r["launches"]; f["alg_bytes"] += r["bytes_total"]
+        roofline["process_eager_launches"] = {k: {"launches": v["launches"], "alg_bytes_per_launch": round(v["alg_bytes"] / max(1, v["launches"]))} for k, v in life.items()}
     roofline["per_instance"] = table
     # whole decode calls of the timed steps (prompt batches excluded): GPU time between the call's first and last event
     roofline["target_decode_call"] = {"calls": st_t["n_calls_1"], "gpu_ms_per_call": round(st_t["gpu_ms_1"] / max(1, st_t["n_calls_1"]), 4),

@@ -74,6 +74,7 @@ struct pi_kt_row { int32_t family, type, n_tok, pad_; uint64_t shape_bytes; /* m
                    uint64_t launches; double bytes_total; uint64_t sampled; double avg_us, avg_sampled_bytes; };
 PI_API void    pi_kernel_timing(int on, int sample_every);
 PI_API int     pi_kernel_timing_rows(struct pi_kt_row * out, int cap);
+PI_API int     pi_kernel_lifetime_rows(struct pi_kt_row * out, int cap);   /* every eager launch since the process started (counts and bytes, never reset): what a PMC pass of the process sees */
 
 /* host_blocks: ne1 rows of ne0 elements in the GGUF/ggml block format of `type` (row-major, rows contiguous) */
 PI_API pi_weight * pi_weight_upload(int type, int64_t ne0, int64_t ne1, const void * host_blocks, void * stream);

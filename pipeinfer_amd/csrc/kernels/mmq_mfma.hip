@@ -57,11 +57,12 @@ int pi_mmq_max_nt() {
 }
 bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
-// accumulator lane and only wins from 5 tokens (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
+// accumulator lane and only won from 5 tokens in round 2 (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
 // and on short matrices (attn_v of a GQA model: 64 row groups) only past the VALU kernel's 8 tokens per pass
 bool pi_mmq_wants(int type, int n_tok, int64_t rows) {
     if (!pi_mmq_supported(type) || n_tok < pi_mmq_min_nt()) return false;
-    if (type == PI_Q6_K) return n_tok >= 5 && (rows >= 4096 || n_tok > 8);
+    // (round 4: from 4 tokens on matrices of >= 4096 rows — in the bench the VALU kernel took 72.3 us for the 193 MB ffn_down at 4 tokens, the matrix cores take 65.7)
+    if (type == PI_Q6_K) return n_tok >= 4 && (rows >= 4096 || n_tok > 8);
     // short launches: a row group walks its K / 256 blocks one after the other (13.4 us at K = 8192 however few rows there are), while the VALU kernel's
     // tile-per-wave instances put every tile of a short matrix in flight at once.  Measured (us, 3 / 4 / 8 tokens, matrix cores vs VALU): 1024 x 8192 Q5_K (attn_v of
     // a GQA model) 14.5 / 14.5 / 14.5 vs 6.4 / 7.0 / 9.9; 2048 x 8192 13.7 / 13.5 / 13.6 vs 8.5 / 10.4 / 14.9; 4096 x 8192 14.4 / 14.1 / 13.9 vs 12.0 / 13.6 / 21.3;
@@ -792,13 +793,14 @@ template <int TYPE, int S, int R, int TB16, int TB8>
 static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     if (g.nt <= 8) mmq_go2<TYPE, S, R, TB8, true>(g, groups, stream, ea, eb);
     else if (g.nt <= 16) mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
-    else if constexpr (S >= 2) mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
+    else mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
 }
 
 template <int TYPE>
 static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     constexpr int T8 = TYPE == PI_Q4_K ? 4 : 2;                 // blocks per tile at <= 8 tokens (Q5_K: the ring carries the fifth bits too)
-    if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14)) cfg = 24;      // two chunks double the chains a wave carries: the one-wave row groups (96 accumulators) would spill
+    static const bool s1nc2 = getenv("PI_MMQ_S1NC2") && atoi(getenv("PI_MMQ_S1NC2")) != 0;
+    if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14) && !s1nc2) cfg = 24;      // two chunks double the chains a wave carries: the one-wave row groups (96 accumulators) would spill
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;

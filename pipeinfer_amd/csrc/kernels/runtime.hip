@@ -537,6 +537,7 @@ std::mutex g_kt_mu;
 bool g_kt_on = false; int g_kt_every = 8;
 std::map<std::tuple<int, int, int, uint64_t>, kt_stat> g_kt_tab;       // (family, type, tokens, launch shape) -> eager launches
 uint64_t kt_shape(int fam, double bytes) { return fam <= PI_KT_MMQ ? (uint64_t) bytes : 0; }   // mat launches: one row per distinct launch (its algorithmic bytes name it: wo, q+k, up+gate, ...)
+std::map<std::tuple<int, int, int, uint64_t>, kt_stat> g_kt_life;      // ... since the process started, never cleared (what a rocprofv3 --pmc pass of the same process sees)
 std::vector<pi_kt_sample> g_kt_pending;                      // timed launches whose events have not been read yet
 std::vector<hipEvent_t> g_kt_pool;
 thread_local pi_kt_sink * g_kt_sink = nullptr;
@@ -564,7 +565,8 @@ bool pi_kt_begin(int fam, int type, int nt, double bytes, hipEvent_t & ea, hipEv
         return false;
     }
     std::lock_guard<std::mutex> lk(g_kt_mu);
-    if (!g_kt_on) return false;                              // (eager launches outside a timing window are not counted: the table belongs to the window)
+    { kt_stat & life = g_kt_life[std::make_tuple(fam, type, ntc, kt_shape(fam, bytes))]; life.launches++; life.bytes += bytes; }      // every eager launch of the process (PMC passes: no graphs)
+    if (!g_kt_on) return false;                              // (eager launches outside a timing window are not part of its table)
     kt_stat & st = g_kt_tab[std::make_tuple(fam, type, ntc, kt_shape(fam, bytes))];
     const bool sample = (st.launches % (uint64_t) g_kt_every) == 0;
     st.launches++; st.bytes += bytes;
@@ -582,12 +584,21 @@ extern "C" void pi_kernel_timing(int on, int sample_every) {
     g_kt_pending.clear();
     g_kt_tab.clear();
 }
-// one row per instance launched since pi_kernel_timing(1, N): call after a device sync.  Returns the number of rows (<= cap)
+// one row per instance launched since pi_kernel_timing(1, N) — or, lifetime != 0, per instance launched eagerly since the process started (no durations): call after a
+// device sync.  Returns the number of rows (<= cap)
+static int kt_rows(std::map<std::tuple<int, int, int, uint64_t>, kt_stat> & tab, struct pi_kt_row * out, int cap);
 extern "C" int pi_kernel_timing_rows(struct pi_kt_row * out, int cap) {
     std::lock_guard<std::mutex> lk(g_kt_mu);
     kt_fold_pending();
+    return kt_rows(g_kt_tab, out, cap);
+}
+extern "C" int pi_kernel_lifetime_rows(struct pi_kt_row * out, int cap) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    return kt_rows(g_kt_life, out, cap);
+}
+static int kt_rows(std::map<std::tuple<int, int, int, uint64_t>, kt_stat> & tab, struct pi_kt_row * out, int cap) {
     int n = 0;
-    for (auto & kv : g_kt_tab) {
+    for (auto & kv : tab) {
         if (n >= cap) break;
         const kt_stat & st = kv.second;
         pi_kt_row & r = out[n++];

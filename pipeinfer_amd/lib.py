@@ -86,6 +86,8 @@ def _declare(lib):
     lib.pi_kernel_timing.argtypes = [i32, i32]
     lib.pi_kernel_timing_rows.argtypes = [vp, i32]
     lib.pi_kernel_timing_rows.restype = i32
+    lib.pi_kernel_lifetime_rows.argtypes = [vp, i32]
+    lib.pi_kernel_lifetime_rows.restype = i32
     lib.pi_weight_upload.restype = vp
     lib.pi_weight_upload.argtypes = [i32, i64, i64, vp, vp]
     lib.pi_weight_free.argtypes = [vp]

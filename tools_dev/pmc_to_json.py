@@ -55,9 +55,9 @@ for name, v in raw.items():
 families = {}
 for f, v in sorted(fam.items()):
     e = {"launches": len(v), "avg_fetch_bytes_per_launch": int(sum(v) / len(v))}
-    bf = (bench_json or {}).get("roofline", {}).get("by_family", {}).get(f)
+    bf = (bench_json or {}).get("roofline", {}).get("process_eager_launches", {}).get(f)
     if bf and bf.get("alg_bytes_per_launch"):
-        # the profiled run's own accounting of the same launches (all of them eager there: PI_NO_GRAPHS=1); includes the draft model's launches, as the counters do
+        # the profiled process's own accounting of the SAME launches (PI_NO_GRAPHS=1: every launch is eager and counted from the first one on, both contexts)
         e["alg_bytes_per_launch_same_run"] = bf["alg_bytes_per_launch"]; e["launches_accounted_same_run"] = bf["launches"]
         e["fetch_over_alg"] = round(e["avg_fetch_bytes_per_launch"] / bf["alg_bytes_per_launch"], 4)
     families[f] = e
