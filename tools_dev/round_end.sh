@@ -15,10 +15,16 @@ line() { # name, bench args...
 import json,sys; d=json.loads([l for l in open('$out/bench_$name.json') if l.startswith('{')][-1]); r=d['roofline']
 print('$name', d['value'], d['lossless_vs_target_only'], {k:(v['tokens_per_s'], v['lossless_vs_target_only']) for k,v in d['other_schedules'].items()}, r['family'], r['frac'], r['traffic'], r['target_decode_call'], r['draft_decode_call'], d.get('cpu_baseline', {}).get('value'))"
 }
+# (the GPU box's /tmp holds 79 GB: the synthetic GGUFs of one configuration at a time)
+cache=${PIPEINFER_CACHE:-/tmp/pipeinfer_models}
 line 70b_n1 --steps 10 --warmup 2
 line 7b_n1 --workload 7b --steps 5 --warmup 1
+rm -f $cache/llama-2-70b-* $cache/llama-2-7b-*
 line falcon40b_n1 --workload falcon40b --steps 3 --warmup 1 --no-cpu-baseline
+rm -f $cache/falcon-*
 line goliath_n1 --workload goliath --n-draft 8 --steps 3 --warmup 1 --no-cpu-baseline
+rm -f $cache/goliath-*
+PIPEINFER_ALLOW_SHARED_GPU=1 timeout 1500 python3 bench.py --gpus 8 --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_70b_n8_one_device.json 2> $out/bench_70b_n8_one_device.err; echo "8 ranks on one device: rc=$?"
 echo "copy (in the build container):"
 echo "  cp gpurun_out/${tag}prof/pmc_fetch_size.json profiles/${tag}_pmc_fetch_size_70b.json"
 echo "  for f in 70b_n1 7b_n1 falcon40b_n1 goliath_n1; do cp $out/bench_\$f.json profiles/${tag}_bench_\$f.json; done"
