@@ -799,8 +799,12 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
 template <int TYPE>
 static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     constexpr int T8 = TYPE == PI_Q4_K ? 4 : 2;                 // blocks per tile at <= 8 tokens (Q5_K: the ring carries the fifth bits too)
-    static const bool s1nc2 = getenv("PI_MMQ_S1NC2") && atoi(getenv("PI_MMQ_S1NC2")) != 0;
-    if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14) && !s1nc2) cfg = 24;      // two chunks double the chains a wave carries: the one-wave row groups (96 accumulators) would spill
+    // Two chunks double the chains a wave carries (96 accumulators on a one-wave row group).  Round 3 sent such launches to two-wave row groups (it spilled with the 8-block ring);
+    // with the one-block tiles of the two-chunk form (a 2-block ring) the one-wave instance fits — 254 VGPRs, no spill — and the tall launches stop repeating the block scalars in
+    // two waves and take two rounds of workgroups instead of 3.5.  Same-box A/B at 24 / 32 tokens, us per launch: 57344 x 8192 139.3 / 138.8 -> 102.2 / 100.7, 28672 x 8192
+    // 72.1 / 71.6 -> 54.6 / 53.3, 44032 x 4096 59.1 / 58.7 -> 56.2 / 55.8, Q6_K 32000 x 8192 78.0 / 75.2 -> 77.9 / 75.8; 70B prompts 987 -> 1 098 tok/s.  PI_MMQ_S1NC2=0: round 3's choice.
+    static const bool s1nc2 = !(getenv("PI_MMQ_S1NC2") && atoi(getenv("PI_MMQ_S1NC2")) == 0);
+    if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14) && !s1nc2) cfg = 24;
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;
