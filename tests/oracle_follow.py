@@ -9,22 +9,21 @@ import numpy as np
 
 class RunLog:
     def __init__(self):
-        self.runs, self.order = {}, []
+        self.entries, self.order, self.runs = [], [], {}            # entries in start order; order: their run ids; runs: id -> the LATEST entry with that id
 
     def tap(self, run_id, batch_id, n, meta, rows):
         r = self.runs.get(run_id)
-        if r is None or r["finished"]:                                      # (ids are per context and only repeat after 2^30 runs)
-            self.runs[run_id] = dict(batch_id=batch_id, n=n, meta=meta, rows=None, finished=False)
-            self.order.append(run_id)
-        else:
+        if r is None or r["finished"]:                                      # a start (ids are per context and only repeat after 2^30 runs)
+            r = dict(batch_id=batch_id, n=n, meta=meta, rows=None, finished=False)
+            self.entries.append(r); self.order.append(run_id); self.runs[run_id] = r
+        else:                                                               # the finish of the run that is open under this id
             r["rows"], r["finished"] = rows, True
 
     def replay(self, o, oh, n_ctx, n_vocab):
         """o: the oracle library (tests.oracle_lib.oracle()), oh: a model handle of o_model_load with the same n_ctx.  Returns (runs compared, mismatches)."""
         words = (n_ctx + 31) // 32
         compared, bad = 0, []
-        for k, rid in enumerate(self.order):
-            r = self.runs[rid]
+        for k, r in enumerate(self.entries):
             n, block = r["n"], r["meta"]
             tok, pos, dyn = block[:n], block[n:2 * n], block[2 * n:2 * n + 4]
             assert int(dyn[3]) == 0, "a run's own block never carries a cell table"
