@@ -192,7 +192,7 @@ def summarize(results):
 
 FAMILIES = {0: "matvec", 1: "matrix_cores", 2: "norm_quant", 3: "quantize", 4: "act_quant", 5: "attention", 6: "other"}
 FAMILY_KERNELS = {"matvec_nt1": "k_mmvq_kq / k_mmvq_kq2 / k_mmvq_q0r (VALU mat-vec, one token)", "matvec_multi": "k_mmvq_* (VALU mat-vec, 2..8 tokens)",
-                  "matrix_cores": "k_mmq_kq (matrix-core mat-mat, 3..32 tokens per pass)", "norm_quant": "k_norm_quant", "quantize": "k_quantize_q8_K / _q8_0",
+                  "matrix_cores": "k_mmq_kq / k_mmq_g2 (matrix-core mat-mat, 3..32 tokens per pass)", "norm_quant": "k_norm_quant", "quantize": "k_quantize_q8_K / _q8_0",
                   "act_quant": "k_act_quant", "attention": "k_attention", "other": "k_get_rows, k_rope_kv, k_topk1/2, k_norm, k_add, ..."}
 
 

@@ -19,7 +19,10 @@ TYPES = {"2": "Q4_0", "3": "Q4_1", "6": "Q5_0", "7": "Q5_1", "8": "Q8_0", "10": 
 d, source = sys.argv[1], sys.argv[2]
 bench_json = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1]) if len(sys.argv) > 3 else None
 raw = collections.defaultdict(list)
-for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+if os.path.isfile(d) and d.endswith(".json"):                                        # re-derive the family tables of an existing file from its by_symbol section
+    for name, v in json.load(open(d))["by_symbol"].items():
+        raw[name] = [float(v["avg_fetch_bytes_per_launch"])] * int(v["launches"])
+for f in ([] if os.path.isfile(d) else sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == "FETCH_SIZE":
             raw[re.sub(r"\(.*", "", r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024 * 2)
@@ -31,6 +34,9 @@ def family(name):
     if m:
         width = "nt17-32" if m.group(6) == "2" else "nt3-8" if m.group(5) == "true" else "nt9-16"
         return "matrix_cores", f"{TYPES.get(m.group(1), m.group(1))}_matrix_cores_{width}"
+    m = re.match(r"void k_mmq_g2<(\d+), (\d+)>", name)                               # two row groups per wave: Q4_K, <= 8 tokens
+    if m:
+        return "matrix_cores", "Q4_K_matrix_cores_nt3-8"
     m = re.match(r"void k_mmvq_kq2<(\d+), (\d+), (\d+), ", name)                      # two weight types in one launch: counted with the first type, like bench.py's accounting
     if m:
         return ("matvec_nt1" if m.group(3) == "1" else "matvec_multi"), f"{TYPES.get(m.group(1), m.group(1))}_nt{m.group(3)}"
