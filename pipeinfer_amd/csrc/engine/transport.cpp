@@ -54,7 +54,7 @@ struct msg_hdr { int32_t kind, run_seq, batch_id, n_tokens, flags, gen, pad0, pa
 struct stage_block {                             // index = rank
     ring_ctl in;                                 // producer: rank - 1 (the head for rank 1); consumer: rank
     msg_hdr slots[TP_IN1_SLOTS];                 // ranks >= 2 use the first TP_X_SLOTS
-    struct alignas(16) xflag_t { std::atomic<uint32_t> value; uint32_t pad; uint64_t stamp; } xflag[TP_X_SLOTS];      // arrival flags of this stage's activation slots (runtime.hip: pi_xflag)
+    struct alignas(16) xflag_t { std::atomic<uint32_t> value; uint32_t pad; uint64_t stamp; } xflag[TP_X_SLOTS], xprobe;      // arrival flags of this stage's activation slots (runtime.hip: pi_xflag); xprobe: the set-up probe of that path
     std::atomic<uint32_t> ipc_ready, probe_written, joined, setup_done, flags_done;
     std::atomic<int32_t> device;                 // HIP device ordinal of the rank's process (-1: none)
     char ipc_handle[64];                         // hipIpcMemHandle_t
@@ -331,6 +331,24 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
             if (hipHostGetDevicePointer(&dp, tp->base, 0) == hipSuccess && dp) tp->ctl_dev = (uint8_t *) dp;
         }
         if (!tp->ctl_dev) { (void) hipGetLastError(); fprintf(stderr, "[pipeinfer transport, rank %d] the control block cannot be mapped for device access: headers are published by the host\n", tp->rank); L->flags_off.store(1); }
+        // Probe the path on this node before any run depends on it (like the ring probe above): each stage's device writes the next stage's probe flag and each stage's device
+        // polls its own.  A poll that never sees the write (a topology where a device does not observe another device's stores to mapped host memory) costs 3 s here, once,
+        // and sends every rank to the host path - instead of one time-out per run.
+        if (tp->ctl_dev) {
+            const uint32_t probe_ticket = 0x2bad5eed;
+            auto probe_dev = [&](int rank_of_consumer) { return (void *) (tp->ctl_dev + ((uint8_t *) &L->st[rank_of_consumer].xprobe - tp->base)); };
+            bool ok = true;
+            if (tp->rank + 1 < tp->world) ok = pi_op_flag_publish(probe_dev(tp->rank + 1), probe_ticket, nullptr, 0, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess;
+            if (ok && tp->rank >= 2) {
+                int32_t * scratch = nullptr;                      // {abort word, time-out flag}
+                ok = hipMalloc((void **) &scratch, 2 * sizeof(int32_t)) == hipSuccess && hipMemset(scratch, 0, 2 * sizeof(int32_t)) == hipSuccess;
+                int32_t seen[2] = {0, 1};
+                ok = ok && pi_op_abort_begin_wait(scratch, 1, nullptr, probe_dev(tp->rank), probe_ticket, 3000000, scratch + 1, nullptr, nullptr) == 0
+                        && hipDeviceSynchronize() == hipSuccess && hipMemcpy(seen, scratch, sizeof(seen), hipMemcpyDeviceToHost) == hipSuccess && seen[1] == 0 && seen[0] == (1 << 1);
+                if (scratch) (void) hipFree(scratch);
+            }
+            if (!ok) { (void) hipGetLastError(); fprintf(stderr, "[pipeinfer transport, rank %d] the arrival-flag probe failed on this node: headers are published by the host\n", tp->rank); L->flags_off.store(1); }
+        }
     } else if (tp->rank >= 1) L->flags_off.store(1);
     L->st[tp->rank].flags_done.store(1, std::memory_order_release);
     for (int r = 1; r < tp->world; r++)
