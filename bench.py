@@ -274,6 +274,13 @@ def roofline_tables(counts, samples):
     return out, inst
 
 
+def default_coalesce(n_draft):
+    """widest pass the target's feeder composes: 8 tokens - two speculative runs at the headline's n_draft 3 (or one run of 8 drafted tokens), and the widest pass of the
+    two-row-groups-per-wave matrix-core kernel.  Round 4, results written by a kernel (tok/s at 8 | 16): 70B 102-105 | 92.8, 7B 257 | 257, Falcon-40B 75.8 | 75.6,
+    Goliath (n_draft 8) 55.7 | 46.5 - a wider pass mostly carries runs that continuous speculation cancels while they compute."""
+    return 8
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) as CHILD processes through torch.distributed.run,
     wait for them, print rank 0's single JSON line and return non-zero if any rank failed.  Nothing here initialises the GPU."""
@@ -371,7 +378,9 @@ def main():
     # Engine feature, not a driver change: the target's feeder takes every live run waiting in its queue into one forward pass (include/pipeinfer.h: run coalescing).
     # On ONE GPU the PipeInfer driver's non-speculative run for a freshly sampled token and the speculative run(s) drafted meanwhile wait behind the run in flight; carried
     # together they stream the 41 GB of weights once instead of once each.  Every token's bits are those it gets alone (tests/test_gpu_engine.py).
-    coalesce = int(os.environ.get("PIPEINFER_COALESCE", "16")) if seg_layers > 0 else 0
+    # Width of a pass (default_coalesce).  Round 4, 70B, with the results written by a kernel (a draft call 2.8 -> 1.8 ms beside the target): 16 tokens 92.8 tok/s
+    # (the faster draft queues more speculative runs than the target can verify before they are cancelled), 12: 98.9, 10: 98.9, 8: 102-105, 7: 101.6, 6: 86.
+    coalesce = int(os.environ.get("PIPEINFER_COALESCE", str(default_coalesce(args.n_draft)))) if seg_layers > 0 else 0
     ct.prepare(); cd.prepare()
     ct.set_coalescing(coalesce)
     print(f"[bench] models resident in HBM after {time.time() - t0:.1f}s", file=sys.stderr)

@@ -61,6 +61,10 @@ PI_API int     pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * str
  *   pi_op_abort_begin_wait  (consumer's stream, ahead of the run)       polls the flag from the device until it carries `ticket` (at most timeout_us: then the run is marked
  *                           aborted and *timeout_flag_dev = 1), then arms the abort word like pi_op_abort_begin, with the producer's abort bit or-ed in;
  *                           hop_ticks_dev (nullable) accumulates {flag written -> seen, time waited, runs} in 10 ns ticks */
+/* A run's results (logits rows, top-8 ids / values, soft-max sums) written into the caller's PAGE-LOCKED host buffers by a kernel on the run's stream, instead of
+ * hipMemcpyAsync: on this runtime a device -> host copy of the logits' size does not complete while another stream's kernels keep the device busy (runtime.hip). */
+PI_API int     pi_op_copy_out(const float * logits_dev, float * logits_host, int64_t n_logits, const int32_t * ids_dev, int32_t * ids_host, const float * vals_dev, float * vals_host,
+                              const float * sum_dev, float * sum_host, int n_tok, void * stream);
 PI_API int     pi_op_flag_publish(void * flag_dev, uint32_t ticket, const int32_t * abort_word_dev, int force_abort, void * stream);
 PI_API int     pi_op_abort_begin_wait(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, const void * flag_dev, uint32_t ticket, int64_t timeout_us,
                                       int32_t * timeout_flag_dev, uint64_t * hop_ticks_dev, void * stream);

@@ -440,6 +440,13 @@ static bool launch_outputs(llama_context * ctx, pi_run * run) {
     if (!ctx->is_last) return true;
     hipStream_t s = ctx->stream;
     const size_t nv = ctx->model->hparams.n_vocab, r0 = (size_t) run->row0; const int n_tokens = run->n_tokens;
+    // by a kernel that writes the run's page-locked buffers (pi_op_copy_out: a copy-engine transfer waits for the OTHER context's kernels); PIPEINFER_COPY_OUT=memcpy: the copies of rounds 1-3
+    static const bool by_memcpy = getenv("PIPEINFER_COPY_OUT") && !strcmp(getenv("PIPEINFER_COPY_OUT"), "memcpy");
+    if (!by_memcpy && !run->host_plain) {
+        if (pi_op_copy_out(ctx->logits_dev + r0 * nv, run->logits_host, (int64_t) n_tokens * (int64_t) nv, ctx->topk_ids_dev + r0 * 8, run->topk_ids, ctx->topk_vals_dev + r0 * 8, run->topk_vals,
+                           ctx->topk_sum_dev + r0, run->topk_sum, n_tokens, s) != 0) { ctx->last_error = std::string("pi_op_copy_out: ") + pi_last_error(); return false; }
+        return true;
+    }
     const bool ok = hipMemcpyAsync(run->logits_host, ctx->logits_dev + r0 * nv, (size_t) 4 * n_tokens * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
                     hipMemcpyAsync(run->topk_ids, ctx->topk_ids_dev + r0 * 8, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
                     hipMemcpyAsync(run->topk_vals, ctx->topk_vals_dev + r0 * 8, (size_t) 4 * n_tokens * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -659,7 +666,10 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
 
     ctx->cells->pre_decode(n_tokens);
     const int kv_head = ctx->cells->find_slot(n_tokens, pos, n_seq_id, seq_id);
-    if (kv_head < 0) { rc = 1; return nullptr; }                              // reference prints "Cannot find cache slot" and fails the decode
+    if (kv_head < 0) {                                                        // reference prints "Cannot find cache slot" and fails the decode (llama.cpp:5560-5563)
+        ctx->last_error = "no KV cache slot for a batch of " + std::to_string(n_tokens) + " token(s): n_ctx " + std::to_string(ctx->n_ctx) + " is too small for the runs in flight";
+        rc = 1; return nullptr;
+    }
     const int n_kv = ctx->cells->n_attend();
     const int words = (ctx->n_ctx + 31) / 32;                                   // fixed row stride of the visibility bitmap
     const size_t meta_bytes = (size_t) n_tokens * 8 + 16 + (size_t) n_tokens * words * 4;

@@ -1,6 +1,7 @@
 // Device runtime glue: error text, fp16 tables, memory helpers, weight upload + one-time re-layout.
 #include "ops_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -169,6 +170,34 @@ extern "C" int pi_op_abort_begin(int32_t * word_dev, int32_t run_id, const int32
 }
 extern "C" int pi_op_abort_cancel(int32_t * word_dev, int32_t run_id, void * stream) {
     hipLaunchKernelGGL(k_abort_cancel, dim3(1), dim3(1), 0, (hipStream_t) stream, word_dev, run_id & 0x3fffffff);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- results leave the device through a kernel ---------------------------------------------------------------------------------------------------
+// hipMemcpyAsync(device -> page-locked host) of a run's logits goes through a copy engine on this runtime, and that copy does not complete while ANOTHER stream's kernels
+// keep the device busy: a draft step of 1.2 ms waited for the whole 11 ms target run beside it (tools_dev/wrap_beside.py, profiles/r04_d2h_copy_stall.log; the same step
+// with its results written by a kernel: 1.3 ms beside the target).  Page-locked host memory is device-addressable, so the last kernel of a run writes the caller's
+// buffers itself; the event recorded behind it releases them to the host.
+typedef uint32_t rt_u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy_out(const float * __restrict__ logits, float * __restrict__ logits_h, size_t n_logits, const int32_t * __restrict__ ids, int32_t * __restrict__ ids_h,
+                                                  const float * __restrict__ vals, float * __restrict__ vals_h, const float * __restrict__ sum, float * __restrict__ sum_h, int n_tok) {
+    const size_t tid = (size_t) blockIdx.x * 256 + threadIdx.x, nthr = (size_t) gridDim.x * 256;
+    if ((((uintptr_t) logits | (uintptr_t) logits_h) & 15) == 0) {
+        const size_t n4 = n_logits / 4;
+        for (size_t i = tid; i < n4; i += nthr) __builtin_nontemporal_store(((const rt_u32x4 *) logits)[i], (rt_u32x4 *) logits_h + i);
+        for (size_t i = n4 * 4 + tid; i < n_logits; i += nthr) logits_h[i] = logits[i];
+    } else for (size_t i = tid; i < n_logits; i += nthr) logits_h[i] = logits[i];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 8 * n_tok; i += 256) { ids_h[i] = ids[i]; vals_h[i] = vals[i]; }
+        for (int i = threadIdx.x; i < n_tok; i += 256) sum_h[i] = sum[i];
+    }
+}
+extern "C" int pi_op_copy_out(const float * logits_dev, float * logits_host, int64_t n_logits, const int32_t * ids_dev, int32_t * ids_host, const float * vals_dev, float * vals_host,
+                              const float * sum_dev, float * sum_host, int n_tok, void * stream) {
+    const int64_t per_wg = 256 * 4 * 4;                                       // four 16-byte stores per thread
+    const unsigned grid = (unsigned) std::max<int64_t>(1, std::min<int64_t>(256, (n_logits + per_wg - 1) / per_wg));
+    hipLaunchKernelGGL(k_copy_out, dim3(grid), dim3(256), 0, (hipStream_t) stream, logits_dev, logits_host, (size_t) n_logits, ids_dev, ids_host, vals_dev, vals_host, sum_dev, sum_host, n_tok);
     PI_CHECK_LAUNCH();
     return 0;
 }

@@ -83,6 +83,7 @@ def _declare(lib):
     lib.pi_set_abort_word.argtypes = [vp]; lib.pi_set_abort_word.restype = None
     lib.pi_op_abort_begin.argtypes = [vp, i32, vp, vp]
     lib.pi_op_abort_cancel.argtypes = [vp, i32, vp]
+    lib.pi_op_copy_out.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.pi_kernel_timing.argtypes = [i32, i32]
     lib.pi_kernel_timing_rows.argtypes = [vp, i32]
     lib.pi_kernel_timing_rows.restype = i32

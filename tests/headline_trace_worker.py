@@ -1,5 +1,5 @@
 """GPU: the configuration bench.py's `value` runs in — PipeInfer driver (mode 0), the target context segmented (a quarter of its layers per segment) behind its feeder thread
-with run coalescing 16, the draft a priority context on the same GPU — with EVERY run compared against the oracle: the run tap records each run's metadata block and the rows it
+with run coalescing at bench.py's width (8 tokens at n_draft 3), the draft a priority context on the same GPU — with EVERY run compared against the oracle: the run tap records each run's metadata block and the rows it
 got back (most of them out of a pass shared with other runs: per-token n_kv and cell table in the attention launches, compose_pass, pass_conflict's same-computation exemption,
 members cancelled inside a pass), and the oracle replays the runs one by one on the same cells.  usage: headline_trace_worker.py <workload[-lN]> [n_predict] [n_draft] [n_parallel] [p_accept]"""
 import ctypes as C, os, sys
@@ -37,7 +37,7 @@ for mode in (2, 0):
     if mode == 0:                                              # bench.py's engine settings for the one-GPU line
         ct.set_segments(max(1, n_layer // 4)); cd.set_priority(1)
         ct.prepare(); cd.prepare()
-        ct.set_coalescing(16)
+        ct.set_coalescing(B.default_coalesce(n_draft))
         ct.set_run_tap(log.tap)
     out, res = LL.speculative(ct, cd, prompt, n_predict=n_predict, n_draft=n_draft, n_parallel=n_parallel, p_accept=p_accept, p_split=0.9, ignore_eos=1, mode=mode)
     outs[mode] = [int(x) for x in out[:n_predict]]

@@ -741,7 +741,7 @@ def test_coalesced_runs_equal_single_runs_at_full_size_shapes(LL, workload):
 
 @pytest.mark.parametrize("workload,n_predict", [("70b-l4", 48), ("7b", 40)])
 def test_headline_schedule_equals_the_oracle_run_by_run(workload, n_predict):
-    """bench.py's `value` configuration itself — PipeInfer driver, target segmented behind its feeder with run coalescing 16, priority draft, one GPU — with every run of the
+    """bench.py's `value` configuration itself — PipeInfer driver, target segmented behind its feeder with run coalescing (bench.default_coalesce: 8 tokens), priority draft, one GPU — with every run of the
     generation (prompt passes, single tokens, speculative batches; most of them members of a pass shared with other runs, some cancelled inside one) replayed one by one through
     the oracle on the cells, n_kv and visibility rows the run was given (tests/headline_trace_worker.py; llama.cpp:1593-1644, 5200-5240, speculative.cpp:1252-1255): bit for bit."""
     import subprocess, sys
