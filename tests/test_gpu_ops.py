@@ -720,3 +720,35 @@ def test_persimmon_attention_inputs_and_relu_sqr_exact(gpu):
     got = U.q8_as_ref_blocks(O.Q8_K, *U.q8_planes(lib, O.Q8_K, n, 3, q8))
     for t in range(3):
         assert np.array_equal(got[t], o.quantize_act(O.Q8_K, h[t]))
+
+
+@pytest.mark.parametrize("n_tok,nv,skew", [(1, 32000, 0), (3, 1001, 0), (2, 4096, 1), (5, 259, 3)])
+def test_copy_out_writes_the_page_locked_buffers(gpu, n_tok, nv, skew):
+    """pi_op_copy_out (runtime.hip): a run's logits rows, top-8 ids / values and soft-max sums written by a kernel into page-locked host memory are the device's bytes —
+    also when a row count or a row offset keeps the logits off the 16-byte vector path (skew: floats the device pointer starts past an aligned address)."""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]; hip.hipHostFree.argtypes = [C.c_void_p]
+    lib.pi_op_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    rng = np.random.default_rng(n_tok * 7919 + nv)
+    n = n_tok * nv
+    logits = rng.standard_normal(n + skew).astype(np.float32)
+    ids = rng.integers(0, nv, 8 * n_tok).astype(np.int32); vals = rng.standard_normal(8 * n_tok).astype(np.float32); sums = rng.standard_normal(n_tok).astype(np.float32)
+    d_log, d_ids, d_vals, d_sum = U.Dev(logits), U.Dev(ids), U.Dev(vals), U.Dev(sums)
+    nbytes = 4 * n + 16 + 4 * 17 * n_tok + 64
+    host = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(host), nbytes, 0) == 0
+    try:
+        C.memset(host, 0xA5, nbytes)
+        h_log, h_ids = host.value, host.value + ((4 * n + 15) // 16) * 16
+        h_vals, h_sum = h_ids + 32 * n_tok, h_ids + 64 * n_tok
+        L.check(lib.pi_op_copy_out(d_log.ptr + 4 * skew, h_log, n, d_ids.ptr, h_ids, d_vals.ptr, h_vals, d_sum.ptr, h_sum, n_tok, None), "pi_op_copy_out")
+        L.check(lib.pi_stream_sync(None))
+        got = lambda p, cnt, dt: np.frombuffer((C.c_char * (cnt * 4)).from_address(p), dtype=dt).copy()
+        assert np.array_equal(got(h_log, n, np.uint32), logits[skew:].view(np.uint32))
+        assert np.array_equal(got(h_ids, 8 * n_tok, np.int32), ids) and np.array_equal(got(h_vals, 8 * n_tok, np.uint32), vals.view(np.uint32)) and np.array_equal(got(h_sum, n_tok, np.uint32), sums.view(np.uint32))
+        tail = np.frombuffer((C.c_char * 16).from_address(h_sum + 4 * n_tok), dtype=np.uint8)
+        assert (tail == 0xA5).all(), "the kernel wrote past the buffers it was given"
+    finally:
+        hip.hipHostFree(host)
