@@ -364,6 +364,7 @@ static int n_segments(const llama_context * ctx) {
     const int nl = ctx->l1 - ctx->l0;
     return ctx->seg_layers > 0 && nl > 0 ? (nl + ctx->seg_layers - 1) / ctx->seg_layers : 1;
 }
+bool hop_store(void * dst, const void * src, size_t bytes, hipStream_t s);
 // x_in (device, [n_tokens][n_embd]) replaces the embedding lookup on stages after the first
 static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, const float * x_in) {
     const int words = (ctx->n_ctx + 31) / 32;
@@ -376,7 +377,7 @@ static bool launch_inputs(llama_context * ctx, int n_tokens, const void * meta, 
               hipMemcpyAsync(ctx->pos_dev, h_pos, (size_t) 4 * n_tokens, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->dyn_dev, h_dyn, 16 + 4 * n_table, hipMemcpyHostToDevice, s) == hipSuccess &&
               hipMemcpyAsync(ctx->mask_dev, h_mask, (size_t) 4 * n_tokens * words, hipMemcpyHostToDevice, s) == hipSuccess;
-    if (ok && x_in) ok = hipMemcpyAsync(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;      // device (peer ring) or host (staged transport)
+    if (ok && x_in) ok = hop_store(ctx->x, x_in, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, s);      // device (this stage's ring: a kernel) or host (staged transport: a copy)
     if (!ok) ctx->last_error = "H2D of batch metadata failed";
     return ok;
 }
@@ -817,6 +818,28 @@ bool context_wait(llama_context * ctx, pi_run * run) {
 
 // One run on a pipeline stage (a process that owns layers [l0, l1)).  Mirrors the worker side of llama_decode_internal
 // (llama.cpp:5588-5760): receive activations, compute the local graph, hand the result on; here the transport is the caller's.
+// ---- the hop's store -------------------------------------------------------------------------------------------------------------------------
+// A stage hands its activations to the next one by STORING them into the consumer's ring slot (a peer mapping of the next stage's HBM).  Until round 4 that was a
+// hipMemcpyAsync; device memory is now written by a kernel of the producing stream - the copy-engine path of this runtime has been seen to wait for kernels of other queues
+// (the draft's D2H beside the target), and a run's 32 KB per token are nothing a copy engine is needed for.  Host destinations (the staged transport) and
+// PIPEINFER_HOP_STORE=memcpy keep the copy.
+__global__ void __launch_bounds__(256) k_hop_store(const uint4 * __restrict__ src, uint4 * __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t) gridDim.x * 256) dst[i] = src[i];
+}
+bool hop_store(void * dst, const void * src, size_t bytes, hipStream_t s) {
+    static const bool by_memcpy = getenv("PIPEINFER_HOP_STORE") && !strcmp(getenv("PIPEINFER_HOP_STORE"), "memcpy");
+    bool dev = false;
+    if (!by_memcpy && bytes % 16 == 0 && (((uintptr_t) dst | (uintptr_t) src) & 15) == 0) {
+        hipPointerAttribute_t a, b;                                             // both ends in device memory (the staged transport hands over host buffers)
+        if (hipPointerGetAttributes(&a, dst) == hipSuccess && hipPointerGetAttributes(&b, src) == hipSuccess) dev = a.type == hipMemoryTypeDevice && b.type == hipMemoryTypeDevice;
+        else (void) hipGetLastError();
+    }
+    if (!dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s) == hipSuccess;
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_hop_store, dim3((unsigned) std::max<size_t>(1, std::min<size_t>(256, (n16 + 1023) / 1024))), dim3(256), 0, s, (const uint4 *) src, (uint4 *) dst, n16);
+    return hipGetLastError() == hipSuccess;
+}
+
 int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
               float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum, int (*should_abort)(void *), void * abort_user, const pi_stage_hop * hop) {
     std::string err;
@@ -872,7 +895,7 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     const size_t nv = ctx->model->hparams.n_vocab;
     (void) hipEventRecord(ec, s);
     // the hop: the activations are stored by THIS stream straight into the consumer's ring slot (x_out: a peer mapping of the next stage's HBM, or host memory) ...
-    if (ok && !cut && !ctx->is_last) ok = hipMemcpyAsync(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, hipMemcpyDefault, s) == hipSuccess;
+    if (ok && !cut && !ctx->is_last) ok = hop_store(x_out, ctx->x, (size_t) 4 * n_tokens * ctx->model->hparams.n_embd, s);
     // ... and the consumer's arrival flag right behind them (with the abort this run ended with: a run cut short here must not be computed downstream either)
     if (ok && flag_out && pi_op_flag_publish(hop->out_flag, hop->out_ticket, ctx->abort_dev, cut ? 1 : 0, s) != 0) { ctx->last_error = std::string("pi_op_flag_publish: ") + pi_last_error(); ok = false; }
     if (ok && !cut && ctx->is_last)

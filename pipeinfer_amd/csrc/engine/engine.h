@@ -236,5 +236,6 @@ int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
                int (*should_abort)(void *) = nullptr, void * abort_user = nullptr, const pi_stage_hop * hop = nullptr);        // 0 done, 1 cut short (should_abort, a cancel, or upstream), < 0 error
 void stage_abort_run(llama_context * ctx, int32_t run_id);                  // any thread: run `run_id` (ctx->stage_run_id while stage_run computes it) returns from every kernel on entry from now on; no effect on any other run
+bool hop_store(void * dst, const void * src, size_t bytes, hipStream_t s);        // context.cpp: a stage's activations into the consumer's ring slot (kernel store for device memory)
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

@@ -225,7 +225,12 @@ void setup_device_rings(pipeinfer_transport * tp) {
             else {
                 float probe[256];
                 for (int i = 0; i < 256; i++) probe[i] = (float) (r * 1000 + i);
-                if ((e = hipMemcpyAsync(tp->peer_ring, probe, sizeof probe, hipMemcpyHostToDevice, tp->copy_stream)) != hipSuccess || (e = hipStreamSynchronize(tp->copy_stream)) != hipSuccess) bad("probe store into the next stage's ring", e);
+                // (through the hop's own store - a kernel of this device writing the peer mapping - so that the probe tests what the runs will use)
+                float * scratch = nullptr;
+                if ((e = hipMalloc((void **) &scratch, sizeof probe)) != hipSuccess || (e = hipMemcpy(scratch, probe, sizeof probe, hipMemcpyHostToDevice)) != hipSuccess) bad("probe scratch", e);
+                else if (!pi::hop_store(tp->peer_ring, scratch, sizeof probe, tp->copy_stream)) bad("probe store into the next stage's ring", hipGetLastError());
+                else if ((e = hipStreamSynchronize(tp->copy_stream)) != hipSuccess) bad("probe store into the next stage's ring", e);
+                if (scratch) (void) hipFree(scratch);
             }
         }
         L->st[r + 1].probe_written.store(1, std::memory_order_release);
