@@ -79,13 +79,23 @@ def kernel_source_sha():
 def committed_traffic(workload, kernel_key):
     """HBM traffic of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction): bench.py cannot
     run the profiler on itself.  The file is only quoted if it was measured on THIS kernel source (sha) and workload."""
-    name = f"r04_pmc_fetch_size_{workload}.json"
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-    except Exception:
-        return None, f"no committed PMC pass for workload {workload} (profiles/{name})"
-    if pmc.get("kernel_src_sha16") != kernel_source_sha():
-        return None, f"profiles/{name} was measured on kernel sources {pmc.get('kernel_src_sha16')}, these are {kernel_source_sha()}: not quoted"
+    import glob
+    sha = kernel_source_sha()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_fetch_size_{workload}.json")), reverse=True)      # newest round first
+    if not files:
+        return None, f"no committed PMC pass for workload {workload} (profiles/r*_pmc_fetch_size_{workload}.json)"
+    pmc, name, seen = None, None, []
+    for f in files:
+        try:
+            cand = json.load(open(f))
+        except Exception:
+            continue
+        seen.append(f"{os.path.basename(f)}: {cand.get('kernel_src_sha16')}")
+        if cand.get("kernel_src_sha16") == sha:
+            pmc, name = cand, os.path.basename(f)
+            break
+    if pmc is None:
+        return None, f"the committed PMC passes were measured on other kernel sources ({'; '.join(seen)}), these are {sha}: not quoted"
     k = pmc.get("families", {}).get(kernel_key)
     if not k:
         return None, f"profiles/{name} has no entry for {kernel_key}"
@@ -130,8 +140,8 @@ def _time_cpu_model(path, n_tokens, n_prompt, cores, budget_s):
 def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_prompt=4):
     """The reference's CPU path (oracle/_ref: its llama.cpp graph builder on its ggml kernels, compiled from its own sources) decoding the target model token by
     token on the host cores; falls back to our C port of them (oracle/liboracle.so).  Test infrastructure: only this leg of bench.py
-    touches oracle/.  Models that fit the time budget are decoded whole; the 70B target is timed on two depth-truncated copies (4 and 8
-    layers with the tensor types of layers 8..15 of the 80 — half of them "more bits" layers, like the whole model) and extrapolated
+    touches oracle/.  Models that fit the time budget are decoded whole; the 70B target is timed on two depth-truncated copies (8 and 16
+    layers with the tensor types of layers 8.. of the 80 — half of them "more bits" layers, like the whole model) and extrapolated
     linearly in the layer count (decode cost is additive per layer: BASELINE.md section 2, method B1)."""
     # ggml's spin-waiting thread pool stops scaling long before a 256-thread host is full: use at most 32 threads and say so
     cores = min(os.cpu_count() or 1, int(os.environ.get("PIPEINFER_CPU_THREADS", "32")))
@@ -140,22 +150,37 @@ def cpu_baseline(tspec, tft, tgt_path, cache, signal, noise, n_tokens=8, n_promp
         spt, done, kind, reps = _time_cpu_model(tgt_path, n_tokens, 16, cores, 25.0)
         return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "threads": cores, "host_cores": os.cpu_count(), "kind": kind, "ms_per_token_repetitions": reps,
                 "sample": f"target-only greedy decode of {done} tokens after a 16-token prompt, same synthetic GGUF, n_threads={cores}; fastest of three repetitions"}
-    p4 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 4))
+    # two copies that are both far beyond any last-level cache (4.5 GB and 8.6 GB of weights per token): round 4's 4-layer copy (2.4 GB) decoded at half the per-layer cost
+    # of the 8-layer one, and the clamp `head = max(0, ...)` hid it
     p8 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 8))
-    t4, d4, kind, reps4 = _time_cpu_model(p4, n_tokens, n_prompt, cores, 10.0)
-    t8, d8, _, reps8 = _time_cpu_model(p8, n_tokens, n_prompt, cores, 15.0)
-    per_layer = max(1e-9, (t8 - t4) / 4.0)
-    head = max(0.0, t4 - 4.0 * per_layer)
-    spt = head + n_layer * per_layer
-    # cores = threads = what the leg actually used (ggml's spin-waiting pool stops scaling near 32 threads); host_cores = what the GPU box's host has
-    # spread of the extrapolation over the repetitions: slowest 8-layer against fastest 4-layer timing and the other way round
-    hi = max(1e-9, (max(reps8) - min(reps4)) / 4e3) * n_layer + head
-    lo = max(1e-9, (min(reps8) - max(reps4)) / 4e3) * n_layer + head
+    p16 = ensure_model(cache, tspec, tft, 0x5EED, signal, noise, layers=(8, 16))
+    t8, d8, kind, reps8 = _time_cpu_model(p8, n_tokens, n_prompt, cores, 10.0)
+    t16, d16, _, reps16 = _time_cpu_model(p16, n_tokens, n_prompt, cores, 18.0)
+    return cpu_extrapolation(n_layer, t8, t16, reps8, reps16, d8, d16, kind, cores)
+
+
+def cpu_extrapolation(n_layer, t8, t16, reps8, reps16, d8, d16, kind, cores):
+    """seconds per token of the full model from the 8- and the 16-layer copy, two ways, both reported and nothing clamped:
+      difference  per layer = (t16 - t8) / 8, head (embedding + lm_head + fixed cost) = t8 - 8 per layer          -> head + n_layer per layer
+      ratio       per layer = t16 / 16 (the head's share charged to the layers: an upper bound)                    -> n_layer t16 / 16
+    `value` is the difference estimate (the head is counted once, as in the full model); `value_range` spans both estimates over the repetitions."""
+    per_layer = (t16 - t8) / 8.0
+    head = t8 - 8.0 * per_layer                                             # may come out negative when the host's timings are noisy: shown as it is
+    spt_diff = head + n_layer * per_layer
+    spt_ratio = n_layer * t16 / 16.0
+    spt = spt_diff if spt_diff > 0 else spt_ratio
+    cands = [spt_diff, spt_ratio, (max(reps16) - min(reps8)) / 8e3 * n_layer + head, (min(reps16) - max(reps8)) / 8e3 * n_layer + head, n_layer * max(reps16) / 16e3, n_layer * min(reps16) / 16e3]
+    cands = [c for c in cands if c > 0]
     return {"value": 1.0 / spt, "unit": "tokens/s", "cores": cores, "threads": cores, "host_cores": os.cpu_count(), "kind": kind,
-            "ms_per_token_4_layers": reps4, "ms_per_token_8_layers": reps8, "value_range": [round(1.0 / hi, 3), round(1.0 / lo, 3)],
-            "sample": f"target-only greedy decode, reference kernels on {cores} of the host's {os.cpu_count()} cores: {d4}+{d8} tokens (fastest of three repetitions each) on 4- and 8-layer copies of the {n_layer}-layer model (tensor types of "
-                      f"layers 8..15, embedding + lm_head included) -> {per_layer * 1e3:.2f} ms per layer + {head * 1e3:.2f} ms head, extrapolated linearly to {n_layer} layers "
-                      f"= {spt * 1e3:.0f} ms per token"}
+            "ms_per_token_8_layers": reps8, "ms_per_token_16_layers": reps16,
+            "ms_per_layer": {"difference": round(per_layer * 1e3, 3), "t16_over_16": round(t16 / 16.0 * 1e3, 3), "t8_over_8": round(t8 / 8.0 * 1e3, 3)}, "ms_head_difference_style": round(head * 1e3, 3),
+            "ms_per_token_full_model": {"difference": round(spt_diff * 1e3, 1), "t16_over_16": round(spt_ratio * 1e3, 1)},
+            "value_range": [round(1.0 / max(cands), 3), round(1.0 / min(cands), 3)],
+            "sample_short": f"reference kernels (oracle/_ref), {cores} of {os.cpu_count()} host cores: target-only greedy decode of {d8}+{d16} tokens on 8- and 16-layer copies of the {n_layer}-layer "
+                            f"model, per layer (t16-t8)/8 = {per_layer * 1e3:.2f} ms, head {head * 1e3:.2f} ms, extrapolated to {spt * 1e3:.0f} ms per token",
+            "sample": f"target-only greedy decode, reference kernels on {cores} of the host's {os.cpu_count()} cores: {d8}+{d16} tokens (fastest of three repetitions each) on 8- and 16-layer copies of the "
+                      f"{n_layer}-layer model (tensor types of layers 8..15 / 8..23, embedding + lm_head included; 4.5 and 8.6 GB of weights per token, both beyond any cache) -> difference style "
+                      f"{per_layer * 1e3:.2f} ms per layer + {head * 1e3:.2f} ms head = {spt_diff * 1e3:.0f} ms per token; ratio style t16/16 = {t16 / 16.0 * 1e3:.2f} ms per layer = {spt_ratio * 1e3:.0f} ms per token"}
 
 
 def lossless_diagnostic(ct, prompt, ref_tokens, spec_tokens, n_predict):
@@ -196,14 +221,98 @@ FAMILY_KERNELS = {"matvec_nt1": "k_mmvq_kq / k_mmvq_kq2 / k_mmvq_q0r (VALU mat-v
                   "act_quant": "k_act_quant", "attention": "k_attention", "other": "k_get_rows, k_rope_kv, k_topk1/2, k_norm, k_add, ..."}
 
 
+LINE_BUDGET = 4000             # the ONE stdout line stays below this many characters: the driver keeps an ~8.5 KB tail of the output and must be able to parse it
+
+
+def _short(text, n=240):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(out, detail_path=None):
+    """The ONE JSON line of the bench contract, kept small (< LINE_BUDGET characters) whatever the size of the tables behind it: headline keys, `roofline` of the dominant
+    kernel family with `by_family` reduced to {share, frac}, the whole-call figures, `cpu_baseline` with a one-sentence sample.  Everything else — `per_instance`, the full
+    `by_family`, cancel / segment statistics, per-stage tables of the N > 1 job — goes to the detail file (and to stderr)."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "acceptance",
+           "lossless_vs_target_only", "ttft_s", "itl_s", "encode_tps", "transport", "hop", "devices_shared")
+    line = {k: out[k] for k in top if k in out}
+    if isinstance(line.get("config"), dict):
+        cfg = dict(line["config"])
+        if not any((cfg.get("driver_additions") or {}).values()):           # all zero (the reference-faithful driver): said once, in the detail file
+            cfg.pop("driver_additions", None)
+        for k, v in list(cfg.items()):
+            if isinstance(v, str):
+                cfg[k] = _short(v, 160)
+        line["config"] = cfg
+    if isinstance(line.get("acceptance"), dict):
+        keep = ("accepted_draft_tokens", "drafted_tokens", "rate", "reference_formula_pct", "spec_runs", "nonspec_runs", "canceled_runs", "runs_skipped_by_stages")
+        line["acceptance"] = {k: v for k, v in line["acceptance"].items() if k in keep}
+    if out.get("first_difference"):
+        fd = out["first_difference"]
+        line["first_difference"] = {k: fd.get(k) for k in ("token_index", "gap", "near_tie")}
+    if "other_schedules" in out:
+        line["other_schedules"] = {name: {"tokens_per_s": s_.get("tokens_per_s"), "lossless_vs_target_only": s_.get("lossless_vs_target_only")} for name, s_ in out["other_schedules"].items()}
+    r = out.get("roofline") or {}
+    keys = ("bound", "kernel", "family", "achieved", "peak", "unit", "frac", "traffic", "traffic_fetch_over_alg", "avg_launch_us", "alg_bytes_per_launch", "launches",
+            "aborted_launches", "share_of_gpu_time", "kernel_src_sha16", "target_decode_call", "target_all_calls", "draft_decode_call", "target_passes")
+    rl = {k: r[k] for k in keys if k in r}
+    if isinstance(rl.get("kernel"), str):
+        rl["kernel"] = _short(rl["kernel"], 80)
+    if "by_family" in r:
+        rl["by_family"] = {name: {"share": f.get("share_of_gpu_time"), "frac": f.get("frac")} for name, f in r["by_family"].items()}
+    if "stages" in r:                                                        # N > 1: one short row per stage
+        rl["stages"] = [{"rank": s_.get("rank"), "layers": s_.get("layers"), "gpu_ms_per_call": s_.get("gpu_ms_per_call"), "frac": round(s_.get("GBps", 0.0) / HBM_PEAK_GBS, 4)} for s_ in r["stages"]]
+    line["roofline"] = rl
+    if "cpu_baseline" in out:
+        c = out["cpu_baseline"]
+        line["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "host_cores", "value_range") if k in c}
+        if isinstance(line["cpu_baseline"].get("value"), float):
+            line["cpu_baseline"]["value"] = round(line["cpu_baseline"]["value"], 4)
+        line["cpu_baseline"]["sample"] = _short(c.get("sample_short") or c.get("sample", ""), 260)
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line)
+    if len(text) > LINE_BUDGET:                                              # never grow past the budget: shed the optional parts, least important first
+        for victim in ("first_difference", "other_schedules", "acceptance"):
+            line.pop(victim, None)
+            text = json.dumps(line)
+            if len(text) <= LINE_BUDGET:
+                break
+    if len(text) > LINE_BUDGET:
+        for victim in ("by_family", "stages", "target_passes", "target_all_calls", "draft_decode_call"):
+            line["roofline"].pop(victim, None)
+            text = json.dumps(line)
+            if len(text) <= LINE_BUDGET:
+                break
+    return text
+
+
+def emit(out, detail_path):
+    """full result -> detail file (+ stderr, BEFORE the line: whoever keeps a tail of the combined output still ends on the line); compact line -> stdout, last"""
+    full = json.dumps(out)
+    written = None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                f.write(full + "\n")
+            written = detail_path
+        except OSError as e:
+            print(f"[bench] could not write the detail file {detail_path}: {e}", file=sys.stderr)
+    print("[bench detail] " + full, file=sys.stderr)
+    sys.stderr.flush()
+    print(compact_line(out, written))
+    sys.stdout.flush()
+
+
 class KtRow(C.Structure):          # struct pi_kt_row (include/pipeinfer_ops.h)
-    _fields_ = [("family", C.c_int32), ("type", C.c_int32), ("n_tok", C.c_int32), ("pad_", C.c_int32), ("shape_bytes", C.c_uint64), ("launches", C.c_uint64),
+    _fields_ = [("family", C.c_int32), ("type", C.c_int32), ("n_tok", C.c_int32), ("sampled_dropped", C.c_int32), ("shape_bytes", C.c_uint64), ("launches", C.c_uint64),
                 ("bytes_total", C.c_double), ("sampled", C.c_uint64), ("avg_us", C.c_double), ("avg_sampled_bytes", C.c_double)]
 
 
 def _rows(buf, n):
     return [{"family": r.family, "type": r.type, "n_tok": r.n_tok, "shape_bytes": int(r.shape_bytes), "launches": int(r.launches), "bytes_total": float(r.bytes_total),
-             "sampled": int(r.sampled), "avg_us": float(r.avg_us), "avg_sampled_bytes": float(r.avg_sampled_bytes)} for r in buf[:n]]
+             "sampled": int(r.sampled), "sampled_dropped": int(r.sampled_dropped), "avg_us": float(r.avg_us), "avg_sampled_bytes": float(r.avg_sampled_bytes)} for r in buf[:n]]
 
 
 def timing_rows(lib):
@@ -226,15 +335,32 @@ def launch_rows(lib, ctx):
     return _rows(buf, lib.pipeinfer_get_launch_rows(ctx.h, buf, 4096))
 
 
+def aborted_launches(lib, ctx):
+    """launches of the context since its reset_stats() that found their run cancelled and returned on entry (device-side counters beside the abort word), per family index"""
+    lib.pipeinfer_get_aborted_launches.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.pipeinfer_get_aborted_launches.restype = C.c_int
+    buf = (C.c_uint64 * 8)()
+    n = lib.pipeinfer_get_aborted_launches(ctx.h, buf, 8)
+    return {i: int(buf[i]) for i in range(max(0, n))}
+
+
 def family_of(r):
     f = FAMILIES.get(r["family"], "other")
     return ("matvec_nt1" if r["n_tok"] == 1 else "matvec_multi") if f == "matvec" else f
 
 
-def roofline_tables(counts, samples):
-    """counts: the launches of the TIMED region (graph contents x replays + eager launches); samples: per-instance durations of the graphs-off replay of the same schedule.
+def roofline_tables(counts, samples, aborted=None):
+    """counts: the launches of the TIMED region (graph contents x replays + eager launches); samples: per-instance durations of the graphs-off replay of the same schedule
+    (launches that did the work: the sampler leaves out the ones that found their run aborted, `sampled_dropped`).
     An instance = (family, weight type, tokens of the launch, launch shape).  Estimated GPU time of an instance in the timed region = its launches there x the replay's
-    average duration of the same instance (the nearest width of the same launch shape when that exact width did not occur in the replay)."""
+    average duration of the same instance (the nearest width of the same launch shape when that exact width did not occur in the replay).
+    aborted: {family index: launches of the timed region that returned on entry because their run had been cancelled} — kept apart: they are taken out of the family's
+    launches (pro rata over its instances: the device counts them per family) instead of being priced with full bytes and a full duration."""
+    aborted = aborted or {}
+    fam_launches = {}
+    for c in counts:
+        fam_launches[c["family"]] = fam_launches.get(c["family"], 0) + c["launches"]
+    live = {f: max(0.0, 1.0 - aborted.get(f, 0) / n) if n else 1.0 for f, n in fam_launches.items()}      # fraction of a family's launches that did the work
     by_key = {}
     for r in samples:
         if r["sampled"]:
@@ -255,23 +381,46 @@ def roofline_tables(counts, samples):
         avg_us = smp["avg_us"] if smp else None
         # attention: a captured graph is launched with n_kv = n_ctx and reads the real n_kv on the device: price it with the bytes of the sampled (eager) launches
         bytes_per = (smp["avg_sampled_bytes"] if (smp and c["family"] == 5) else c["bytes_total"] / c["launches"])
+        n_live = c["launches"] * live.get(c["family"], 1.0)                  # launches that did the work
         row = {"family": family_of(c), "type": TYPE_NAMES.get(c["type"], "-") if c["family"] <= 1 else "-", "n_tok": c["n_tok"], "launch_MB": round(c["shape_bytes"] / 1e6, 2) if c["shape_bytes"] else None,
                "launches": c["launches"], "alg_bytes_per_launch": round(bytes_per), "avg_us": round(avg_us, 3) if avg_us else None, "duration_from": how if smp else "not sampled",
-               "GBps": round(bytes_per / (avg_us * 1e-6) / 1e9, 1) if avg_us else None, "est_gpu_ms": round(c["launches"] * avg_us * 1e-3, 3) if avg_us else None}
+               "samples": smp["sampled"] if smp else 0, "samples_left_out_as_aborted": smp.get("sampled_dropped", 0) if smp else 0,
+               "GBps": round(bytes_per / (avg_us * 1e-6) / 1e9, 1) if avg_us else None, "est_gpu_ms": round(n_live * avg_us * 1e-3, 3) if avg_us else None}
         inst.append(row)
-        f = fam.setdefault(row["family"], {"launches": 0, "launches_priced": 0, "alg_bytes": 0.0, "est_gpu_ms": 0.0})
+        f = fam.setdefault(row["family"], {"launches": 0, "launches_priced": 0, "alg_bytes": 0.0, "est_gpu_ms": 0.0, "aborted": 0, "live": 0.0})
         f["launches"] += c["launches"]
+        f["aborted"] = min(aborted.get(c["family"], 0), fam_launches.get(c["family"], 0))
         if avg_us:
-            f["launches_priced"] += c["launches"]; f["alg_bytes"] += bytes_per * c["launches"]; f["est_gpu_ms"] += c["launches"] * avg_us * 1e-3
+            f["launches_priced"] += c["launches"]; f["live"] += n_live; f["alg_bytes"] += bytes_per * n_live; f["est_gpu_ms"] += n_live * avg_us * 1e-3
     total_ms = sum(f["est_gpu_ms"] for f in fam.values()) or 1.0
     out = {}
     for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["est_gpu_ms"]):
         gbps = f["alg_bytes"] / max(1e-12, f["est_gpu_ms"] * 1e-3) / 1e9
-        out[name] = {"kernels": FAMILY_KERNELS.get(name, name), "launches": f["launches"], "launches_priced": f["launches_priced"], "est_gpu_ms": round(f["est_gpu_ms"], 2),
-                     "share_of_gpu_time": round(f["est_gpu_ms"] / total_ms, 4), "alg_bytes_per_launch": round(f["alg_bytes"] / max(1, f["launches_priced"])),
-                     "avg_launch_us": round(1e3 * f["est_gpu_ms"] / max(1, f["launches_priced"]), 3), "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4)}
+        # (the one-token and the multi-token VALU mat-vecs share a device counter: `aborted_launches` of either is the kernel family's)
+        out[name] = {"kernels": FAMILY_KERNELS.get(name, name), "launches": f["launches"], "launches_priced": f["launches_priced"], "aborted_launches": f["aborted"], "est_gpu_ms": round(f["est_gpu_ms"], 2), "alg_GB": round(f["alg_bytes"] / 1e9, 3),
+                     "share_of_gpu_time": round(f["est_gpu_ms"] / total_ms, 4), "alg_bytes_per_launch": round(f["alg_bytes"] / max(1e-9, f["live"])),
+                     "avg_launch_us": round(1e3 * f["est_gpu_ms"] / max(1e-9, f["live"]), 3), "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4)}
     inst.sort(key=lambda r: -(r["est_gpu_ms"] or 0.0))
     return out, inst
+
+
+def merge_family_tables(tables):
+    """by_family tables of several stages (N > 1: one per stage, each priced with its own GPU's durations) -> one table: bytes and GPU time add up, the rate is their ratio"""
+    acc = {}
+    for t in tables:
+        for name, f in t.items():
+            a = acc.setdefault(name, {"kernels": f["kernels"], "launches": 0, "launches_priced": 0, "aborted_launches": 0, "est_gpu_ms": 0.0, "alg_GB": 0.0, "live": 0.0})
+            a["launches"] += f["launches"]; a["launches_priced"] += f["launches_priced"]; a["aborted_launches"] += f["aborted_launches"]
+            a["est_gpu_ms"] += f["est_gpu_ms"]; a["alg_GB"] += f["alg_GB"]
+            a["live"] += 1e3 * f["est_gpu_ms"] / f["avg_launch_us"] if f["avg_launch_us"] else 0.0
+    total = sum(a["est_gpu_ms"] for a in acc.values()) or 1.0
+    out = {}
+    for name, a in sorted(acc.items(), key=lambda kv: -kv[1]["est_gpu_ms"]):
+        gbps = a["alg_GB"] / max(1e-12, a["est_gpu_ms"] * 1e-3)
+        out[name] = {"kernels": a["kernels"], "launches": a["launches"], "launches_priced": a["launches_priced"], "aborted_launches": a["aborted_launches"], "est_gpu_ms": round(a["est_gpu_ms"], 2),
+                     "alg_GB": round(a["alg_GB"], 3), "share_of_gpu_time": round(a["est_gpu_ms"] / total, 4), "alg_bytes_per_launch": round(1e9 * a["alg_GB"] / max(1e-9, a["live"])),
+                     "avg_launch_us": round(1e3 * a["est_gpu_ms"] / max(1e-9, a["live"]), 3), "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def default_coalesce(n_draft):
@@ -336,6 +485,8 @@ def main():
     ap.add_argument("--max-inflight", type=int, default=0)
     ap.add_argument("--adaptive-window", type=int, default=0, help="our adaptive draft pause (0: off = the reference behaviour)")
     ap.add_argument("--adaptive-pause", type=int, default=0)
+    ap.add_argument("--detail", default=os.environ.get("PIPEINFER_BENCH_DETAIL", "/tmp/pipeinfer_bench_detail.json"),
+                    help="where the full result (per-instance table, every family, cancel / segment statistics) is written; the stdout line stays small")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -418,6 +569,7 @@ def main():
     t_total = time.time() - t_start
     timed_counts = launch_rows(lib, ct) + [r for r in timing_rows(lib)]            # target graphs + whatever ran eagerly (both contexts when graphs are off)
     draft_counts = launch_rows(lib, cd)
+    timed_aborted = aborted_launches(lib, ct)                                      # launches of cancelled runs that returned on entry: not priced as work
     lib.pi_kernel_timing(0, 8)
     st_t, st_d = ct.stats(), cd.stats()                 # per-call GPU time and bytes of the timed steps only
     main_sum = summarize(results)
@@ -450,7 +602,7 @@ def main():
     samples = timing_rows(lib)
     lib.pi_kernel_timing(0, 8)
     # the kernel FAMILY the timed region spent most GPU time in: its launches there (counts) x the replay's per-instance durations
-    by_family, table = roofline_tables(timed_counts, samples)
+    by_family, table = roofline_tables(timed_counts, samples, timed_aborted)
     dom_name = next(iter(by_family), None)
     if dom_name:
         dom = by_family[dom_name]
@@ -460,9 +612,11 @@ def main():
         traffic = round(tr["fetch_over_alg"] * dom["alg_bytes_per_launch"]) if tr else None
         roofline = {"bound": "hbm", "kernel": dom["kernels"], "family": dom_name, "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                     "traffic": traffic, "traffic_fetch_over_alg": tr["fetch_over_alg"] if tr else None, "traffic_source": traffic_src, "kernel_src_sha16": kernel_source_sha(),
-                    "avg_launch_us": dom["avg_launch_us"], "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "launches": dom["launches"],
+                    "avg_launch_us": dom["avg_launch_us"], "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "launches": dom["launches"], "aborted_launches": dom["aborted_launches"],
                     "share_of_gpu_time": dom["share_of_gpu_time"],
-                    "how": "launch counts and algorithmic bytes: the timed region's own (captured graphs x replays); durations: HIP-event samples of a graphs-off replay of the same schedule, per instance"}
+                    "how": "launch counts and algorithmic bytes: the timed region's own (captured graphs x replays) minus the launches that returned on entry because their run had been "
+                           "cancelled (device-side counters per family); durations: HIP-event samples of a graphs-off replay of the same schedule, per instance, launches that did the work only "
+                           "(samples below a third of the instance's median are left out and counted)"}
     else:
         roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
     roofline["by_family"] = by_family
@@ -519,7 +673,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tspec, tft, tgt_path, args.cache, args.signal, args.noise, args.cpu_tokens)
         except Exception as e:  # the GPU result stands on its own; say why the CPU leg is missing
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": repr(e)}
-    print(json.dumps(out))
+    emit(out, args.detail)
 
 
 if __name__ == "__main__":

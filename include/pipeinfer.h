@@ -113,6 +113,8 @@ struct pipeinfer_transport_stats {
     uint64_t flag_runs;                                /* stage: runs that waited for their activations on the device */
     double   flag_wait_gpu_ms;                         /* stage: GPU time those runs' wait kernels spent waiting for their input (pipeline fill + the upstream stage's compute) */
     double   flag_seen_us;                             /* stage: sum over those runs of (flag seen by the waiting kernel - flag stamped by the producing stream), device clock: valid between stages on ONE device */
+    int32_t  hop_store_kernel;                         /* stage: 1 = the activations are stored by a kernel of the producing stream (device rings), 0 = by hipMemcpyAsync (host rings, PIPEINFER_HOP_STORE=memcpy); decided and logged at set-up */
+    int32_t  ring_alloc;                               /* stage: this stage's activation ring: 0 none (first stage / host rings), 1 coarse-grained hipMalloc, 2 fine-grained, 3 uncached device memory */
 };
 /* stage compute behind the transport when it is not a llama_context of this library (the CPU tests plug the oracle in here):
  * 0 = computed, 1 = dropped, < 0 error; x_in / x_out are host pointers when the transport runs on host rings */
@@ -162,7 +164,10 @@ struct pipeinfer_stats {
     uint64_t weight_copy_bytes;  /* HBM held by the tile-major copies of the matrix-core kernel (0 for contexts with n_batch <= 2: they are not made) */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
-LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);
+LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);    /* call with no run in flight (it also zeroes the device-side running sums) */
+/* launches since pipeinfer_reset_stats that found their run cancelled (llama_cancel_run after the start, llama.cpp:9981-9993) and returned on entry — what a cancelled run
+ * stops doing (llama.cpp:5665-5687) — per kernel family (index = pi_kt_row.family in pipeinfer_ops.h).  Returns the families written (<= cap), -1 on error */
+LLAMA_API int  pipeinfer_get_aborted_launches(struct llama_context * ctx, uint64_t * out, int cap);
 
 /* ---- host KV-cell table on its own (no GPU needed): used by the CPU tests ---- */
 typedef struct pi_kvcells pi_kvcells;

@@ -46,11 +46,14 @@ PI_API int     pi_stream_sync(void * stream);
 PI_API int     pi_device_sync(void);
 
 /* Kernel-granular early cancellation (reference: the abort callback polled between graph nodes, ggml.c:15748-15811, llama.cpp:5614-5628, 5665-5687).
- * word_dev: one int32 per context in device memory holding (run id << 1 | aborted).  Every hot-path kernel launched — or captured into a
+ * word_dev: the first int32 of a 64-byte block in device memory (zeroed by the owner) holding (run id << 1 | aborted); words 8..14 of the block count, per kernel family
+ * (enum order of pi_kt_row.family), the launches that found the run aborted and returned on entry.  Every hot-path kernel launched — or captured into a
  * graph — by the calling thread after pi_set_abort_word(word_dev) reads it on entry and returns at once when bit 0 is set (NULL: no check).
  *   pi_op_abort_begin   (in stream order, ahead of a run's kernels)  word = run_id << 1 | (*host_flag != 0); host_flag: pinned host memory, nullable
  *   pi_op_abort_cancel  (any stream, any time)                        if word == run_id << 1 then word |= 1: only the run that is executing NOW is hit */
 PI_API void    pi_set_abort_word(const int32_t * word_dev);
+/* launch accounting only: the attention launches of the calling thread are priced with n_kv cells from now on (0: with the n_kv they are launched with) */
+PI_API void    pi_set_account_n_kv(int n_kv);
 /* launches of the calling thread from now on go to a stream restricted to `n` compute units (hipExtStreamCreateWithCUMask): the launchers size "one round of workgroups" for it (0 / 256: the whole chip) */
 PI_API void    pi_set_cu_count(int n);
 PI_API int     pi_op_abort_begin(int32_t * word_dev, int32_t run_id, const int32_t * host_flag, void * stream);
@@ -74,7 +77,7 @@ PI_API int     pi_op_abort_begin_wait(int32_t * word_dev, int32_t run_id, const 
  * pi_kernel_timing(1, N) opens a window: every eager launch is counted with its algorithmic bytes and every Nth launch of an instance is timed (HIP events of
  * hipExtLaunchKernelGGL = the kernel's own begin / end timestamps); pi_kernel_timing_rows reads the window after a device sync.  Launches captured into a HIP graph are
  * counted per graph instead (pipeinfer_get_launch_rows in pipeinfer.h: graph contents x replays). */
-struct pi_kt_row { int32_t family, type, n_tok, pad_; uint64_t shape_bytes; /* mat launches: algorithmic bytes of this launch shape (0 for the other families) */
+struct pi_kt_row { int32_t family, type, n_tok, sampled_dropped; /* timed launches left out of avg_us: below a third of the median (they found their run aborted) */ uint64_t shape_bytes; /* mat launches: algorithmic bytes of this launch shape (0 for the other families) */
                    uint64_t launches; double bytes_total; uint64_t sampled; double avg_us, avg_sampled_bytes; };
 PI_API void    pi_kernel_timing(int on, int sample_every);
 PI_API int     pi_kernel_timing_rows(struct pi_kt_row * out, int cap);

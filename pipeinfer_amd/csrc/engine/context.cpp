@@ -391,7 +391,8 @@ static bool launch_abort_begin(llama_context * ctx, int32_t run_id) {
 }
 // segment `seg` of the forward pass: every per-call quantity (tokens, positions, mask, kv_head, n_kv) lives in device memory that
 // launch_inputs refreshed, so replaying the captured graph IS this call's segment
-static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out, bool multi = false, bool capture_only = false) {
+// acct_n_kv: the cells the pass really attends over (launch accounting of eager launches only; the kernels read n_kv from dyn_dev)
+static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int seg, pi_kt_sink ** sink_out, bool multi = false, bool capture_only = false, int acct_n_kv = 0) {
     const bool tracing = trace_enabled();
     pi_set_cu_count(ctx->cu_hi > ctx->cu_lo ? ctx->cu_hi - ctx->cu_lo : 0);     // (thread-local: the launchers of this thread size their grids for the CUs this context's stream may use)
     const int nseg = n_segments(ctx);
@@ -400,7 +401,9 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
     const bool head = seg == 0, tail = seg == nseg - 1;
     hipStream_t s = ctx->stream;
     if (ctx->use_graphs && !tracing) {
-        llama_context::graph_entry & ge = ctx->graphs[std::make_pair(n_tokens, 2 * seg + (multi ? 1 : 0))];     // (passes of several runs: their own graphs — per-token n_kv in the attention launches)
+        llama_context::graph_entry * gep = nullptr;
+        { std::lock_guard<std::mutex> glk(ctx->graphs_mu); gep = &ctx->graphs[std::make_pair(n_tokens, 2 * seg + (multi ? 1 : 0))]; }     // (passes of several runs: their own graphs — per-token n_kv in the attention launches)
+        llama_context::graph_entry & ge = *gep;
         bool ok = true;
         if (!ge.exec) {
             // One capture at a time in the process, and a few attempts: on this runtime a capture (thread-local mode) is now and then invalidated by what ANOTHER
@@ -433,7 +436,9 @@ static bool launch_segment(llama_context * ctx, int n_tokens, int kv_head, int s
     }
     if (capture_only) return true;
     pi_set_abort_word(abort_checks_on() ? ctx->abort_dev : nullptr);
+    pi_set_account_n_kv(acct_n_kv);
     const bool fwd = forward(ctx, n_tokens, kv_head, ctx->n_ctx, la, lb, head, tail, multi);
+    pi_set_account_n_kv(0);
     pi_set_abort_word(nullptr);
     return fwd;
 }
@@ -458,7 +463,8 @@ static bool launch_outputs(llama_context * ctx, pi_run * run) {
 static bool launch_forward(llama_context * ctx, int n_tokens, const void * meta, const float * x_in, pi_kt_sink ** sink_out) {
     if (!launch_inputs(ctx, n_tokens, meta, x_in)) return false;
     const int kv_head = ((const int32_t *) meta)[2 * n_tokens];
-    for (int seg = 0, n = n_segments(ctx); seg < n; seg++) if (!launch_segment(ctx, n_tokens, kv_head, seg, sink_out)) return false;
+    const int n_kv = ((const int32_t *) meta)[2 * n_tokens + 1];
+    for (int seg = 0, n = n_segments(ctx); seg < n; seg++) if (!launch_segment(ctx, n_tokens, kv_head, seg, sink_out, false, false, n_kv)) return false;
     return true;
 }
 
@@ -570,7 +576,7 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
             (void) yield_to_urgent(ctx);
             if (runs_cancelled(runs)) break;                                    // llama_cancel_run reached every run of the pass while it was in flight
             ok = launch_abort_begin(ctx, pass->id);
-            if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink, runs.size() > 1);
+            if (ok) ok = launch_segment(ctx, n, kv_head, seg, &runs[0]->sink, runs.size() > 1, false, pass->n_kv);
             if (ok) ok = hipEventRecord(seg_done[seg & 1], ctx->stream) == hipSuccess;
         }
         for (pi_run * r : runs) r->segments_run = seg;
@@ -826,10 +832,19 @@ bool context_wait(llama_context * ctx, pi_run * run) {
 __global__ void __launch_bounds__(256) k_hop_store(const uint4 * __restrict__ src, uint4 * __restrict__ dst, size_t n16) {
     for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t) gridDim.x * 256) dst[i] = src[i];
 }
+// How the store is done is decided ONCE, at the transport's set-up, from what the transport knows about its rings (hop_store_set_mode: 1 = kernel, both ends are device
+// memory — this stage's HBM and the peer mapping of the next stage's ring; 2 = hipMemcpyAsync, host rings) and logged there per rank.  Mode 0 (no transport: the in-process
+// stage chains of the tests) asks the runtime what the two pointers are; hipPointerGetAttributes on an IPC-mapped peer pointer is not something to rely on silently.
+static std::atomic<int> g_hop_store_mode{0};
+void hop_store_set_mode(int mode) { g_hop_store_mode.store(mode == 1 || mode == 2 ? mode : 0); }
+int hop_store_mode() { return g_hop_store_mode.load(); }
 bool hop_store(void * dst, const void * src, size_t bytes, hipStream_t s) {
     static const bool by_memcpy = getenv("PIPEINFER_HOP_STORE") && !strcmp(getenv("PIPEINFER_HOP_STORE"), "memcpy");
     bool dev = false;
-    if (!by_memcpy && bytes % 16 == 0 && (((uintptr_t) dst | (uintptr_t) src) & 15) == 0) {
+    const int mode = g_hop_store_mode.load(std::memory_order_relaxed);
+    const bool aligned = bytes % 16 == 0 && (((uintptr_t) dst | (uintptr_t) src) & 15) == 0;
+    if (mode == 1) dev = !by_memcpy && aligned;
+    else if (mode == 0 && !by_memcpy && aligned) {
         hipPointerAttribute_t a, b;                                             // both ends in device memory (the staged transport hands over host buffers)
         if (hipPointerGetAttributes(&a, dst) == hipSuccess && hipPointerGetAttributes(&b, src) == hipSuccess) dev = a.type == hipMemoryTypeDevice && b.type == hipMemoryTypeDevice;
         else (void) hipGetLastError();
@@ -884,7 +899,7 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
             if (seg >= 2) (void) hipEventSynchronize(ctx->seg_events[seg & 1]);
             if (seg > 0 && should_abort(abort_user)) { cut = true; break; }
             if (!(flag_in && seg == 0)) ok = launch_abort_begin(ctx, rid);      // (the wait kernel armed the word for the first segment; later ones keep an abort it carries)
-            if (ok) ok = launch_segment(ctx, n_tokens, kv_head, seg, nullptr);
+            if (ok) ok = launch_segment(ctx, n_tokens, kv_head, seg, nullptr, false, false, ((const int32_t *) meta)[2 * n_tokens + 1]);
             if (ok) ok = hipEventRecord(ctx->seg_events[seg & 1], s) == hipSuccess;
         }
         ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
@@ -906,7 +921,10 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     (void) hipEventRecord(e1, s);
     if (ok && flag_in)                                                          // what the wait saw (time-out, clock ticks) and the abort word the run ended with
         ok = hipMemcpyAsync(ctx->hop_host, ctx->hop_dev, 32, hipMemcpyDeviceToHost, s) == hipSuccess && hipMemcpyAsync(ctx->hop_host + 32, ctx->abort_dev, 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (ok) ok = hipStreamSynchronize(s) == hipSuccess;
+    // a failed launch leaves the wait kernel (and whatever was enqueued) on the stream: raise the run's host flag — the wait kernel polls it — and always drain the stream
+    // before the events are destroyed and the caller closes the transport (it used to return at once and the wait could spin for its whole time-out)
+    if (!ok && ctx->abort_host) ctx->abort_host[rid & 255] = 1;
+    if (hipStreamSynchronize(s) != hipSuccess) ok = false;
     ctx->stage_run_id.store(0);
     // cancelled while its (last) kernels were enqueued: they returned on entry, what the copies above moved is not a result
     if (ok && !cut && ((ctx->abort_host && ctx->abort_host[rid & 255]) || (should_abort && should_abort(abort_user)))) cut = true;

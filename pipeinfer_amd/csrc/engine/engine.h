@@ -161,6 +161,7 @@ struct llama_context {
     int32_t * tokens_dev = nullptr, * pos_dev = nullptr, * dyn_dev = nullptr; uint32_t * mask_dev = nullptr;
     struct graph_entry { hipGraphExec_t exec = nullptr; pi_kt_sink sink; std::atomic<uint64_t> replays{0}; };     // sink: what the graph launches (kernel_timing.h); replays since the last reset_stats
     std::map<std::pair<int, int>, graph_entry> graphs;   // one captured graph per (n_tokens, segment) (kv_head / n_kv come from dyn_dev)
+    std::mutex graphs_mu;                    // the map itself (lookups / first-use inserts by the launching thread, the statistics readers on the caller's thread); entries are stable
     bool use_graphs = true;
     // Segmented launch (pipeinfer_context_set_segments): the stage's layers are captured as segments of `seg_layers` layers and a feeder
     // thread enqueues them one or two ahead of the GPU.  Between segments it (a) drops the rest of a run that has been cancelled meanwhile
@@ -237,5 +238,7 @@ int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta
                int (*should_abort)(void *) = nullptr, void * abort_user = nullptr, const pi_stage_hop * hop = nullptr);        // 0 done, 1 cut short (should_abort, a cancel, or upstream), < 0 error
 void stage_abort_run(llama_context * ctx, int32_t run_id);                  // any thread: run `run_id` (ctx->stage_run_id while stage_run computes it) returns from every kernel on entry from now on; no effect on any other run
 bool hop_store(void * dst, const void * src, size_t bytes, hipStream_t s);        // context.cpp: a stage's activations into the consumer's ring slot (kernel store for device memory)
+void hop_store_set_mode(int mode);                                               // 1: always the kernel (device rings), 2: always hipMemcpyAsync (host rings), 0: ask the runtime per call (no transport)
+int  hop_store_mode();
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv);
 }

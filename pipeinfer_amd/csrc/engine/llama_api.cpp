@@ -288,6 +288,7 @@ extern "C" int pipeinfer_context_set_coalescing(struct llama_context * ctx, int 
 // launches of this context's captured graphs since pipeinfer_reset_stats: graph contents x replays, one row per instance (family, type, tokens, launch shape)
 extern "C" int pipeinfer_get_launch_rows(struct llama_context * ctx, struct pi_kt_row * out, int cap) {
     std::map<std::tuple<int, int, int, uint64_t>, std::pair<uint64_t, double>> tab;
+    std::lock_guard<std::mutex> glk(ctx->graphs_mu);                          // (the feeder thread inserts a graph the first time it meets a pass width)
     for (auto & kv : ctx->graphs) {
         const uint64_t rep = kv.second.replays.load(std::memory_order_relaxed);
         if (!rep) continue;
@@ -300,7 +301,7 @@ extern "C" int pipeinfer_get_launch_rows(struct llama_context * ctx, struct pi_k
     for (auto & kv : tab) {
         if (n >= cap) break;
         pi_kt_row & r = out[n++];
-        r.family = std::get<0>(kv.first); r.type = std::get<1>(kv.first); r.n_tok = std::get<2>(kv.first); r.pad_ = 0; r.shape_bytes = std::get<3>(kv.first);
+        r.family = std::get<0>(kv.first); r.type = std::get<1>(kv.first); r.n_tok = std::get<2>(kv.first); r.sampled_dropped = 0; r.shape_bytes = std::get<3>(kv.first);
         r.launches = kv.second.first; r.bytes_total = kv.second.second; r.sampled = 0; r.avg_us = 0.0; r.avg_sampled_bytes = 0.0;
     }
     return n;
@@ -383,7 +384,24 @@ extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer
     out->n_passes = ctx->stat_passes; out->n_pass_runs = ctx->stat_pass_runs; out->n_pass_tokens = ctx->stat_pass_tokens; out->n_coalesced_passes = ctx->stat_coalesced_passes;
     out->weight_copy_bytes = ctx->model->hbm_copy_bytes;
 }
-extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0; for (auto & kv : ctx->graphs) kv.second.replays.store(0); }
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0;
+    { std::lock_guard<std::mutex> glk(ctx->graphs_mu); for (auto & kv : ctx->graphs) kv.second.replays.store(0); }
+    // device-side running sums: aborted launches per kernel family (words 8..14 of the abort block), the arrival-flag clock ticks of a pipeline stage.  Call with no run in flight.
+    if (ctx->abort_dev && ctx->stream) { (void) hipMemsetAsync(ctx->abort_dev + 8, 0, 8 * sizeof(int32_t), ctx->stream); (void) hipStreamSynchronize(ctx->stream); }
+    if (ctx->hop_dev && ctx->stream) { (void) hipMemsetAsync(ctx->hop_dev, 0, 64, ctx->stream); (void) hipStreamSynchronize(ctx->stream); }
+    ctx->stat_flag_seen_us = 0.0; ctx->stat_flag_wait_ms = 0.0; ctx->stat_flag_runs = 0;
+}
+// launches of this context since pipeinfer_reset_stats that found their run aborted (llama_cancel_run after the start) and returned on entry, per kernel family
+// (index = pi_kt_row.family); synchronises the context's control stream.  Returns the number of families written (<= cap), -1 on error
+extern "C" int pipeinfer_get_aborted_launches(struct llama_context * ctx, uint64_t * out, int cap) {
+    const int n = std::min(cap, (int) PI_KT_NFAM);
+    for (int i = 0; i < n; i++) out[i] = 0;
+    if (!ctx->abort_dev) return n;
+    int32_t h[8] = { 0 };
+    if (hipMemcpy(h, ctx->abort_dev + 8, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    for (int i = 0; i < n; i++) out[i] = (uint64_t) (uint32_t) h[i];
+    return n;
+}
 
 // ---- stand-alone KV-cell table (host logic tests) ---------------------------------------------------------------------------------
 struct pi_kvcells { pi::kv_cells cells; explicit pi_kvcells(int n) : cells(n) {} };

@@ -42,6 +42,8 @@ constexpr int TP_RES_SLOTS = 4;                  // result slots (last stage -> 
 constexpr int TP_CANCEL_CAP = 8192;
 enum { KIND_RUN = 1, KIND_SHUTDOWN = 2 };
 enum { F_SKIPPED = 1 };
+enum ring_alloc_kind { RING_NONE = 0, RING_COARSE = 1, RING_FINEGRAINED = 2, RING_UNCACHED = 3 };
+const char * ring_alloc_name(int k) { return k == RING_FINEGRAINED ? "fine-grained" : k == RING_UNCACHED ? "uncached" : k == RING_COARSE ? "coarse-grained (hipMalloc)" : "none"; }
 
 struct alignas(64) ring_ctl {
     std::atomic<uint64_t> head;                  // messages produced
@@ -56,6 +58,8 @@ struct stage_block {                             // index = rank
     msg_hdr slots[TP_IN1_SLOTS];                 // ranks >= 2 use the first TP_X_SLOTS
     struct alignas(16) xflag_t { std::atomic<uint32_t> value; uint32_t pad; uint64_t stamp; } xflag[TP_X_SLOTS], xprobe;      // arrival flags of this stage's activation slots (runtime.hip: pi_xflag); xprobe: the set-up probe of that path
     std::atomic<uint32_t> ipc_ready, probe_written, joined, setup_done, flags_done;
+    std::atomic<uint32_t> probe2_armed;                   // coherence probe of the real hop (store + flag against a consumer that has the slot cached and its reader enqueued)
+    std::atomic<int32_t> ring_alloc;             // how this rank's activation ring was allocated (ring_alloc_kind)
     std::atomic<int32_t> device;                 // HIP device ordinal of the rank's process (-1: none)
     char ipc_handle[64];                         // hipIpcMemHandle_t
 };
@@ -92,6 +96,8 @@ struct pipeinfer_transport {
     bool flags_on = false, ctl_registered = false; uint8_t * ctl_dev = nullptr;
     void * flag_dev(int rank_of_consumer, uint64_t k) const { return ctl_dev + ((uint8_t *) &L->st[rank_of_consumer].xflag[k % TP_X_SLOTS] - base); }
     int peer_access = -1;                        // hipDeviceCanAccessPeer(this device, next stage's device); -1: not asked
+    int ring_alloc = RING_NONE;                  // this stage's own ring
+    int64_t device_wait_us = 600ll * 1000 * 1000; // bound of a run's device-side wait for its activations (its own, generous: a slow but healthy upstream must not kill the job; a cancel, a failure or a dead pipeline end the wait early)
     // head side
     int32_t gen = 0;
     uint64_t started = 0, consumed = 0;
@@ -195,7 +201,24 @@ void setup_device_rings(pipeinfer_transport * tp) {
     if (r >= 1 && (e = hipStreamCreateWithFlags(&tp->copy_stream, hipStreamNonBlocking)) != hipSuccess) { bad("hipStreamCreate", e); return; }
     if (r >= 2) {
         hipIpcMemHandle_t h;
-        if ((e = hipMalloc((void **) &tp->my_ring, L->x_slot_bytes * TP_X_SLOTS)) != hipSuccess) { bad("hipMalloc of the activation ring", e); tp->my_ring = nullptr; }
+        // The ring is written by ANOTHER device (the upstream stage's k_hop_store over xGMI) and read by this one, with a device-side flag in between — no host
+        // synchronisation and no runtime-inserted cache maintenance stands between the remote write and this device's first read of a re-used slot.  Ordinary hipMalloc
+        // memory is coarse-grained: this device may keep lines of the slot's previous contents in its L2, coherent with other agents only at kernel / synchronisation
+        // boundaries the runtime knows about.  Fine-grained device memory is coherent with other agents at system scope DURING a kernel (a peer's release store followed by
+        // this device's system-scope acquire of the flag — k_flag_publish / k_abort_begin_wait — makes the data visible); 128 KB per slot, its bandwidth is irrelevant.
+        // PIPEINFER_RING_ALLOC = finegrained (default) | uncached | coarse.
+        const char * want = getenv("PIPEINFER_RING_ALLOC");
+        int kind = want && !strcmp(want, "coarse") ? RING_COARSE : want && !strcmp(want, "uncached") ? RING_UNCACHED : RING_FINEGRAINED;
+        e = hipSuccess;
+        if (kind != RING_COARSE) {
+            e = hipExtMallocWithFlags((void **) &tp->my_ring, L->x_slot_bytes * TP_X_SLOTS, kind == RING_UNCACHED ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+            if (e == hipSuccess && (e = hipIpcGetMemHandle(&h, tp->my_ring)) != hipSuccess) { (void) hipFree(tp->my_ring); tp->my_ring = nullptr; }      // (must be exportable)
+            if (e != hipSuccess) { (void) hipGetLastError(); fprintf(stderr, "[pipeinfer transport, rank %d] no %s activation ring (%s): falling back to hipMalloc (coarse-grained)\n", r, ring_alloc_name(kind), hipGetErrorString(e)); tp->my_ring = nullptr; kind = RING_COARSE; }
+        }
+        if (kind == RING_COARSE) e = hipMalloc((void **) &tp->my_ring, L->x_slot_bytes * TP_X_SLOTS);
+        tp->ring_alloc = kind; L->st[r].ring_alloc.store(kind);
+        fprintf(stderr, "[pipeinfer transport, rank %d] activation ring on device %d: %s memory, %d slots of %zu bytes\n", r, tp->device, ring_alloc_name(kind), TP_X_SLOTS, (size_t) L->x_slot_bytes);
+        if (e != hipSuccess) { bad("allocation of the activation ring", e); tp->my_ring = nullptr; }
         else if ((e = hipMemset(tp->my_ring, 0, L->x_slot_bytes * TP_X_SLOTS)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) bad("hipMemset of the activation ring", e);
         else if ((e = hipIpcGetMemHandle(&h, tp->my_ring)) != hipSuccess) bad("hipIpcGetMemHandle", e);
         else memcpy(L->st[r].ipc_handle, &h, sizeof h);
@@ -327,6 +350,15 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
     for (int r = 0; r < tp->world; r++)
         if (!tp->wait_for([&] { return L->st[r].setup_done.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never finished the transport set-up"); pipeinfer_transport_close(tp); return nullptr; }
     tp->device_mode = P->device >= 0 && !L->device_fail.load();
+    if (const char * dw = getenv("PIPEINFER_DEVICE_WAIT_MS")) if (atoll(dw) > 0) tp->device_wait_us = atoll(dw) * 1000;
+    if (P->device >= 0 && tp->rank >= 1) {
+        // the hop's store, decided here once and said per rank: a kernel of the producing stream when both ends are device memory (this stage's HBM -> the peer mapping of
+        // the next stage's ring), hipMemcpyAsync when the rings are in host memory.  Nothing is left to hipPointerGetAttributes on an IPC mapping.
+        const bool by_memcpy = getenv("PIPEINFER_HOP_STORE") && !strcmp(getenv("PIPEINFER_HOP_STORE"), "memcpy");
+        pi::hop_store_set_mode(tp->device_mode ? 1 : 2);
+        fprintf(stderr, "[pipeinfer transport, rank %d] hop store: %s (%s rings%s)\n", tp->rank, tp->device_mode && !by_memcpy ? "kernel of the producing stream (k_hop_store)" : "hipMemcpyAsync",
+                tp->device_mode ? "device" : "host", by_memcpy ? ", PIPEINFER_HOP_STORE=memcpy" : "");
+    }
     // Arrival flags (stage ranks, device mode; PIPEINFER_TRANSPORT_FLAGS=0: the host-published headers of round 3): the segment's control block is page-locked and mapped, so
     // that the producing stage's stream can write a flag and the consuming stage's stream can poll it.  A rank that cannot map it says so and every rank uses the host path.
     if (tp->device_mode && tp->rank >= 1 && !(getenv("PIPEINFER_TRANSPORT_FLAGS") && atoi(getenv("PIPEINFER_TRANSPORT_FLAGS")) == 0)) {
@@ -353,8 +385,51 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
                 if (scratch) (void) hipFree(scratch);
             }
             if (!ok) { (void) hipGetLastError(); fprintf(stderr, "[pipeinfer transport, rank %d] the arrival-flag probe failed on this node: headers are published by the host\n", tp->rank); L->flags_off.store(1); }
-        }
-    } else if (tp->rank >= 1) L->flags_off.store(1);
+            // Second probe — the REAL pattern of a hop, not only the flag (the first probe says nothing about the activations): the consumer reads slot 0 of its ring twice, so that
+            // whatever its caches keep of the slot's old contents is there, and enqueues the wait kernel with the slot's reader (the same k_hop_store a run takes its input with)
+            // behind it; only then does the producer store a new pattern through the peer mapping and publish the flag from its stream.  What the reader sees must be the new
+            // pattern: no host synchronisation and no kernel launch stands between the remote write and the read, exactly as in a run.  A stale or partial block sends every
+            // rank to the host-published headers.
+            constexpr int PN = 1024; const uint32_t ticket2 = 0x3c0ffee5;
+            float * got_dev = nullptr; int32_t * word2 = nullptr; bool armed = false;
+            if (ok && tp->rank >= 2 && tp->my_ring) {
+                armed = hipMalloc((void **) &got_dev, 2 * PN * sizeof(float)) == hipSuccess && hipMalloc((void **) &word2, 64) == hipSuccess && hipMemset(word2, 0, 64) == hipSuccess
+                     && pi::hop_store(got_dev + PN, tp->my_ring, PN * sizeof(float), nullptr) && pi::hop_store(got_dev + PN, tp->my_ring, PN * sizeof(float), nullptr) && hipDeviceSynchronize() == hipSuccess
+                     && pi_op_abort_begin_wait(word2, 1, nullptr, probe_dev(tp->rank), ticket2, 3000000, word2 + 1, nullptr, nullptr) == 0
+                     && pi::hop_store(got_dev, tp->my_ring, PN * sizeof(float), nullptr);
+                if (!armed) (void) hipGetLastError();
+            }
+            if (tp->rank >= 2) L->st[tp->rank].probe2_armed.store(armed ? 1 : 2, std::memory_order_release);
+            if (tp->rank + 1 < tp->world) {                                      // producer side of the boundary behind this stage
+                const int c = tp->rank + 1;
+                (void) tp->wait_for([&] { return L->st[c].probe2_armed.load(std::memory_order_acquire) != 0; }, tp->timeout_ms);
+                if (ok && tp->peer_ring && L->st[c].probe2_armed.load() == 1) {
+                    std::vector<float> pat(PN); for (int i = 0; i < PN; i++) pat[i] = (float) (tp->rank * 7777 + i) + 0.5f;
+                    float * pat_dev = nullptr;
+                    std::this_thread::sleep_for(std::chrono::microseconds(500));   // (the consumer's wait kernel is spinning by now; not required, it makes the probe the harder case)
+                    const bool sent = hipMalloc((void **) &pat_dev, PN * sizeof(float)) == hipSuccess && hipMemcpy(pat_dev, pat.data(), PN * sizeof(float), hipMemcpyHostToDevice) == hipSuccess
+                                   && pi::hop_store(tp->peer_ring, pat_dev, PN * sizeof(float), tp->copy_stream) && pi_op_flag_publish(probe_dev(c), ticket2, nullptr, 0, tp->copy_stream) == 0
+                                   && hipStreamSynchronize(tp->copy_stream) == hipSuccess;
+                    if (!sent) { (void) hipGetLastError(); fprintf(stderr, "[pipeinfer transport, rank %d] the hop probe could not be sent\n", tp->rank); }
+                    if (pat_dev) (void) hipFree(pat_dev);
+                }
+            }
+            if (armed) {
+                std::vector<float> got(PN); int32_t seen[2] = {0, 1};
+                bool fresh = hipDeviceSynchronize() == hipSuccess && hipMemcpy(got.data(), got_dev, PN * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(seen, word2, sizeof seen, hipMemcpyDeviceToHost) == hipSuccess && seen[1] == 0;
+                int bad_at = -1;
+                for (int i = 0; fresh && i < PN; i++) if (got[i] != (float) ((tp->rank - 1) * 7777 + i) + 0.5f) { fresh = false; bad_at = i; }
+                if (!fresh) {
+                    (void) hipGetLastError();
+                    fprintf(stderr, "[pipeinfer transport, rank %d] the hop probe FAILED (%s): a reader enqueued behind the device-side wait did not see the block the upstream device stored before its flag — "
+                                    "activation ring: %s memory.  Headers are published by the host instead.\n", tp->rank, bad_at >= 0 ? "stale or partial data" : "the flag never arrived", ring_alloc_name(tp->ring_alloc));
+                    L->flags_off.store(1);
+                } else fprintf(stderr, "[pipeinfer transport, rank %d] hop probe ok: store + device flag from device %d seen fresh by a reader enqueued behind the wait (ring: %s memory)\n", tp->rank, L->st[tp->rank - 1].device.load(), ring_alloc_name(tp->ring_alloc));
+            }
+            if (got_dev) (void) hipFree(got_dev);
+            if (word2) (void) hipFree(word2);
+        } else if (tp->rank >= 2) L->st[tp->rank].probe2_armed.store(2, std::memory_order_release);
+    } else if (tp->rank >= 1) { L->flags_off.store(1); L->st[tp->rank].probe2_armed.store(2, std::memory_order_release); }
     L->st[tp->rank].flags_done.store(1, std::memory_order_release);
     for (int r = 1; r < tp->world; r++)
         if (!tp->wait_for([&] { return L->st[r].flags_done.load(std::memory_order_acquire) != 0; }, tp->timeout_ms)) { tp->fail("rank " + std::to_string(r) + " never finished the flag set-up"); pipeinfer_transport_close(tp); return nullptr; }
@@ -435,7 +510,7 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
             // the id again, and ids never repeat — the same non-zero id on both sides of the key load means the key was that run's throughout
             const int32_t rid = ctx->stage_run_id.load(std::memory_order_acquire);
             const uint64_t key = watch_key.load(std::memory_order_acquire);
-            if (rid != 0 && key != ~0ull && ctx->stage_run_id.load(std::memory_order_acquire) == rid && seen.count(key)) pi::stage_abort_run(ctx, rid);
+            if (rid != 0 && key != ~0ull && ctx->stage_run_id.load(std::memory_order_acquire) == rid && (seen.count(key) || L->fatal.load(std::memory_order_relaxed))) pi::stage_abort_run(ctx, rid);     // (a dead pipeline: whatever waits on the device for input that will never come is released)
             std::this_thread::sleep_for(std::chrono::microseconds(key != ~0ull ? 30 : 200));
         }
     });
@@ -498,7 +573,7 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
             if (flags) {
                 if (!is_first) { hop.in_flag = tp->flag_dev(r, t); hop.in_ticket = (uint32_t) (t + 1); }
                 if (!is_last) { hop.out_flag = tp->flag_dev(r + 1, oh); hop.out_ticket = (uint32_t) (oh + 1); }
-                hop.wait_timeout_us = (int64_t) tp->timeout_ms * 1000;
+                hop.wait_timeout_us = tp->device_wait_us;
             }
             if (backend) rc = backend->run(backend->user, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr);
             else rc = pi::stage_run(ctx, n, tp->meta_of(m.run_seq), meta_bytes, x_in, xo, rs ? tp->res_logits(rs) : nullptr, rs ? tp->res_ids(rs) : nullptr, rs ? tp->res_vals(rs) : nullptr, rs ? tp->res_sums(rs) : nullptr, abort_probe, tp,
@@ -534,6 +609,8 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
     if (x_registered) (void) hipHostUnregister(tp->base + L->off_x);
     st.cancel_notes = tp->cancel_cursor;
     st.device_flags = tp->flags_on && ctx && !backend ? 1 : 0;
+    st.hop_store_kernel = pi::hop_store_mode() == 1 && !(getenv("PIPEINFER_HOP_STORE") && !strcmp(getenv("PIPEINFER_HOP_STORE"), "memcpy")) ? 1 : 0;
+    st.ring_alloc = tp->ring_alloc;
     if (ctx) { st.flag_runs = ctx->stat_flag_runs; st.flag_wait_gpu_ms = ctx->stat_flag_wait_ms; st.flag_seen_us = ctx->stat_flag_seen_us; }
     if (out) *out = st;
     return rc_all;

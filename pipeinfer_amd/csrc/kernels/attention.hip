@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
         __syncthreads();
         if (rg > 0) return;
     }
+    if (aborted & 1) pi_abort_note(ga.abort_w, 5);                                      // (counted once per launch, where the value is first looked at: in front of the stores)
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
         const int rr = SPLIT ? 0 : rg + i * NRG;
@@ -344,7 +345,8 @@ static void att_launch(const att_args & g, int rows, int rw, hipStream_t stream)
     // algorithmic bytes: K and V of n_kv cells (f16) + the query rows + the fp32 output.  (A captured graph is launched with n_kv = n_ctx and reads the real
     // n_kv from device memory: its count carries the upper bound, bench.py prices attention from the call statistics instead.)
     const int nt = g.n_tok > 0 ? g.n_tok : 1;
-    const double bytes = (double) g.n_kv * g.n_head_kv * HD * 2 * 2 + (double) nt * g.n_head * HD * (2 + 4);
+    const int n_kv_priced = pi_account_n_kv() > 0 && pi_account_n_kv() < g.n_kv ? pi_account_n_kv() : g.n_kv;      // (eager launches of the engine: the pass's own n_kv)
+    const double bytes = (double) n_kv_priced * g.n_head_kv * HD * 2 * 2 + (double) nt * g.n_head * HD * (2 + 4);
     if (g.alibi_m) {
         switch (rw) {
             case 1: PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention<HD, 1, true>), grid, dim3(256), lds, stream, g); break;

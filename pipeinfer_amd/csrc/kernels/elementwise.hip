@@ -173,7 +173,7 @@ static __device__ __forceinline__ void wave_emit_frags(const q8k_frags & F, cons
 }
 
 __global__ void __launch_bounds__(64) k_quantize_q8_K(const float * __restrict__ x, int64_t k, int8_t * __restrict__ qs, float * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
-    if (pi_aborted(abort_w)) return;
+    if (pi_aborted(abort_w, 3)) return;
     const int t = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
     const int64_t nb = k >> 8;
     const float4 v = *(const float4 *) (x + (int64_t) t * k + (int64_t) blk * 256 + lane * 4);
@@ -194,7 +194,7 @@ static __device__ __forceinline__ void q8_0_store_scale(const int q[4], float d,
 
 // one wave = 8 blocks of 32 = two groups of 4 blocks; values past k belong to the zero padding of the last group
 __global__ void __launch_bounds__(64) k_quantize_q8_0(const float * __restrict__ x, int64_t k, int64_t ng, uint32_t * __restrict__ qs, uint16_t * __restrict__ dd, float * __restrict__ ss, const int32_t * __restrict__ abort_w) {
-    if (pi_aborted(abort_w)) return;
+    if (pi_aborted(abort_w, 3)) return;
     const int t = blockIdx.y, lane = threadIdx.x;
     const int64_t e0 = (int64_t) blockIdx.x * 256 + lane * 4;
     if (e0 >= ng * 128) return;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(1024) k_norm_quant(const float * __restrict__ 
     }
     const float var = (float) (block_sum(acc) / n);
     const float scale = 1.0f / sqrtf(var + eps);
-    if (aborted & 1) return;                                                   // (no barrier below this line)
+    if (aborted & 1) { pi_abort_note(abort_w, 2); return; }                                                   // (no barrier below this line)
     int cc = 0;
     for (int64_t c0 = (int64_t) wave * 256; c0 < n_pad; c0 += (int64_t) nw * 256, cc++) {    // whole 256-value chunks per wave
         const int64_t e0 = c0 + lane * 4;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_norm_quant_mw(const float * __restrict_
     }
     const float var = (float) (block_sum(acc) / n);
     const float scale = 1.0f / sqrtf(var + eps);
-    if (aborted & 1) return;
+    if (aborted & 1) { pi_abort_note(abort_w, 2); return; }
     float4 v = xv[0];
 #pragma unroll
     for (int i = 1; i < NLMAX; i++) if (g == i) v = xv[i];                                  // (compile-time register indices: a dynamic one would spill)
@@ -438,7 +438,7 @@ extern "C" int pi_op_norm_quantize(const float * x, const float * w, const float
 // act(gate) [* up] straight into the quantised activation planes: which = 0 silu(gate)*up, 1 gelu(gate).  One wave per 256 values.
 __global__ void __launch_bounds__(256) k_act_quant(const float * __restrict__ g, const float * __restrict__ u, int which, int64_t n, int vdt, int64_t ng,
                                                     const uint16_t * __restrict__ tab, uint8_t * __restrict__ qs, uint8_t * __restrict__ dd, int16_t * __restrict__ bsums, const q8k_frags F, const int32_t * __restrict__ abort_w) {
-    if (pi_aborted(abort_w)) return;
+    if (pi_aborted(abort_w, 4)) return;
     const int t = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c0 = ((int64_t) blockIdx.x * 4 + wave) * 256, e0 = c0 + lane * 4;
     const int64_t n_pad = vdt == PI_Q8_K ? n : ng * 128;

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q6 ? 1600 : Q5 ? 832 : 320;
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 1)) return;
     constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0) + (Q6 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
     constexpr int FRAG = NT8 ? 512 : 1024, CH_LDS = 8 * FRAG + 1024, MQ_BLK_LDS = NC * CH_LDS, NP1 = NT8 ? 5 : 9, NP = NC * NP1;   // NP: DMA pieces of 1 KB per block (all chunks)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -570,7 +570,7 @@ template <int R, int TB>
 __global__ void __launch_bounds__(64 * R) k_mmq_g2(const mmvq_args g, const int n_groups) {
     constexpr uint32_t TILE = PI_MQ_TILE, QOFF = 320;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 1)) return;
     constexpr int NW = R, D = 2 * TB, LW = 4, NB = 3;
     constexpr int FRAG = 512, MQ_BLK_LDS = 8 * FRAG + 1024, NP = 5, ZSLOT = 8 * FRAG + 576;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

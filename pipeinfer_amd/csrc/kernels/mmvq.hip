@@ -458,7 +458,7 @@ static __device__ __forceinline__ void mmvq_kq_body(const mmvq_args & g, uint8_t
 template <int TYPE, int NT, int R, int ST>
 __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq(const mmvq_args g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 0)) return;
     mmvq_kq_body<TYPE, NT, R, ST, kq_lds<TYPE, R * NT>::FLOATS>(g, lds);
 }
 
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attr
 template <int TA, int TB, int NT, int R, int ST>
 __global__ void __launch_bounds__(ST == 2 ? (NT <= 2 ? 1024 : 128) : 256) __attribute__((amdgpu_waves_per_eu(ST && NT <= 2 ? 4 : 1))) k_mmvq_kq2(const mmvq_args g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 0)) return;
     constexpr int FA = kq_lds<TA, R * NT>::FLOATS, FB = kq_lds<TB, R * NT>::FLOATS, LSTR = FA > FB ? FA : FB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave_id = ST == 2 ? (int) blockIdx.x : (int) (blockIdx.x * (blockDim.x >> 6) + wave);
@@ -488,7 +488,7 @@ template <int TYPE, int NT, int G>
 __global__ void __launch_bounds__(1024) k_mmvq_q0r(const mmvq_args g) {
     const mmvq_seg & sg = g.seg[0];
     __shared__ float hand[NT][64];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 0)) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int r = lane >> 3, k = lane & 7;
     const int64_t row = (int64_t) blockIdx.x * 8 + r;
@@ -572,7 +572,7 @@ template <int TYPE, int NT>
 __global__ void __launch_bounds__(256) k_mmvq_q0(const mmvq_args g) {
     const mmvq_seg & sg = g.seg[0];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 0)) return;
     // LDS tile: qs [NT][TILE groups][128] | d [NT][TILE][4] f16
     uint8_t * l_qs = lds;
     uint16_t * l_d = (uint16_t *) (lds + (size_t) NT * MMVQ_TILE * 128);
@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(256) k_mmvq_leg(const mmvq_args g) {
     constexpr int DSTR = Y81 ? 16 : 8;                                       // bytes of activation scales per group: 4 floats or 4 f16
     const mmvq_seg & sg = g.seg[0];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w)) return;
+    if (pi_aborted(g.abort_w, 0)) return;
     uint8_t * l_qs = lds;                                                    // qs [NT][TILE groups][128] | d [NT][TILE][DSTR] | s [NT][TILE][16]
     uint8_t * l_d = lds + (size_t) NT * MMVQ_TILE * 128;
     float * l_s = (float *) (l_d + (size_t) NT * MMVQ_TILE * DSTR);

@@ -41,6 +41,7 @@ struct pi_weight {
 void pi_set_error(const char * fmt, ...);
 // abort word the calling thread's launches (and captures) hand to their kernels (pi_set_abort_word; nullptr: no check)
 const int32_t * pi_abort_word();
+int pi_account_n_kv();                                       // > 0: the cells an attention launch of this thread really reads (pi_set_account_n_kv)
 // compute units the launching context's stream may use (pipeinfer_context_set_cu_range -> hipExtStreamCreateWithCUMask; 256 without a mask): what "one round of workgroups" means
 int pi_cu_count();
 const pi_tables & pi_get_tables();

@@ -78,7 +78,17 @@ static __device__ __forceinline__ float pi_wave_max(float v) {
 // is set.  The load bypasses L1 (sc1, agent scope: what a poll of another agent's atomic needs) and is issued first; kernels that stream
 // weights look at the value only after their first loads are in flight (vmcnt retires in order, so the wait costs them nothing).
 static __device__ __forceinline__ int pi_abort_peek(const int32_t * w) { return w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
-static __device__ __forceinline__ bool pi_aborted(const int32_t * w) { return (pi_abort_peek(w) & 1) != 0; }
+// The word is the first int32 of a 64-byte block (include/pipeinfer_ops.h): words 8..14 count, per kernel family (kernel_timing.h: pi_kt_family), the LAUNCHES that found
+// the run aborted and returned — one thread of a launch adds one, on the abort path only.  bench.py's roofline keeps those launches apart from the ones that did the work.
+static __device__ __forceinline__ void pi_abort_note(const int32_t * w, int fam) {
+    if ((threadIdx.x | threadIdx.y | threadIdx.z | blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+        __hip_atomic_fetch_add(const_cast<int32_t *>(w) + 8 + fam, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ bool pi_aborted(const int32_t * w, int fam = 6 /* PI_KT_OTHER */) {
+    if ((pi_abort_peek(w) & 1) == 0) return false;
+    pi_abort_note(w, fam);
+    return true;
+}
 
 // KV cell of token i of a pass.  dyn (device memory, refreshed per call so that one captured graph serves every call): {kv_head, n_kv, n_tokens, has_table, cell[0..n_tokens)}.
 // A run's tokens sit in consecutive cells from kv_head (find_slot, llama.cpp:1593-1644); a pass that carries several runs at once (context.cpp: coalescing) brings a table.

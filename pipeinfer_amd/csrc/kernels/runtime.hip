@@ -109,6 +109,10 @@ extern "C" int pi_stream_sync(void * stream) { PI_CHECK_HIP(hipStreamSynchronize
 static thread_local const int32_t * g_abort_word = nullptr;
 const int32_t * pi_abort_word() { return g_abort_word; }
 extern "C" void pi_set_abort_word(const int32_t * word_dev) { g_abort_word = word_dev; }
+// cells the attention launches of this thread are PRICED with (launch accounting only): a forward pass is launched with n_kv = n_ctx and reads the real n_kv on the device
+static thread_local int g_account_n_kv = 0;
+int pi_account_n_kv() { return g_account_n_kv; }
+extern "C" void pi_set_account_n_kv(int n_kv) { g_account_n_kv = n_kv > 0 ? n_kv : 0; }
 static thread_local int g_cu_count = 256;
 int pi_cu_count() { return g_cu_count; }
 extern "C" void pi_set_cu_count(int n) { g_cu_count = n > 0 && n <= 256 ? n : 256; }
@@ -134,15 +138,18 @@ __global__ void k_flag_publish(pi_xflag * flag, uint32_t ticket, const int32_t *
 __global__ void k_abort_begin_wait(int32_t * word, int32_t run_id, const int32_t * host_flag, const pi_xflag * flag, uint32_t ticket, unsigned long long limit_ticks,
                                    int32_t * timeout_flag, unsigned long long * hop_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t v = 0; bool timed_out = false;
-    while (true) {
+    uint32_t v = 0; bool timed_out = false, given_up = false;
+    for (uint32_t it = 0; ; it++) {
         v = __hip_atomic_load(&flag->value, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((v >> 1) == ticket) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) { timed_out = true; break; }
+        // the run's host flag (llama_cancel_run / stage_abort_run / a failed launch of this very run): whoever raises it ends the wait — the run is aborted, not timed out
+        if (host_flag && (it & 15) == 15 && __hip_atomic_load(host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { given_up = true; break; }
         __builtin_amdgcn_s_sleep(4);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-    if (timed_out) { if (timeout_flag) *timeout_flag = 1; v = 1; }
+    if (timeout_flag) *timeout_flag = timed_out ? 1 : 0;                           // (rewritten by every run: a time-out is that run's, not sticky)
+    if (timed_out || given_up) v = 1;
     else if (hop_ticks) { hop_ticks[0] += t1 - flag->stamp; hop_ticks[1] += t1 - t0; hop_ticks[2] += 1; }     // flag written -> seen (one clock: stages on one device); time spent waiting; runs
     const int32_t f = host_flag ? __hip_atomic_load(host_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
     __hip_atomic_exchange(word, (run_id << 1) | (f != 0) | (int32_t) (v & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -557,11 +564,14 @@ extern "C" size_t pi_q8_nbytes(int vdt, int64_t k, int n_tok) {
 // launch accounting (kernel_timing.h): per-instance launch counts + algorithmic bytes, sampled durations of eager launches
 // =================================================================================================================
 #include "kernel_timing.h"
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
 namespace {
-struct kt_stat { uint64_t launches = 0; double bytes = 0.0; uint64_t sampled = 0; double us = 0.0, sampled_bytes = 0.0; };
+// us / sbytes: every timed launch of the instance, kept one by one — launches that found their run aborted return on entry (a few microseconds whatever the shape) and must not
+// be averaged with the launches that did the work (kt_rows drops the samples below a third of the instance's median and reports how many)
+struct kt_stat { uint64_t launches = 0; double bytes = 0.0; std::vector<float> us; std::vector<double> sbytes; };
 std::mutex g_kt_mu;
 bool g_kt_on = false; int g_kt_every = 8;
 std::map<std::tuple<int, int, int, uint64_t>, kt_stat> g_kt_tab;       // (family, type, tokens, launch shape) -> eager launches
@@ -578,7 +588,7 @@ hipEvent_t kt_event() {
 void kt_fold_pending() {                                     // (caller holds g_kt_mu; the device has been synchronised)
     for (auto & s : g_kt_pending) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { kt_stat & st = g_kt_tab[std::make_tuple(s.fam, s.type, s.nt, kt_shape(s.fam, s.bytes))]; st.sampled++; st.us += 1e3 * ms; st.sampled_bytes += s.bytes; }
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { kt_stat & st = g_kt_tab[std::make_tuple(s.fam, s.type, s.nt, kt_shape(s.fam, s.bytes))]; st.us.push_back(1e3f * ms); st.sbytes.push_back(s.bytes); }
         g_kt_pool.push_back(s.a); g_kt_pool.push_back(s.b);
     }
     g_kt_pending.clear();
@@ -632,8 +642,17 @@ static int kt_rows(std::map<std::tuple<int, int, int, uint64_t>, kt_stat> & tab,
         const kt_stat & st = kv.second;
         pi_kt_row & r = out[n++];
         r.family = std::get<0>(kv.first); r.type = std::get<1>(kv.first); r.n_tok = std::get<2>(kv.first); r.shape_bytes = std::get<3>(kv.first);
-        r.launches = st.launches; r.bytes_total = st.bytes; r.sampled = st.sampled;
-        r.avg_us = st.sampled ? st.us / (double) st.sampled : 0.0; r.avg_sampled_bytes = st.sampled ? st.sampled_bytes / (double) st.sampled : 0.0;
+        r.launches = st.launches; r.bytes_total = st.bytes;
+        // the launches that did the work: samples of at least a third of the instance's median duration (an aborted launch costs its dispatch, 2-5 us)
+        double us = 0.0, sb = 0.0; uint64_t kept = 0;
+        if (!st.us.empty()) {
+            std::vector<float> sorted(st.us);
+            std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+            const float floor_us = sorted[sorted.size() / 2] / 3.0f;
+            for (size_t i = 0; i < st.us.size(); i++) if (st.us[i] >= floor_us) { us += st.us[i]; sb += st.sbytes[i]; kept++; }
+        }
+        r.sampled = kept; r.sampled_dropped = (int32_t) (st.us.size() - kept);
+        r.avg_us = kept ? us / (double) kept : 0.0; r.avg_sampled_bytes = kept ? sb / (double) kept : 0.0;
     }
     return n;
 }

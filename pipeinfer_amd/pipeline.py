@@ -51,7 +51,7 @@ class TransportStats(C.Structure):
     _fields_ = [("runs", C.c_uint64), ("skipped", C.c_uint64), ("cut_short", C.c_uint64), ("cancel_notes", C.c_uint64),
                 ("wait_in_ms", C.c_double), ("compute_ms", C.c_double), ("send_ms", C.c_double),
                 ("received", C.c_uint64), ("wait_out_ms", C.c_double), ("hop_gpu_ms", C.c_double), ("peer_access", C.c_int32), ("device_flags", C.c_int32),
-                ("flag_runs", C.c_uint64), ("flag_wait_gpu_ms", C.c_double), ("flag_seen_us", C.c_double)]
+                ("flag_runs", C.c_uint64), ("flag_wait_gpu_ms", C.c_double), ("flag_seen_us", C.c_double), ("hop_store_kernel", C.c_int32), ("ring_alloc", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -230,6 +230,53 @@ class HipStage:
         self.model.free()
 
 
+RING_ALLOC = {0: "none", 1: "coarse-grained (hipMalloc)", 2: "fine-grained", 3: "uncached"}
+
+
+def stage_family_tables(lib, backend, n_ctx, B):
+    """A stage's share of the N > 1 roofline, the same accounting as N = 1 (bench.py: roofline_tables): launch counts and algorithmic bytes = this stage's captured graphs x
+    their replays (every run it served), aborted launches from the device-side counters; durations = HIP-event samples of a graphs-off replay of the pass widths it served,
+    on its own context and its own GPU, after the serve loop (synthetic tokens, n_kv = 256: the kernels and launch shapes are those of the runs).  Returns (counts, samples, aborted)."""
+    ctx = backend.ctx
+    counts = B.launch_rows(lib, ctx)
+    aborted = B.aborted_launches(lib, ctx)
+    by_width = {}
+    for r in counts:
+        by_width[r["n_tok"]] = by_width.get(r["n_tok"], 0) + r["launches"]
+    widths = sorted(sorted(by_width, key=lambda w: -by_width[w])[:6])        # the six widths that carry most launches; the others are priced with the nearest one
+    n_embd, words, n_kv = backend.n_embd, (n_ctx + 31) // 32, min(256, n_ctx - 64)
+    x_in = lib.pi_malloc(4 * 64 * n_embd); x_out = lib.pi_malloc(4 * 64 * n_embd)
+    lib.pi_memset(x_in, 0, 4 * 64 * n_embd, None); lib.pi_device_sync()
+    ctx.set_graphs(0)
+    lib.pi_kernel_timing(1, 3)
+    try:
+        for w in widths:
+            if w > 64:
+                continue
+            meta = np.zeros(2 * w + 4 + w * words, np.int32)
+            meta[:w] = 3 + np.arange(w); meta[w:2 * w] = n_kv - w + np.arange(w)
+            meta[2 * w:2 * w + 4] = (n_kv - w, n_kv, w, 0)
+            mask = np.zeros((w, words), np.uint32)
+            for i in range(w):                                                # token i sees cells [0, n_kv - w + i]
+                vis = n_kv - w + i + 1
+                mask[i, :vis // 32] = 0xFFFFFFFF
+                if vis % 32:
+                    mask[i, vis // 32] = (1 << (vis % 32)) - 1
+            meta[2 * w + 4:] = mask.view(np.int32).ravel()
+            for _ in range(3):
+                rc = lib.pipeinfer_stage_run(ctx.h, w, meta.ctypes.data, meta.nbytes, None if backend.is_first else x_in, None if backend.is_last else x_out,
+                                             backend.logits.ctypes.data, backend.ids.ctypes.data, backend.vals.ctypes.data, backend.sums.ctypes.data)
+                if rc != 0:
+                    raise RuntimeError("pipeinfer_stage_run (roofline replay): " + lib.pipeinfer_context_error(ctx.h).decode())
+        lib.pi_device_sync()
+        samples = B.timing_rows(lib)
+    finally:
+        lib.pi_kernel_timing(0, 8)
+        ctx.set_graphs(1)
+        lib.pi_free(x_in); lib.pi_free(x_out)
+    return counts, samples, aborted
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N  (N > 1)
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -315,8 +362,15 @@ def bench_main(args, rank, world):
         st = tp.serve(ctx=backend.ctx)
         stats = backend.stats()
         t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"] + st["hop_gpu_ms"], float(st["runs"]), st["wait_out_ms"], float(st["peer_access"]),
-                          float(st["device_flags"]), float(st["flag_runs"]), st["flag_wait_gpu_ms"], st["flag_seen_us"]], dtype=torch.float64)    # single-token calls
+                          float(st["device_flags"]), float(st["flag_runs"]), st["flag_wait_gpu_ms"], st["flag_seen_us"], float(st["hop_store_kernel"]), float(st["ring_alloc"])], dtype=torch.float64)    # single-token calls
         dist.gather(t, None, dst=0)
+        # this stage's rows of the by-family roofline (counts of everything it served x durations of a graphs-off replay on its own GPU)
+        try:
+            rows = stage_family_tables(lib, backend, args.n_ctx, B)
+        except Exception as e:                                                # the line still goes out; the head says which stage has no table
+            print(f"[bench rank {rank}] no roofline table from this stage: {e!r}", file=sys.stderr)
+            rows = None
+        dist.gather_object(rows, None, dst=0)
         dist.barrier()
         tp.close()
         backend.close()
@@ -353,8 +407,10 @@ def bench_main(args, rank, world):
     tp.shutdown()
     tp_device_mode = tp.device_mode
     head_stats = tp.stats()
-    gathered = [torch.zeros(15, dtype=torch.float64) for _ in range(world)]
-    dist.gather(torch.zeros(15, dtype=torch.float64), gathered, dst=0)
+    gathered = [torch.zeros(17, dtype=torch.float64) for _ in range(world)]
+    dist.gather(torch.zeros(17, dtype=torch.float64), gathered, dst=0)
+    stage_rows = [None] * world
+    dist.gather_object(None, stage_rows, dst=0)
     dist.barrier()
     tp.close()
     if not os.environ.get("PIPEINFER_KEEP_STAGE_FILES"):
@@ -374,12 +430,20 @@ def bench_main(args, rank, world):
                     # device-side arrival flags: runs are announced early and enqueued behind a device wait; flag_seen_us = flag stamped by the producing stream -> seen by
                     # the waiting kernel (one device clock: meaningful between stages that share a device), wait_for_input_gpu_ms = GPU time spent waiting for input
                     "device_flags": bool(gathered[r][11]), "flag_runs": int(gathered[r][12]), "wait_for_input_gpu_ms": round(float(gathered[r][13]), 1),
-                    "flag_seen_us_per_run": round(float(gathered[r][14]) / max(1.0, float(gathered[r][12])), 2) if gathered[r][12] > 0 else None} for r in range(1, world)]
+                    "flag_seen_us_per_run": round(float(gathered[r][14]) / max(1.0, float(gathered[r][12])), 2) if gathered[r][12] > 0 else None,
+                    # decided and logged at the transport's set-up, per rank: how this stage stores its activations into the next stage's ring, and what memory its own ring is
+                    "hop_store": "kernel" if gathered[r][15] else "memcpy", "ring_alloc": RING_ALLOC.get(int(gathered[r][16]), "?")} for r in range(1, world)]
     slow = max(stage_stats, key=lambda s: s["gpu_ms_per_call"])
-    # dominant kernel = the single-token Q4_K mat-vec of every stage; its HBM traffic comes from the committed single-GPU PMC pass of the same
-    # kernel sources (the per-launch traffic of a mat-vec does not depend on which stage launches it)
-    tr, traffic_src = B.committed_traffic(args.workload, "matvec_nt1")
-    traffic = tr["avg_fetch_bytes_per_launch"] if tr else None
+    # the same by-family roofline as N = 1: every stage's launch counts (graphs x replays, aborted launches apart) priced with the durations of a graphs-off replay on its
+    # own GPU; families add up over the stages; the dominant family is the one the stages spent most GPU time in.  HBM traffic: the committed single-GPU PMC pass of the same
+    # kernel sources (bytes fetched per algorithmic byte of a family do not depend on which stage launches it)
+    per_stage, stage_inst = {}, {}
+    for r in range(1, world):
+        if stage_rows[r] is not None:
+            per_stage[r], stage_inst[r] = B.roofline_tables(*stage_rows[r])
+    by_family = B.merge_family_tables(list(per_stage.values()))
+    dom_name = next(iter(by_family), None)
+    tr, traffic_src = B.committed_traffic("70b" if args.workload == "70b" else args.workload, dom_name) if dom_name else (None, "no stage sent a table")
     sched = {0: "PipeInfer (asynchronous continuous speculation, examples/speculative)", 1: "synchronous tree speculation (examples/speculative_orig)", 2: "target only"}[args.mode]
     out = {"metric": B.METRIC if args.workload == "70b" else f"accepted tokens/sec + acceptance rate, {tspec} {tft} target / {dspec} draft", "value": main_sum["tokens_per_s"], "unit": "tokens/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_total / args.steps, 2), "higher_is_better": True,
@@ -400,13 +464,25 @@ def bench_main(args, rank, world):
                       "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}, draft wrong on {args.draft_miss:.0%} of the vocabulary"},
            "acceptance": {k: v for k, v in main_sum.items() if k != "tokens_per_s"},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff,
-           "roofline": {"bound": "hbm", "kernel": "k_mmvq_kq<Q4_K,NT=1> inside the slowest stage's forward pass", "achieved": slow["GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(slow["GBps"] / B.HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "note": "achieved = algorithmic bytes of the slowest stage's single-token calls / their GPU time (whole stage call, not one kernel)", "stages": stage_stats}}
+           "roofline": None}
+    if dom_name:
+        dom = by_family[dom_name]
+        out["roofline"] = {"bound": "hbm", "kernel": dom["kernels"], "family": dom_name, "achieved": dom["achieved_GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                           "traffic": round(tr["fetch_over_alg"] * dom["alg_bytes_per_launch"]) if tr else None, "traffic_fetch_over_alg": tr["fetch_over_alg"] if tr else None, "traffic_source": traffic_src,
+                           "kernel_src_sha16": B.kernel_source_sha(), "avg_launch_us": dom["avg_launch_us"], "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "launches": dom["launches"],
+                           "aborted_launches": dom["aborted_launches"], "share_of_gpu_time": dom["share_of_gpu_time"], "by_family": by_family,
+                           "by_family_per_stage": {str(r): t for r, t in per_stage.items()}, "per_instance_per_stage": {str(r): t for r, t in stage_inst.items()},
+                           "how": "per stage: launch counts and bytes of everything the stage served (captured graphs x replays, launches aborted on entry apart) x HIP-event durations of a graphs-off "
+                                  "replay of the same pass widths on the stage's own GPU after the serve loop; families summed over the stages" + (" (ranks share one device here: the replays ran side by side)" if shared_gpu else ""),
+                           "slowest_stage_decode_call": {"rank": slow["rank"], "gpu_ms_per_call": slow["gpu_ms_per_call"], "GBps": slow["GBps"], "frac": round(slow["GBps"] / B.HBM_PEAK_GBS, 4)},
+                           "stages": stage_stats}
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": slow["GBps"], "peak": B.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(slow["GBps"] / B.HBM_PEAK_GBS, 4), "traffic": None,
+                           "note": "no stage sent a launch table: achieved = the slowest stage's single-token calls (whole stage call)", "stages": stage_stats}
     if not args.no_cpu_baseline:
         try:
             full = B.ensure_model(cache, tspec, tft, 0x5EED, args.signal, args.noise) if n_layer <= 32 else None
             out["cpu_baseline"] = B.cpu_baseline(tspec, tft, full, cache, args.signal, args.noise, args.cpu_tokens)
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": repr(e)}
-    print(json.dumps(out))
+    B.emit(out, getattr(args, "detail", None))

@@ -643,7 +643,13 @@ def test_cancel_after_the_start_stops_the_run_at_kernel_granularity(LL, segments
         c.seq_rm(2, 8, -1); ref.seq_rm(2, 8, -1)
     st = c.stats()
     assert st["n_cancel_runs"] == 12 and st["n_cancel_runs_started"] == 12, st
-    print(f"segments={segments}: 12 runs cancelled after their start took {st['cancel_gpu_ms']:.3f} ms of GPU time in all; segments dropped by the feeder: {st['n_segments_skipped']}")
+    # what the cancelled runs' launches did instead of working is on the device's books, per kernel family (bench.py keeps them out of the roofline); reset_stats clears them
+    import bench as B
+    ab = B.aborted_launches(c.lib, c)
+    print(f"segments={segments}: 12 runs cancelled after their start took {st['cancel_gpu_ms']:.3f} ms of GPU time in all; segments dropped by the feeder: {st['n_segments_skipped']}; launches aborted on entry per family: {ab}")
+    assert sum(ab.values()) > 0 or st["n_segments_skipped"] > 0, (ab, st)
+    c.reset_stats()
+    assert sum(B.aborted_launches(c.lib, c).values()) == 0
     c.free(); ref.free(); m.free()
 
 

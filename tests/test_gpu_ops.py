@@ -646,7 +646,7 @@ def test_abort_word_stops_kernels_of_the_cancelled_run_only(gpu):
     act = rng.standard_normal((n_tok, k)).astype(np.float32)
     want = O.Impl("oracle").mul_mat(t, blocks, k, rows, act)
     w = upload_weight(lib, t, rows, k, blocks)
-    word = U.Dev(np.zeros(4, np.int32))
+    word = U.Dev(np.zeros(16, np.int32))                               # the abort block: word 0 = (run id << 1 | aborted), words 8..14 = launches aborted on entry, per kernel family
     xd = U.Dev(act)
     sentinel = np.full((n_tok, rows), 12345.0, np.float32)
 
@@ -675,9 +675,13 @@ def test_abort_word_stops_kernels_of_the_cancelled_run_only(gpu):
     run(False, lambda: L.check(lib.pi_op_abort_cancel(word.ptr, 7, None)))                      # the executing run: stopped
     assert word.get(np.int32)[0] == (7 << 1) | 1
     run(False, lambda: None)                                                                    # ... and stays stopped: every later kernel of it returns on entry
+    # the two aborted rounds above are on the device's books, per family (pi_kt_row.family: 0 mat-vec, 3 quantise, 6 other = k_norm): what bench.py takes out of the roofline
+    counters = word.get(np.int32)[8:15]
+    assert counters[0] == 2 and counters[3] == 2 and counters[6] == 2 and counters[1] == counters[2] == counters[4] == counters[5] == 0, counters
     run(True, lambda: L.check(lib.pi_op_abort_begin(word.ptr, 8, None, None)))                  # the next run starts clean
     run(True, lambda: L.check(lib.pi_op_abort_cancel(word.ptr, 7, None)))                       # a late cancel of the old run cannot touch it
     assert word.get(np.int32)[0] == 8 << 1
+    assert np.array_equal(word.get(np.int32)[8:15], counters), "launches that did the work are not counted"
     lib.pi_weight_free(w)
     del flag
 

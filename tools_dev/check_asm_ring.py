@@ -49,5 +49,13 @@ for km in re.finditer(r"^(_Z8k_mmq_g2\S+):.*?\.Lfunc_end\d+:", text, re.S | re.M
         if hit and not in_asm:
             bad += 1
             print(f"{km.group(1)}: line {n}: `{t}` touches v{sorted(hit)} while its load (line {pending[min(hit)]}) is in flight")
+# a spilled ring register would be stored before its load has landed: the hand-counted instances must not spill at all
+for m in re.finditer(r"\.name:\s+(_Z8k_mmq_g2\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+    if int(m.group(2)):
+        bad += 1
+        print(f"{m.group(1)}: {m.group(2)} spilled VGPRs")
+if total == 0:
+    bad += 1
+    print("no ring loads found: the audit did not see k_mmq_g2 at all")
 print(f"{total} ring loads checked, {bad} violations")
 sys.exit(1 if bad else 0)
