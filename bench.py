@@ -261,7 +261,8 @@ def compact_line(out, detail_path=None):
     if "by_family" in r:
         rl["by_family"] = {name: {"share": f.get("share_of_gpu_time"), "frac": f.get("frac")} for name, f in r["by_family"].items()}
     if "stages" in r:                                                        # N > 1: one short row per stage
-        rl["stages"] = [{"rank": s_.get("rank"), "layers": s_.get("layers"), "gpu_ms_per_call": s_.get("gpu_ms_per_call"), "frac": round(s_.get("GBps", 0.0) / HBM_PEAK_GBS, 4)} for s_ in r["stages"]]
+        rl["stages"] = [{"rank": s_.get("rank"), "layers": s_.get("layers"), "gpu_ms_per_call": s_.get("gpu_ms_per_call"), "frac": round(s_.get("GBps", 0.0) / HBM_PEAK_GBS, 4),
+                         "hop_store": s_.get("hop_store"), "ring": s_.get("ring_alloc")} for s_ in r["stages"]]
     line["roofline"] = rl
     if "cpu_baseline" in out:
         c = out["cpu_baseline"]

@@ -91,8 +91,10 @@ template <int TYPE, int S> struct mq_w { uint32_t dd, rec, rec2; mq_q<S> q; mq_q
 // NC: chunks of 16 tokens per pass over the weights (prompt batches: NC = 2 walks 32 tokens with ONE weight stream — the operand of a (block, lane k) is built once and
 // fed to one MFMA per chunk; every chunk keeps its own chains, so each token's bits are those of a 16-token pass)
 // PIPE (S >= 2, one chunk, Q4_K / Q5_K): the block step as a two-stage software pipeline — see "pipelined form" below
+// The kernel body as a device function (inlined into k_mmq_kq and into the two-type k_mmq_kq2t): workgroup `wg` of the launch's part that starts at row group `group0`
+// and ends at `n_groups` (both counted over the whole launch: the segments' wave0 are) walks row groups group0 + wg * R ..
 template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
-__global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
+static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const int n_groups, const int wg, const int group0) {
     static_assert(!PIPE || (NC == 1 && S >= 2 && TYPE != PI_Q6_K), "pipelined form: one chunk, split row groups, Q4_K / Q5_K");
     static_assert(NC == 1 || (NC == 2 && !NT8), "two chunks only for full 16-token chunks");
     static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
@@ -100,13 +102,12 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
     constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q6 ? 1600 : Q5 ? 832 : 320;
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if (pi_aborted(g.abort_w, 1)) return;
     constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0) + (Q6 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
     constexpr int FRAG = NT8 ? 512 : 1024, CH_LDS = 8 * FRAG + 1024, MQ_BLK_LDS = NC * CH_LDS, NP1 = NT8 ? 5 : 9, NP = NC * NP1;   // NP: DMA pieces of 1 KB per block (all chunks)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
     const int r = lane & 15, gq = lane >> 4;                                              // weight row r, K-slice gq: sub-blocks 2gq, 2gq+1; C tile: tokens 4 gq ..
-    const int rg_raw = (int) blockIdx.x * R + rgl;
+    const int rg_raw = group0 + wg * R + rgl;
     const bool active = rg_raw < n_groups;
     const int rg = active ? rg_raw : n_groups - 1;
     const int si = (rg >= g.seg[1].wave0) + (rg >= g.seg[2].wave0);
@@ -546,6 +547,23 @@ tiles_done:
     }
 }
 
+template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
+__global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
+    if (pi_aborted(g.abort_w, 1)) return;
+    mmq_kq_body<TYPE, S, R, TB, NT8, NC, PIPE>(g, n_groups, (int) blockIdx.x, 0);
+}
+// Two weight types in ONE matrix-core launch (<= 8 tokens): the Q4_K_M mixtures keep attn_q / attn_k in Q4_K and put attn_v into Q5_K or Q6_K (llama.cpp:7923-7933).  At one
+// or two tokens k_mmvq_kq2 carries all three; from three tokens attn_v used to be a launch of its own behind q + k (64 row groups of the 70B model: 12-15 us on the VALU
+// kernel, all of it launch latency).  Here the first `wgs_a` workgroups walk the TA segments (row groups [0, groups_a)) and the rest the TB segments (the launch's LAST
+// segments) — a workgroup is of one type, so each keeps its own tile format, blocks per tile and barriers; both parts share S and R (the block size).  The v part runs in the
+// shadow of q + k: 192 + 22 workgroups of the 70B model are still one round.  Same bits as the single-type launches (the body is the same code).
+template <int TA, int TB_, int S, int R, int TBA, int TBB>
+__global__ void __launch_bounds__(64 * S * R) k_mmq_kq2t(const mmvq_args g, const int groups_a, const int groups_all, const int wgs_a) {
+    if (pi_aborted(g.abort_w, 1)) return;
+    if ((int) blockIdx.x < wgs_a) mmq_kq_body<TA, S, R, TBA, true>(g, groups_a, (int) blockIdx.x, 0);
+    else mmq_kq_body<TB_, S, R, TBB, true>(g, groups_all, (int) blockIdx.x - wgs_a, groups_a);
+}
+
 // =================================================================================================================
 // k_mmq_g2<R, TB>: Q4_K, <= 8 tokens, tall launches (the fused up + gate of a layer: 3 584 row groups = 14 per CU) — two row groups per wave, packed accumulators.
 //
@@ -853,6 +871,50 @@ static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hip
     else if (type == PI_Q5_K) mmq_dispatch_t<PI_Q5_K>(g, groups, cfg, stream, ea, eb);
     else mmq_dispatch_t<PI_Q4_K>(g, groups, cfg, stream, ea, eb);
 }
+// ---- two weight types in one launch (k_mmq_kq2t): Q4_K segments followed by Q5_K or Q6_K segments, 3..8 tokens, S = 4 (the short-matrix configurations) ----
+template <int TB_, int R>
+static void mmq_2t_go(const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int TBA = 4, TBB = TB_ == PI_Q6_K ? 2 : 4;                                    // blocks per tile at <= 8 tokens, as in mmq_dispatch_t's S = 4 rows
+    constexpr size_t tiles = (size_t) 3 * (TBA > TBB ? TBA : TBB) * (8 * 512 + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
+    constexpr size_t lds = tiles > fold ? tiles : fold;
+    static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, TBA, TBB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
+    const int wgs_a = (groups_a + R - 1) / R, wgs_b = (groups_all - groups_a + R - 1) / R;
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
+    else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
+}
+static void mmq_2t_dispatch(int type_b, int r, const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (type_b == PI_Q6_K) { if (r == 1) mmq_2t_go<PI_Q6_K, 1>(g, groups_a, groups_all, stream, ea, eb); else if (r == 2) mmq_2t_go<PI_Q6_K, 2>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go<PI_Q6_K, 3>(g, groups_a, groups_all, stream, ea, eb); }
+    else                   { if (r == 1) mmq_2t_go<PI_Q5_K, 1>(g, groups_a, groups_all, stream, ea, eb); else if (r == 2) mmq_2t_go<PI_Q5_K, 2>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go<PI_Q5_K, 3>(g, groups_a, groups_all, stream, ea, eb); }
+}
+// row groups per workgroup (S = 4) the single-type dispatcher would give the Q4_K part; 0: that part is not one of the short-matrix configurations (no two-type launch)
+static int mmq_2t_rows_per_wg(int64_t rows_a) {
+    const int groups = (int) ((rows_a + 15) / 16 * 256 / pi_cu_count());
+    return groups > 768 ? 0 : groups > 512 ? 3 : groups >= 384 ? 2 : 1;
+}
+// may a launch of n_a Q4_K matrices (rows_a rows in all) followed by matrices of type_b go out as ONE matrix-core launch?  PI_MMQ_2T=0 switches it off.
+bool pi_mmq2_applies(int type_b, int n_tok, int64_t rows_a) {
+    static const bool on = !(getenv("PI_MMQ_2T") && atoi(getenv("PI_MMQ_2T")) == 0);
+    if (!on || (type_b != PI_Q5_K && type_b != PI_Q6_K) || n_tok > 8) return false;
+    return pi_mmq_wants(PI_Q4_K, n_tok, rows_a) && mmq_2t_rows_per_wg(rows_a) > 0;
+}
+// L: segments [0, n_a) Q4_K, [n_a, nseg) of type_b, all with tile-major copies; g.frag / g.aux / g.nt set
+int pi_mmq_launch2(int type_b, int n_a, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (pi_op_mul_mat_reserve() != 0) return -1;
+    mmvq_args & g = L.g;
+    int groups = 0, groups_a = 0; int64_t rows_a = 0;
+    for (int i = 0; i < MMVQ_MAX_SEG; i++) {
+        if (i < L.nseg) { g.seg[i].wave0 = groups; groups += (g.seg[i].M + 15) / 16; if (i < n_a) { groups_a = groups; rows_a += g.seg[i].M; } }
+        else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
+    }
+    const int r = mmq_2t_rows_per_wg(rows_a);
+    if (r <= 0 || n_a <= 0 || n_a >= L.nseg || g.nt > 8) { pi_set_error("pi_mmq_launch2: not a two-type launch"); return -1; }
+    g.dbg = 0;
+    mmq_2t_dispatch(type_b, r, g, groups_a, groups, stream, ea, eb);
+    PI_CHECK_LAUNCH();
+    return 0;
+}
+
 static const int mmq_cfgs[] = { 17, 18, 14, 22, 24, 41, 42, 43 };
 // dynamic-LDS limits of every instance, set once and outside any stream capture (a launch inside a captured graph must not change function attributes)
 extern "C" int pi_op_mul_mat_reserve(void) {
@@ -860,6 +922,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
     for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int type_b : { PI_Q5_K, PI_Q6_K }) for (int r : { 1, 2, 3 }) mmq_2t_dispatch(type_b, r, g, 0, 0, nullptr, nullptr, nullptr);
     done = true;
     PI_CHECK_LAUNCH();
     return 0;

@@ -928,10 +928,24 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     }
     const bool all_b = type_b >= 0 && type_b_mask == (1 << n_w) - 1;            // a single type that is not Q4_K
     const bool mixed = type_b >= 0 && !all_b;
-    if (type_b == -2 || (mixed && !mmvq2_applies(PI_Q4_K, type_b, n_tok, (int) (w0->ne0 / 256)))) {
+    // ... or, at 3..8 tokens, on the matrix cores (k_mmq_kq2t): the Q4_K matrices first, the second type's behind them
+    bool mixed_mfma = false; int n_a = 0;
+    if (mixed && vdt == PI_Q8_K) {
+        while (n_a < n_w && ws[n_a]->type == PI_Q4_K) n_a++;
+        bool suffix = n_a > 0 && type_b_mask == (((1 << n_w) - 1) & ~((1 << n_a) - 1)), copies = true;
+        int64_t rows_a = 0;
+        for (int i = 0; i < n_w; i++) { copies = copies && ws[i]->mq != nullptr; if (i < n_a) rows_a += ws[i]->ne1; }
+        mixed_mfma = suffix && copies && n_tok >= pi_mmq_min_nt() && pi_mmq2_applies(type_b, n_tok, rows_a);
+    }
+    if (type_b == -2 || (mixed && !mixed_mfma && !mmvq2_applies(PI_Q4_K, type_b, n_tok, (int) (w0->ne0 / 256)))) {
         bool same = true;
         for (int i = 1; i < n_w; i++) same = same && ws[i]->type == w0->type;
-        if (!same) { pi_set_error("pi_op_mul_mat_multi: weights differ in type (only Q4_K with Q5_K or Q6_K share a launch, at 1-2 tokens)"); return -1; }
+        if (!same) {
+            if (rope) { pi_set_error("pi_op_mul_mat_multi: weights differ in type (Q4_K with Q5_K or Q6_K share a launch at 1-2 tokens, and at 3-8 on the matrix cores)"); return -1; }
+            // plain outputs: the matrices that cannot share a launch go out one by one
+            for (int i = 0; i < n_w; i++) { const int rc = mul_mat_multi_impl(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, nullptr, stream_); if (rc) return rc; }
+            return 0;
+        }
     }
     if (vdt != PI_Q8_K && n_w > 1) {
         for (int i = 0; i < n_w; i++) { const int rc = mul_mat_multi_impl(1, ws + i, q8, n_tok, outs + i, ress ? ress + i : nullptr, nullptr, stream_); if (rc) return rc; }
@@ -949,7 +963,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     bool mfma = !mixed && vdt == PI_Q8_K && pi_mmq_wants(w0->type, n_tok, rows_all);
     for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
-    if (mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
+    if (mfma || mixed_mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
     const int step = mfma ? (n_tok > 16 ? pi_mmq_max_nt() : 16) : 8;
     for (int t0 = 0; t0 < n_tok; t0 += step) {
         const int nt = n_tok - t0 < step ? n_tok - t0 : step;
@@ -978,6 +992,17 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             else { L.g.ad = base + od + (size_t) t0 * nbq * 8; L.g.abs_ = nullptr; }
         }
         int rc = -1;
+        if (mixed_mfma) {
+            L.g.frag = base + ofa + (size_t) (t0 / 16) * nbq * 8192;
+            L.g.aux = base + oax + (size_t) (t0 / 16) * nbq * 1024;
+            L.g.type_b_mask = 0;
+            hipEvent_t ea = nullptr, eb = nullptr;
+            const bool sample = kt_begin(PI_Q4_K, nt, L, ea, eb, PI_KT_MMQ);
+            rc = pi_mmq_launch2(type_b, n_a, L, stream, ea, eb);
+            if (sample) kt_end(PI_Q4_K, nt, L, ea, eb, PI_KT_MMQ);
+            if (rc) return rc;
+            continue;
+        }
         if (mixed) {
             if (type_b == PI_Q5_K) rc = nt == 1 ? launch_mmvq2<PI_Q5_K, 1>(L, stream) : launch_mmvq2<PI_Q5_K, 2>(L, stream);
             else                   rc = nt == 1 ? launch_mmvq2<PI_Q6_K, 1>(L, stream) : launch_mmvq2<PI_Q6_K, 2>(L, stream);
@@ -1048,7 +1073,11 @@ extern "C" int pi_op_mul_mat_qkv_rope(const pi_weight * wq, const pi_weight * wk
     {   // attn_q / attn_k in Q4_K with attn_v in Q5_K or Q6_K (the Q4_K_M mixture, llama.cpp:7923-7933): ONE launch at decode widths
         int tb_type = -1, n_a = 0; bool ok2 = true;
         for (int j = 0; j < 3; j++) { if (ws[j]->type == PI_Q4_K) n_a++; else if (tb_type < 0 || tb_type == ws[j]->type) tb_type = ws[j]->type; else ok2 = false; }
-        if (ok2 && n_a > 0 && n_a < 3 && mmvq2_applies(PI_Q4_K, tb_type, n_tok, (int) (wq->ne0 / 256))) {
+        // (and from three tokens on the matrix cores, when the Q4_K matrices come first: k_mmq_kq2t)
+        int64_t rows_a = 0; bool copies = true, a_first = true;
+        for (int j = 0; j < 3; j++) { copies = copies && ws[j]->mq != nullptr; if (ws[j]->type == PI_Q4_K) { rows_a += ws[j]->ne1; a_first = a_first && j < n_a; } }
+        const bool on_mfma = a_first && copies && n_tok >= pi_mmq_min_nt() && pi_mmq2_applies(tb_type, n_tok, rows_a);
+        if (ok2 && n_a > 0 && n_a < 3 && (mmvq2_applies(PI_Q4_K, tb_type, n_tok, (int) (wq->ne0 / 256)) || on_mfma)) {
             mmvq_rope r;
             r.pos = pos; r.cs = tb->cs; r.dyn = dyn_dev; r.kv_head = kv_head; r.hd = hd;
             for (int j = 0; j < 3; j++) { r.store[j] = store[j]; r.dst16[j] = dst[j]; r.stride16[j] = stride[j]; }

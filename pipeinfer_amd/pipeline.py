@@ -323,7 +323,14 @@ def bench_main(args, rank, world):
     cache = args.cache
     os.makedirs(cache, exist_ok=True)
 
+    # the whole model's file, when an N = 1 run of this box has left it in the cache: every rank maps it and uploads only its own layer range (the loader is lazy per
+    # range) — a second 41 GB of stage files would not fit the GPU box's /tmp beside it (the tensors are the same bytes: same seed, same generator)
+    full_path = B.model_path(cache, tspec, tft, 0x5EED, args.signal, args.noise)
+    use_full = os.path.exists(full_path)
+
     def stage_file(tag, only):
+        if use_full:
+            return full_path
         path = os.path.join(cache, f"{tspec}-{tft}-bigram-g{args.signal}-n{args.noise}-{tag}of{n_stage}.gguf")
         made.append(path)
         if not os.path.exists(path):

@@ -406,7 +406,7 @@ def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_lay
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("workload,n_predict,n_draft,n_parallel,p_accept", [("7b", 48, 3, 3, 0.1), ("70b-l4", 48, 3, 3, 0.1), ("falcon40b-l4", 40, 3, 3, 0.002), ("goliath-l4", 40, 8, 2, 0.002)])
+@pytest.mark.parametrize("workload,n_predict,n_draft,n_parallel,p_accept", [("7b", 20, 3, 3, 0.1), ("70b-l4", 32, 3, 3, 0.1), ("falcon40b-l4", 28, 3, 3, 0.002), ("goliath-l4", 24, 8, 2, 0.002)])
 def test_every_run_equals_the_oracle_at_full_size_shapes(workload, n_predict, n_draft, n_parallel, p_accept):
     """the same per-run comparison at the shapes of BASELINE's configurations: the whole Llama-2-7B Q4_K_M (K = 4096 / 11008, 32 layers), and
     Llama-2-70B shapes (GQA 64/8, K = 8192 / 28672: the tile-per-wave decode instances, the matrix-core kernel on verify batches and prompt
@@ -598,16 +598,24 @@ def test_bench_starts_its_own_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PYTHONPATH=root, OMP_NUM_THREADS="2", PIPEINFER_CACHE=str(tmp_path / "models"))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    detail = str(tmp_path / "detail.json")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--detail", detail]
     r = subprocess.run(cmd, env=dict(env, PIPEINFER_ALLOW_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 3 and out["value"] > 0 and out["lossless_vs_target_only"] is True
-    assert out["transport"] in ("peer", "host") and out["devices_shared"] is True
+    assert len(lines) == 1 and len(lines[0]) < 4000, r.stdout                    # ONE small line on stdout (the driver keeps a tail of the output) ...
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["value"] > 0 and line["lossless_vs_target_only"] is True and line["detail"] == detail
+    assert line["transport"] in ("peer", "host") and line["devices_shared"] is True
+    rl = line["roofline"]
+    assert rl["bound"] == "hbm" and rl["frac"] > 0 and rl["family"] in rl["by_family"] and [s_["rank"] for s_ in rl["stages"]] == [1, 2], rl      # the by-family roofline of N = 1, summed over the stages
+    out = json.load(open(detail))                                                 # ... everything else in the detail file
     assert set(out["hop_ms"]) == {"1", "2"} and set(out["wait_for_input_ms"]) == {"1", "2"}
-    print("bench --gpus 3 (one shared GPU):", {k: out[k] for k in ("value", "transport", "hop_ms", "hop_us_per_run", "wait_for_input_ms")})
+    assert set(out["roofline"]["by_family_per_stage"]) == {"1", "2"}
+    st = {s_["rank"]: s_ for s_ in out["roofline"]["stages"]}
+    assert st[1]["hop_store"] == ("kernel" if out["transport"] == "peer" else "memcpy") and st[2]["ring_alloc"] in ("fine-grained", "uncached", "coarse-grained (hipMalloc)", "none"), st
+    print("bench --gpus 3 (one shared GPU):", {k: out[k] for k in ("value", "transport", "hop_ms", "hop_us_per_run", "wait_for_input_ms")}, {r_: (s_["hop_store"], s_["ring_alloc"]) for r_, s_ in st.items()},
+          {k: (v["share_of_gpu_time"], v["frac"]) for k, v in out["roofline"]["by_family"].items()})
     # more ranks than devices without the override: refused loudly, non-zero exit, no result line
     r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r2.returncode != 0 and "refusing to share devices" in r2.stderr and not r2.stdout.strip()

@@ -634,6 +634,61 @@ def test_two_weight_types_share_one_launch(gpu, types, k, n_tok):
         lib.pi_weight_free(w)
 
 
+@pytest.mark.parametrize("types", [(O.Q4_K, O.Q4_K, O.Q5_K), (O.Q4_K, O.Q4_K, O.Q6_K), (O.Q4_K, O.Q6_K, O.Q6_K)])
+@pytest.mark.parametrize("k,n_tok,n_head,n_head_kv", [(2048, 3, 48, 2), (8192, 6, 48, 4), (4096, 8, 40, 8), (5120, 5, 32, 32), (8192, 4, 64, 8)])
+def test_two_weight_types_share_one_matrix_core_launch(gpu, types, k, n_tok, n_head, n_head_kv):
+    """The same mixture at verify widths (3..8 tokens): attn_v (Q5_K / Q6_K) rides in the q + k matrix-core launch (k_mmq_kq2t: the first workgroups walk the Q4_K row
+    groups, the last ones the second type's, each with its own tile format) instead of being a launch of its own behind it.  Bits: the oracle's vec_dot per matrix
+    (ggml-quants.c:5318-5381, 5967-6050, 6741-6810); RoPE and the cache writes those of the separate operators.  Shapes: 70B-like GQA (64 / 8 heads of 128), MHA, a
+    ragged row count per workgroup, K = 5120 (a last tile that is not full)."""
+    lib, U = gpu
+    from pipeinfer_amd import lib as L
+    rng = np.random.default_rng(k + 7 * n_tok)
+    hd, n_ctx, kv_head = 128, 24, 7
+    n_embd, n_gqa = n_head * hd, n_head_kv * hd
+    ws, blocks = [], []
+    for t, m in zip(types, (n_embd, n_gqa, n_gqa)):
+        b = synth.random_blocks(t, m * k, rng, 0.05).reshape(m, -1)
+        blocks.append(b)
+        ws.append(upload_weight(lib, t, m, k, b))
+    act = rng.standard_normal((n_tok, k)).astype(np.float32)
+    pos = rng.integers(0, 200, n_tok).astype(np.int32)
+    table = lib.pi_rope_table_create(256, hd, 10000.0, 1.0, 0)
+    xd, pd = U.Dev(act), U.Dev(pos)
+    q8 = U.Dev(nbytes=lib.pi_q8_nbytes(O.Q8_K, k, n_tok))
+    L.check(lib.pi_op_quantize(O.Q8_K, xd.ptr, k, n_tok, q8.ptr, None))
+    outs = [U.Dev(nbytes=4 * n_tok * m) for m in (n_embd, n_gqa, n_gqa)]
+    wl = (C.c_void_p * 3)(*ws); ol = (C.c_void_p * 3)(*[o.ptr for o in outs])
+    lib.pi_kernel_timing(1, 1 << 30)                                   # count the launches: ONE matrix-core launch for the three matrices
+    L.check(lib.pi_op_mul_mat_multi(3, wl, q8.ptr, n_tok, ol, None, None))
+    lib.pi_device_sync()
+    import bench as B
+    rows = [r for r in B.timing_rows(lib) if r["family"] <= 1]
+    lib.pi_kernel_timing(0, 8)
+    assert len(rows) == 1 and rows[0]["family"] == 1 and rows[0]["launches"] == 1, rows
+    o = O.Impl("oracle")
+    for t, m, b, dv in zip(types, (n_embd, n_gqa, n_gqa), blocks, outs):
+        want = o.mul_mat(t, b, k, m, act)
+        got = dv.get(np.float32, (n_tok, m))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (O.TYPE_NAMES[t], float(np.abs(got - want).max()))
+    dyn = U.Dev(np.array([kv_head, 32, n_tok, 0], np.int32))
+    res = []
+    for fused in (False, True):
+        q16 = U.Dev(np.zeros(n_tok * n_embd, np.uint16)); kc = U.Dev(np.zeros(n_ctx * n_gqa, np.uint16)); vc = U.Dev(np.zeros(n_ctx * n_gqa, np.uint16))
+        if fused:
+            L.check(lib.pi_op_mul_mat_qkv_rope(ws[0], ws[1], ws[2], q8.ptr, n_tok, pd.ptr, table, hd, n_head, n_head_kv, -1, dyn.ptr, q16.ptr, kc.ptr, vc.ptr, None))
+        else:
+            L.check(lib.pi_op_rope_kv_store(outs[0].ptr, outs[1].ptr, outs[2].ptr, n_embd, n_gqa, n_gqa, pd.ptr, table, 0, hd, n_head, n_head_kv, n_tok, kv_head, q16.ptr, kc.ptr, vc.ptr, None, None))
+        lib.pi_device_sync()
+        res.append((q16.get(np.uint16), kc.get(np.uint16), vc.get(np.uint16)))
+    for a, b, name in zip(res[0], res[1], "qkv"):
+        assert np.array_equal(a, b), name
+    assert res[0][1].any() and res[0][2].any()
+    lib.pi_rope_table_free(table)
+    for w in ws:
+        lib.pi_weight_free(w)
+
+
 def test_abort_word_stops_kernels_of_the_cancelled_run_only(gpu):
     """Kernel-granular early cancellation (reference: the abort callback polled between graph nodes, ggml.c:15748-15811, llama.cpp:5665-5687): every hot-path
     kernel launched under pi_set_abort_word reads (run id << 1 | aborted) on entry.  pi_op_abort_cancel is a compare-and-swap on the run id: it stops the run that
