@@ -50,9 +50,9 @@ int pi_mmq_min_nt() {
     return v;
 }
 extern "C" int pi_op_mmq_min_tokens(void) { return pi_mmq_min_nt(); }
-// tokens one launch of the matrix-core kernel walks: 32 (two chunks of 16 over one weight stream) unless PI_MMQ_CHUNKS=1
+// tokens one launch of the matrix-core kernel walks: 64 (four chunks of 16 over one weight stream, register-staged activations); PI_MMQ_CHUNKS=2 / 1: 32 / 16
 int pi_mmq_max_nt() {
-    static const int v = [] { const char * e = getenv("PI_MMQ_CHUNKS"); return e && atoi(e) == 1 ? 16 : 32; }();
+    static const int v = [] { const char * e = getenv("PI_MMQ_CHUNKS"); return e && atoi(e) == 1 ? 16 : e && atoi(e) == 2 ? 32 : 64; }();
     return v;
 }
 bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
@@ -93,10 +93,14 @@ template <int TYPE, int S> struct mq_w { uint32_t dd, rec, rec2; mq_q<S> q; mq_q
 // PIPE (S >= 2, one chunk, Q4_K / Q5_K): the block step as a two-stage software pipeline — see "pipelined form" below
 // The kernel body as a device function (inlined into k_mmq_kq and into the two-type k_mmq_kq2t): workgroup `wg` of the launch's part that starts at row group `group0`
 // and ends at `n_groups` (both counted over the whole launch: the segments' wave0 are) walks row groups group0 + wg * R ..
-template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
+// STG (prompt passes, NC = 4: 33..64 tokens over ONE weight stream): the activation image of a block — NC x 9 KB — is staged through registers (global_load -> ds_write,
+// two LDS buffers, one barrier per block) instead of by LDS-DMA: three DMA buffers of that size would leave the first 64 KB of LDS, the range an M0-based DMA
+// destination can address.  The reference decodes a prompt as ONE batch of up to n_batch = 512 tokens (llama.cpp:5493-5496, speculative.cpp:235-239).
+template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false, bool STG = false>
 static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const int n_groups, const int wg, const int group0) {
     static_assert(!PIPE || (NC == 1 && S >= 2 && TYPE != PI_Q6_K), "pipelined form: one chunk, split row groups, Q4_K / Q5_K");
-    static_assert(NC == 1 || (NC == 2 && !NT8), "two chunks only for full 16-token chunks");
+    static_assert(NC == 1 || ((NC == 2 || NC == 4) && !NT8), "several chunks only for full 16-token chunks");
+    static_assert(STG == (NC == 4) && (!STG || (TB == 1 && !PIPE)), "four chunks: register-staged, one block per tile");
     static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
     constexpr bool Q5 = TYPE == PI_Q5_K, Q6 = TYPE == PI_Q6_K;
     constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q6 ? 1600 : Q5 ? 832 : 320;
@@ -236,7 +240,111 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
             }
         }
     };
+    // ---- four chunks (STG): the block's weight operands are built ONCE — they do not depend on the chunk — and the chunks then run one after the other, each with its own
+    //      d / fragments / MFMAs / chain updates, behind a scheduling barrier: the generic form below keeps every chunk's d and fragments live at once (402 VGPRs at S = 2) ----
+    auto compute_pp = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
+        const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if constexpr (Q6) {
+            const int n = gq >> 1, hh = gq & 1;
+            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
+            const uint32_t aoff = (uint32_t) (r + 32 * n) * 16 + 8 * hh;
+            uint4 b1[KS], b2[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+                const int half = S == 1 ? (kk >> 2) : S == 2 ? s : (s >> 1);
+                const uint32_t selA = 0x04000400u + (uint32_t) half * 0x00010001u, selB = selA + 0x00020002u;
+                const uint32_t SLa = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, selA), 0xE400E400u);
+                const uint32_t SHa = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec2, selA), 0x4C004C00u, 0xF408F408u);
+                const uint32_t SLb = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, selB), 0x2C002C00u, 0xD400D400u);
+                const uint32_t SHb = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec2, selB), 0xE408E408u);
+                const uint32_t q = qdword(W, kk), q8 = q >> 8;
+                const uint32_t h = hdword(W, kk) >> (2 * hh), h8 = h >> 8;
+                const uint32_t w0 = pk_add((q & 0x000F000Fu) | magic | ((h & 0x00030003u) << 4), 0xE420E420u);
+                const uint32_t w1 = pk_add((q8 & 0x000F000Fu) | magic | ((h8 & 0x00030003u) << 4), 0xE420E420u);
+                const uint32_t w2 = pk_add((q & 0x00F000F0u) | magic | ((h & 0x00300030u) << 4), 0xE600E600u);
+                const uint32_t w3 = pk_add((q8 & 0x00F000F0u) | magic | ((h8 & 0x00300030u) << 4), 0xE600E600u);
+                b1[kk] = make_uint4(pk_mul(w0, SHa), pk_mul(w1, SHa), pk_mul(w2, SHb), pk_mul(w3, SHb));
+                b2[kk] = make_uint4(pk_mul(w0, SLa), pk_mul(w1, SLa), pk_mul(w2, SLb), pk_mul(w3, SLb));
+            }
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++) {
+                const float4 dy4 = *(const float4 *) (blk + ch * CH_LDS + 8 * FRAG + 16 * gq);
+                const float d[4] = { dy4.x * dx, dy4.y * dx, dy4.z * dx, dy4.w * dx };
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++) {
+                    const uint8_t * fr = blk + ch * CH_LDS + (s * KS + kk) * FRAG + aoff;
+                    const uint2 a_lo = *(const uint2 *) fr, a_hi = *(const uint2 *) (fr + 16 * 16);
+                    const uint4 af = make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
+                    pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b1[kk]), z, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, b2[kk]), c, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[ch][kk][i] = fmaf(d[i], c[i], acc[ch][kk][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff)), dminx = pi_h2f((uint16_t) (W.dd >> 16));
+            const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);
+            const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);
+            const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);
+            uint4 bw[KS];
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+                const uint32_t q = qdword(W, kk), qh = q >> 8;
+                if constexpr (Q5) {
+                    const uint32_t t = hdword(W, kk) >> (2 * gq), th = t >> 8;
+                    bw[kk].x = pk_fma((q & 0x000F000Fu) | magic | ((t & 0x00010001u) << 4), S1, C1);
+                    bw[kk].y = pk_fma((qh & 0x000F000Fu) | magic | ((th & 0x00010001u) << 4), S1, C1);
+                    bw[kk].z = pk_fma((q & 0x00F000F0u) | magic | ((t & 0x00020002u) << 7), S2, C2);
+                    bw[kk].w = pk_fma((qh & 0x00F000F0u) | magic | ((th & 0x00020002u) << 7), S2, C2);
+                } else {
+                    bw[kk].x = pk_fma((q & 0x000F000Fu) | magic, S1, C1);
+                    bw[kk].y = pk_fma((qh & 0x000F000Fu) | magic, S1, C1);
+                    bw[kk].z = pk_fma((q & 0x00F000F0u) | magic, S2, C2);
+                    bw[kk].w = pk_fma((qh & 0x00F000F0u) | magic, S2, C2);
+                }
+            }
+            const uint32_t M0 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04020402u), 0xE400E400u);
+            const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);
+#pragma unroll
+            for (int ch = 0; ch < NC; ch++) {
+                const float4 dy4 = *(const float4 *) (blk + ch * CH_LDS + 8 * FRAG + 16 * gq);
+                const float dy[4] = { dy4.x, dy4.y, dy4.z, dy4.w };
+                float d[4], nd[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { d[i] = dy[i] * dx; nd[i] = -dy[i] * dminx; }
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++) {
+                    const uint4 af = *(const uint4 *) (blk + ch * CH_LDS + (s * KS + kk) * FRAG + lane * 16);
+                    const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw[kk]), z, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[ch][kk][i] = fmaf(d[i], c[i], acc[ch][kk][i]);
+                }
+                const uint2 bs = *(const uint2 *) (blk + ch * CH_LDS + 8 * FRAG + 64 + lane * 8);
+                const uint4 am = make_uint4(bs.x, bs.y, 0u, 0u);
+                if constexpr (Q5) {
+                    if (s == 0) {
+                        const uint4 bm = make_uint4(M0, M1, 0u, 0u);
+                        const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const float prod = nd[i] * cm[i]; accm[ch][0][i] = accm[ch][0][i] + prod; }
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < CS; cc++) {
+                        const int c = s * CS + cc;
+                        const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);
+                        const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) accm[ch][cc][i] = fmaf(nd[i], cm[i], accm[ch][cc][i]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk, bool live) __attribute__((always_inline)) {
+        if constexpr (STG) { compute_pp(W, blk); return; }
         if constexpr (Q6) { compute_q6(W, blk); return; }
         // ---- block scalars: d, dmin of the row; this lane's two scales and two mins, bytes of one record ----
         const uint32_t ddl = live ? W.dd : 0u;
@@ -395,19 +503,67 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
     constexpr int NB = 3;
     static_assert(D == 2 * TB, "ring = two tiles");
     mq_w<TYPE, S> ring[D];
-#pragma unroll
-    for (int u = 0; u < D; u++) load_w(u, ring[u]);
     const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
+    if constexpr (!STG) {
 #pragma unroll
-    for (int j = 0; j < NB - 1; j++) dma_tile(j, lds0 + j * TB * MQ_BLK_LDS);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();
+        for (int u = 0; u < D; u++) load_w(u, ring[u]);
+#pragma unroll
+        for (int j = 0; j < NB - 1; j++) dma_tile(j, lds0 + j * TB * MQ_BLK_LDS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+    }
     // after the DMAs of tile T + NB - 1 a wave issues TB * LW refills in tile T; when tile T ends, the DMAs of tile T + 1 are older than
     // (NB - 2) tiles of refills + this tile's refills + at least floor(9 TB / NW) DMAs of each younger tile
     constexpr int DMA_MIN = (NP * TB) / NW, WAIT_N = (NB - 1) * TB * LW + (NB - 2) * DMA_MIN;
     // 2 NB tiles per trip: buffer (T % NB) and ring half (T % 2) are compile-time.  The uniform branches around a tile and around a block's
     // compute are deliberate: they are basic-block boundaries for the scheduler, which otherwise interleaves several blocks, doubles the
     // registers in use and spills (measured: 90 -> 124 VGPRs at S = 4, 170 -> 256 + 340 bytes of scratch at S = 1 without them)
+    if constexpr (STG) {
+        // ---- register-staged form: block b is computed from LDS buffer b & 1 while block b + 1's image travels global -> registers; it is written to the other buffer behind the
+        //      compute and one barrier ends the step (the buffer being written was last read in step b - 1, which every wave has left through the barrier that ended it).
+        //      No branch anywhere near a load: the source addresses are clamped (chunks past the launch's last one re-read that one: their results are never stored). ----
+        constexpr int NTHR = 64 * S * R, UNITS = NC * 576, NL = (UNITS + NTHR - 1) / NTHR;          // 16-byte units of one block image, per thread
+        const int nch = (nt + 15) >> 4;
+        // (addresses are recomputed per use: a handful of VALU per 16-byte unit, against ten registers held through the whole loop)
+        uint4 st[NL];
+        auto stage_load = [&](int b) __attribute__((always_inline)) {
+            const uint32_t bb = (uint32_t) (b < nb ? b : nb - 1);
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                const int u = i * NTHR + (int) threadIdx.x < UNITS ? i * NTHR + (int) threadIdx.x : UNITS - 1;
+                const int ch = u / 576, w = u - ch * 576, chs = ch < nch ? ch : nch - 1;
+                const size_t cb = (size_t) chs * nb + bb;
+                st[i] = w < 512 ? *(const uint4 *) (g.frag + cb * 8192 + (size_t) w * 16) : *(const uint4 *) (g.aux + cb * 1024 + (size_t) (w - 512) * 16);
+            }
+        };
+        auto stage_store = [&](uint8_t * buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                const int u = i * NTHR + (int) threadIdx.x < UNITS ? i * NTHR + (int) threadIdx.x : UNITS - 1;
+                const int ch = u / 576, w = u - ch * 576;
+                *(uint4 *) (buf + ch * CH_LDS + w * 16) = st[i];
+            }
+        };
+        mq_w<TYPE, S> W0, W1;
+        stage_load(0);
+        load_w(0, W0); load_w(1, W1);
+        stage_store(lds);
+        __syncthreads();
+        for (int b0 = 0; b0 < nb; b0 += 2) {
+            stage_load(b0 + 1);
+            compute(W0, lds, true);
+            load_w(b0 + 2, W0);
+            stage_store(lds + MQ_BLK_LDS);
+            __syncthreads();
+            if (b0 + 1 >= nb) break;
+            stage_load(b0 + 2);
+            compute(W1, lds + MQ_BLK_LDS, true);
+            load_w(b0 + 3, W1);
+            stage_store(lds);
+            __syncthreads();
+        }
+        __syncthreads();
+    } else
     if constexpr (PIPE) {
         static_assert(TB % 2 == 0, "the pending sets alternate with the block parity");
         mq_act A0, A1;
@@ -550,7 +706,7 @@ tiles_done:
 template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const int n_groups) {
     if (pi_aborted(g.abort_w, 1)) return;
-    mmq_kq_body<TYPE, S, R, TB, NT8, NC, PIPE>(g, n_groups, (int) blockIdx.x, 0);
+    mmq_kq_body<TYPE, S, R, TB, NT8, NC, PIPE, NC == 4>(g, n_groups, (int) blockIdx.x, 0);
 }
 // Two weight types in ONE matrix-core launch (<= 8 tokens): the Q4_K_M mixtures keep attn_q / attn_k in Q4_K and put attn_v into Q5_K or Q6_K (llama.cpp:7923-7933).  At one
 // or two tokens k_mmvq_kq2 carries all three; from three tokens attn_v used to be a launch of its own behind q + k (64 row groups of the 70B model: 12-15 us on the VALU
@@ -791,9 +947,9 @@ tiles_done:
 static bool mmq_pipe_on() { static const bool on = !(getenv("PI_MMQ_PIPE") && atoi(getenv("PI_MMQ_PIPE")) == 0); return on; }
 template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false>
 static void mmq_go2(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    constexpr size_t tiles = (size_t) 3 * TB * NC * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
+    constexpr size_t tiles = (size_t) (NC == 4 ? 2 : 3) * TB * NC * (8 * (NT8 ? 512 : 1024) + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
-    static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
+    static_assert(NC == 4 || tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
     // (Two blocks per scheduling region — the block-axis analogue of k_mmq_g2's two row groups — was built and measured too: no gain on any split-row-group shape,
     //  Q6_K 8192 x 28672 62.7 -> 67.5 us; removed.)
     // the pipelined block step pays at 9..16 tokens (same-box A/B, us per launch: 8192 x 8192 18.70 -> 17.66, 8192 x 28672 53.7 -> 50.2) and is a wash at <= 8 (17.02 / 17.17, 44.7 / 44.4)
@@ -811,7 +967,8 @@ template <int TYPE, int S, int R, int TB16, int TB8>
 static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     if (g.nt <= 8) mmq_go2<TYPE, S, R, TB8, true>(g, groups, stream, ea, eb);
     else if (g.nt <= 16) mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
-    else mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
+    else if (g.nt <= 32) mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
+    else mmq_go2<TYPE, S, R, 1, false, 4>(g, groups, stream, ea, eb);                     // prompt passes: four chunks over one weight stream, register-staged activations
 }
 
 template <int TYPE>
@@ -823,6 +980,9 @@ static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t
     // 72.1 / 71.6 -> 54.6 / 53.3, 44032 x 4096 59.1 / 58.7 -> 56.2 / 55.8, Q6_K 32000 x 8192 78.0 / 75.2 -> 77.9 / 75.8; 70B prompts 987 -> 1 098 tok/s.  PI_MMQ_S1NC2=0: round 3's choice.
     static const bool s1nc2 = !(getenv("PI_MMQ_S1NC2") && atoi(getenv("PI_MMQ_S1NC2")) == 0);
     if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14) && !s1nc2) cfg = 24;
+    // four chunks (33..64 tokens): a one-wave row group would carry 4 x 48 chain registers; two-wave row groups (4 x 24) keep them in registers
+    static const int pp_tall = getenv("PI_MMQ_PP_TALL_CFG") ? atoi(getenv("PI_MMQ_PP_TALL_CFG")) : 24;      // (A/B: 42 = four waves x two row groups)
+    if (g.nt > 32 && (cfg == 17 || cfg == 18 || cfg == 14 || cfg == 24)) cfg = pp_tall;
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;
@@ -921,7 +1081,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     static bool done = false;
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
-    for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32, 64 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
     for (int type_b : { PI_Q5_K, PI_Q6_K }) for (int r : { 1, 2, 3 }) mmq_2t_dispatch(type_b, r, g, 0, 0, nullptr, nullptr, nullptr);
     done = true;
     PI_CHECK_LAUNCH();

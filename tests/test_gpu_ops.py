@@ -117,6 +117,9 @@ def test_mul_mat_golden_blocks(gpu, t):
                                           (512, 4100, 5), (1024, 2100, 8), (256, 5500, 3), (512, 9222, 5), (256, 8200, 3), (768, 12288, 16), (512, 12000, 2),
                                           # ... 17..32 tokens: two chunks of 16 over ONE weight stream (every waves-per-row-group choice; a ragged second chunk; prompts in steps of 32)
                                           (4096, 2064, 32), (2048, 9000, 24), (1024, 14000, 33), (512, 20000, 32), (768, 12288, 48), (256, 30000, 31), (8192, 130, 64), (1024, 6200, 18),
+                                          # ... 33..64 tokens: four chunks over ONE weight stream, activations staged through registers (prompt passes; a ragged last chunk, 64 + 36 tokens,
+                                          # every waves-per-row-group choice: <= 383 / 384..512 / 513..768 / more row groups)
+                                          (4096, 2064, 64), (2048, 9000, 40), (512, 20000, 100), (256, 7000, 128), (28672, 40, 50), (1024, 10000, 57),
                                           # Q4_0 / Q8_0 range-per-wave kernel: 4, 8, 12 groups per wave, ragged last wave, rows not a multiple of 8
                                           (1024, 19, 1), (4544, 71, 1), (4544, 71, 2), (16384, 9, 1), (18176, 13, 1), (24576, 11, 1), (24576, 11, 2), (32768, 8, 1),
                                           # rows shorter than a 256-value chunk / with a last half chunk (32-blocks only): the tiny Baichuan, Refact and Bloom fixtures
