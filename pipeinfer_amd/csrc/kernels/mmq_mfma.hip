@@ -41,6 +41,7 @@
 using pi_half8 = __attribute__((ext_vector_type(8))) _Float16;
 using pi_half2 = __attribute__((ext_vector_type(2))) _Float16;
 using pi_f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef uint32_t pi_u32x4 __attribute__((ext_vector_type(4)));
 
 int pi_mmq_min_nt() {
     // measured on 70B shapes (tools_dev/perf_mmvq.py, us per launch, 8192x8192 / 28672x8192 / 8192x28672; one token: 11.2 / 30.4 / 34.0): the VALU
@@ -54,6 +55,17 @@ extern "C" int pi_op_mmq_min_tokens(void) { return pi_mmq_min_nt(); }
 int pi_mmq_max_nt() {
     static const int v = [] { const char * e = getenv("PI_MMQ_CHUNKS"); return e && atoi(e) == 1 ? 16 : e && atoi(e) == 2 ? 32 : 64; }();
     return v;
+}
+// tokens per launch of a prompt pass over matrices of `rows` rows in all: 64 (four chunks over one weight stream, register-staged activations) — except for the tall launches
+// (> 1152 row groups: the fused up + gate), whose one-wave row groups walk two chunks at 2.7 TB/s and would have to be split over four waves for four (measured, 70B up + gate
+// per 64 tokens: 2 x 99 us in two-chunk launches, 218-260 us in one four-chunk launch; every shorter launch gains: ffn_down Q6_K 2 x 108 -> 143, Q4_K 2 x 83 -> 122, wo 2 x 27 -> 41)
+int pi_mmq_step(int type, int n_tok, int64_t rows) {
+    (void) type;
+    static const int force = getenv("PI_MMQ_STEP") ? atoi(getenv("PI_MMQ_STEP")) : 0;
+    if (force) return force;
+    if (n_tok <= 16) return 16;
+    const int64_t groups = (rows + 15) / 16 * 256 / pi_cu_count();
+    return groups > 1152 ? (pi_mmq_max_nt() < 32 ? pi_mmq_max_nt() : 32) : pi_mmq_max_nt();
 }
 bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
@@ -525,7 +537,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         constexpr int NTHR = 64 * S * R, UNITS = NC * 576, NL = (UNITS + NTHR - 1) / NTHR;          // 16-byte units of one block image, per thread
         const int nch = (nt + 15) >> 4;
         // (addresses are recomputed per use: a handful of VALU per 16-byte unit, against ten registers held through the whole loop)
-        uint4 st[NL];
+        pi_u32x4 st[NL];                                                          // (a native vector type: an array of HIP's uint4 structs stayed in scratch memory)
         auto stage_load = [&](int b) __attribute__((always_inline)) {
             const uint32_t bb = (uint32_t) (b < nb ? b : nb - 1);
 #pragma unroll
@@ -533,7 +545,8 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
                 const int u = i * NTHR + (int) threadIdx.x < UNITS ? i * NTHR + (int) threadIdx.x : UNITS - 1;
                 const int ch = u / 576, w = u - ch * 576, chs = ch < nch ? ch : nch - 1;
                 const size_t cb = (size_t) chs * nb + bb;
-                st[i] = w < 512 ? *(const uint4 *) (g.frag + cb * 8192 + (size_t) w * 16) : *(const uint4 *) (g.aux + cb * 1024 + (size_t) (w - 512) * 16);
+                const uint8_t * src = w < 512 ? g.frag + cb * 8192 + (size_t) w * 16 : g.aux + cb * 1024 + (size_t) (w - 512) * 16;
+                st[i] = *(const pi_u32x4 *) src;
             }
         };
         auto stage_store = [&](uint8_t * buf) __attribute__((always_inline)) {
@@ -541,7 +554,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
             for (int i = 0; i < NL; i++) {
                 const int u = i * NTHR + (int) threadIdx.x < UNITS ? i * NTHR + (int) threadIdx.x : UNITS - 1;
                 const int ch = u / 576, w = u - ch * 576;
-                *(uint4 *) (buf + ch * CH_LDS + w * 16) = st[i];
+                *(pi_u32x4 *) (buf + ch * CH_LDS + w * 16) = st[i];
             }
         };
         mq_w<TYPE, S> W0, W1;
@@ -713,11 +726,19 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq(const mmvq_args g, const 
 // kernel, all of it launch latency).  Here the first `wgs_a` workgroups walk the TA segments (row groups [0, groups_a)) and the rest the TB segments (the launch's LAST
 // segments) — a workgroup is of one type, so each keeps its own tile format, blocks per tile and barriers; both parts share S and R (the block size).  The v part runs in the
 // shadow of q + k: 192 + 22 workgroups of the 70B model are still one round.  Same bits as the single-type launches (the body is the same code).
-template <int TA, int TB_, int S, int R, int TBA, int TBB>
+// RB: row groups per workgroup of the SECOND type's part.  The part is small (64 row groups of the 70B model) and, in Q6_K, slow per block: three row groups to a workgroup made
+// it the launch's long pole (27-29 us against 21 for q + k alone); with RB = 1 it spreads over 64 CUs, one wave per SIMD (the workgroup's other waves leave at once — a
+// terminated wave does not take part in barriers), and the launch is still one round: 192 + 64 workgroups.
+// NC = 4: the same for prompt passes (33..64 tokens, register-staged activations): attn_v's 64 row groups were a 37-41 us launch of their own per 64 tokens.
+template <int TA, int TB_, int S, int R, int RB, int TBA, int TBB, int NC = 1>
 __global__ void __launch_bounds__(64 * S * R) k_mmq_kq2t(const mmvq_args g, const int groups_a, const int groups_all, const int wgs_a) {
+    static_assert(NC == 1 || (NC == 4 && TBA == 1 && TBB == 1), "verify widths (<= 8 tokens) or four chunks");
     if (pi_aborted(g.abort_w, 1)) return;
-    if ((int) blockIdx.x < wgs_a) mmq_kq_body<TA, S, R, TBA, true>(g, groups_a, (int) blockIdx.x, 0);
-    else mmq_kq_body<TB_, S, R, TBB, true>(g, groups_all, (int) blockIdx.x - wgs_a, groups_a);
+    if ((int) blockIdx.x < wgs_a) mmq_kq_body<TA, S, R, TBA, NC == 1, NC, false, NC == 4>(g, groups_a, (int) blockIdx.x, 0);
+    else {
+        if constexpr (RB < R) { if ((int) threadIdx.x >= 64 * S * RB) return; }
+        mmq_kq_body<TB_, S, RB, TBB, NC == 1, NC, false, NC == 4>(g, groups_all, (int) blockIdx.x - wgs_a, groups_a);
+    }
 }
 
 // =================================================================================================================
@@ -738,7 +759,6 @@ __global__ void __launch_bounds__(64 * S * R) k_mmq_kq2t(const mmvq_args g, cons
 // The fold needs no LDS: all eight chains of a (row, token) sit in two lanes 32 apart (v_permlane32_swap), summed in hsum_float_8's order.
 // Same bits as k_mmq_kq, the VALU kernel and the reference (test_mul_mat_vs_oracle runs every shape through it).
 // =================================================================================================================
-typedef uint32_t pi_u32x4 __attribute__((ext_vector_type(4)));
 struct g2_w { uint32_t dd, rec; pi_u32x4 q0, q1; };      // one lane's share of one Q4_K block of one row group: (d, dmin), its scales / mins record, 8 quant dwords
 template <int R, int TB>
 __global__ void __launch_bounds__(64 * R) k_mmq_g2(const mmvq_args g, const int n_groups) {
@@ -968,7 +988,8 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
     if (g.nt <= 8) mmq_go2<TYPE, S, R, TB8, true>(g, groups, stream, ea, eb);
     else if (g.nt <= 16) mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
     else if (g.nt <= 32) mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
-    else mmq_go2<TYPE, S, R, 1, false, 4>(g, groups, stream, ea, eb);                     // prompt passes: four chunks over one weight stream, register-staged activations
+    else if constexpr (S == 4) mmq_go2<TYPE, S, R, 1, false, 4>(g, groups, stream, ea, eb);   // prompt passes: four chunks over one weight stream, register-staged activations
+    else mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);                         // (not reached: mmq_dispatch_t sends launches of > 32 tokens to the four-wave configurations)
 }
 
 template <int TYPE>
@@ -981,8 +1002,10 @@ static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t
     static const bool s1nc2 = !(getenv("PI_MMQ_S1NC2") && atoi(getenv("PI_MMQ_S1NC2")) == 0);
     if (g.nt > 16 && (cfg == 17 || cfg == 18 || cfg == 14) && !s1nc2) cfg = 24;
     // four chunks (33..64 tokens): a one-wave row group would carry 4 x 48 chain registers; two-wave row groups (4 x 24) keep them in registers
-    static const int pp_tall = getenv("PI_MMQ_PP_TALL_CFG") ? atoi(getenv("PI_MMQ_PP_TALL_CFG")) : 24;      // (A/B: 42 = four waves x two row groups)
-    if (g.nt > 32 && (cfg == 17 || cfg == 18 || cfg == 14 || cfg == 24)) cfg = pp_tall;
+    // four chunks: four-wave row groups (48 chain registers per wave; two-wave row groups need 96 + the staged block image: 256 VGPRs and ~90 spilled inside the loop).
+    // Tall launches (one-wave row groups) do not come here: pi_mmq_step keeps them at 32 tokens per launch.  PI_MMQ_PP_CFG overrides (A/B).
+    static const int pp_cfg = getenv("PI_MMQ_PP_CFG") ? atoi(getenv("PI_MMQ_PP_CFG")) : 0;
+    if (g.nt > 32) { if (pp_cfg) cfg = pp_cfg; else if (cfg == 17 || cfg == 18 || cfg == 14 || cfg == 24 || cfg == 22) cfg = 43; }
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;
@@ -1032,45 +1055,80 @@ static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hip
     else mmq_dispatch_t<PI_Q4_K>(g, groups, cfg, stream, ea, eb);
 }
 // ---- two weight types in one launch (k_mmq_kq2t): Q4_K segments followed by Q5_K or Q6_K segments, 3..8 tokens, S = 4 (the short-matrix configurations) ----
-template <int TB_, int R>
+template <int TB_, int R, int RB>
 static void mmq_2t_go(const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     constexpr int TBA = 4, TBB = TB_ == PI_Q6_K ? 2 : 4;                                    // blocks per tile at <= 8 tokens, as in mmq_dispatch_t's S = 4 rows
     constexpr size_t tiles = (size_t) 3 * (TBA > TBB ? TBA : TBB) * (8 * 512 + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
     static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
-    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, TBA, TBB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
-    const int wgs_a = (groups_a + R - 1) / R, wgs_b = (groups_all - groups_a + R - 1) / R;
-    if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
-    else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
+    const int wgs_a = (groups_a + R - 1) / R, wgs_b = (groups_all - groups_a + RB - 1) / RB;
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
+    else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
 }
-static void mmq_2t_dispatch(int type_b, int r, const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    if (type_b == PI_Q6_K) { if (r == 1) mmq_2t_go<PI_Q6_K, 1>(g, groups_a, groups_all, stream, ea, eb); else if (r == 2) mmq_2t_go<PI_Q6_K, 2>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go<PI_Q6_K, 3>(g, groups_a, groups_all, stream, ea, eb); }
-    else                   { if (r == 1) mmq_2t_go<PI_Q5_K, 1>(g, groups_a, groups_all, stream, ea, eb); else if (r == 2) mmq_2t_go<PI_Q5_K, 2>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go<PI_Q5_K, 3>(g, groups_a, groups_all, stream, ea, eb); }
+// four chunks: the second part always one row group per workgroup (a prompt launch is many rounds long anyway)
+template <int TB_, int R>
+static void mmq_2t_go4(const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr size_t tiles = (size_t) 2 * 4 * (8 * 1024 + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
+    constexpr size_t lds = tiles > fold ? tiles : fold;
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, 1, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }
+    const int wgs_a = (groups_a + R - 1) / R, wgs_b = groups_all - groups_a;
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, 1, 1, 1, 4>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
+    else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, 1, 1, 1, 4>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
+}
+template <int TB_>
+static void mmq_2t_dispatch_t(int r, int rb, bool four, const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (four) {                                                                             // (launches of a prompt pass: up to 64 tokens, four chunks)
+        if (r == 1) mmq_2t_go4<TB_, 1>(g, groups_a, groups_all, stream, ea, eb); else if (r == 2) mmq_2t_go4<TB_, 2>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go4<TB_, 3>(g, groups_a, groups_all, stream, ea, eb);
+        return;
+    }
+    if (r == 1) mmq_2t_go<TB_, 1, 1>(g, groups_a, groups_all, stream, ea, eb);
+    else if (r == 2) { if (rb == 1) mmq_2t_go<TB_, 2, 1>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go<TB_, 2, 2>(g, groups_a, groups_all, stream, ea, eb); }
+    else             { if (rb == 1) mmq_2t_go<TB_, 3, 1>(g, groups_a, groups_all, stream, ea, eb); else mmq_2t_go<TB_, 3, 3>(g, groups_a, groups_all, stream, ea, eb); }
+}
+static void mmq_2t_dispatch(int type_b, int r, int rb, bool four, const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    if (type_b == PI_Q6_K) mmq_2t_dispatch_t<PI_Q6_K>(r, rb, four, g, groups_a, groups_all, stream, ea, eb);
+    else                   mmq_2t_dispatch_t<PI_Q5_K>(r, rb, four, g, groups_a, groups_all, stream, ea, eb);
 }
 // row groups per workgroup (S = 4) the single-type dispatcher would give the Q4_K part; 0: that part is not one of the short-matrix configurations (no two-type launch)
 static int mmq_2t_rows_per_wg(int64_t rows_a) {
     const int groups = (int) ((rows_a + 15) / 16 * 256 / pi_cu_count());
     return groups > 768 ? 0 : groups > 512 ? 3 : groups >= 384 ? 2 : 1;
 }
-// may a launch of n_a Q4_K matrices (rows_a rows in all) followed by matrices of type_b go out as ONE matrix-core launch?  PI_MMQ_2T=0 switches it off.
-bool pi_mmq2_applies(int type_b, int n_tok, int64_t rows_a) {
-    static const bool on = !(getenv("PI_MMQ_2T") && atoi(getenv("PI_MMQ_2T")) == 0);
-    if (!on || (type_b != PI_Q5_K && type_b != PI_Q6_K) || n_tok > 8) return false;
-    return pi_mmq_wants(PI_Q4_K, n_tok, rows_a) && mmq_2t_rows_per_wg(rows_a) > 0;
+// row groups per workgroup of the second type's part: one when the launch then still is one round of workgroups, else the first part's; 0: more than one round either way
+static int mmq_2t_rows_per_wg_b(int r, int64_t rows_a, int64_t rows_b) {
+    const int64_t wgs_a = ((rows_a + 15) / 16 + r - 1) / r, gb = (rows_b + 15) / 16;
+    if (wgs_a + gb <= pi_cu_count()) return 1;
+    if (wgs_a + (gb + r - 1) / r <= pi_cu_count()) return r;
+    return 0;
 }
-// L: segments [0, n_a) Q4_K, [n_a, nseg) of type_b, all with tile-major copies; g.frag / g.aux / g.nt set
-int pi_mmq_launch2(int type_b, int n_a, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+// may a launch of n_a Q4_K matrices (rows_a rows in all) followed by matrices of type_b (rows_b rows) go out as ONE matrix-core launch?  PI_MMQ_2T=0 switches it off.
+// (Only while both parts fit one round of workgroups: the 7B model's attn_v has as many rows as attn_k — fused, q + k + v would be a round and a half.)
+// n_tok: the PASS's tokens.  Verify widths (<= 8) and prompt passes (> 32: launches of 64 tokens, four chunks; a tail of <= 32 tokens goes out in launches of 8).
+bool pi_mmq2_applies(int type_b, int n_tok, int64_t rows_a, int64_t rows_b) {
+    static const bool on = !(getenv("PI_MMQ_2T") && atoi(getenv("PI_MMQ_2T")) == 0);
+    if (!on || (type_b != PI_Q5_K && type_b != PI_Q6_K) || (n_tok > 8 && n_tok <= 32)) return false;
+    const int r = mmq_2t_rows_per_wg(rows_a);
+    if (n_tok > 32) return r > 0 && pi_mmq_max_nt() >= 64;
+    return pi_mmq_wants(PI_Q4_K, n_tok, rows_a) && r > 0 && mmq_2t_rows_per_wg_b(r, rows_a, rows_b) > 0;
+}
+// L: segments [0, n_a) Q4_K, [n_a, nseg) of type_b, all with tile-major copies; g.frag / g.aux / g.nt set.  four: a launch of a prompt pass (g.nt <= 64 tokens, a multiple
+// of 64 tokens into the pass: the four-chunk instance, whatever is left of the pass); else g.nt <= 8
+int pi_mmq_launch2(int type_b, int n_a, bool four, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     if (pi_op_mul_mat_reserve() != 0) return -1;
     mmvq_args & g = L.g;
-    int groups = 0, groups_a = 0; int64_t rows_a = 0;
+    int groups = 0, groups_a = 0; int64_t rows_a = 0, rows_b = 0;
     for (int i = 0; i < MMVQ_MAX_SEG; i++) {
-        if (i < L.nseg) { g.seg[i].wave0 = groups; groups += (g.seg[i].M + 15) / 16; if (i < n_a) { groups_a = groups; rows_a += g.seg[i].M; } }
+        if (i < L.nseg) { g.seg[i].wave0 = groups; groups += (g.seg[i].M + 15) / 16; if (i < n_a) { groups_a = groups; rows_a += g.seg[i].M; } else rows_b += g.seg[i].M; }
         else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
     }
+    // (the second part's row groups are counted per matrix: each of its matrices starts a row group, like the first part's)
     const int r = mmq_2t_rows_per_wg(rows_a);
-    if (r <= 0 || n_a <= 0 || n_a >= L.nseg || g.nt > 8) { pi_set_error("pi_mmq_launch2: not a two-type launch"); return -1; }
+    int rb = four ? 1 : r > 0 ? mmq_2t_rows_per_wg_b(r, rows_a, rows_b) : 0;
+    if (r > 0 && rb <= 0) rb = r;                                                           // (more than one round: still correct, pi_mmq2_applies does not choose it)
+    if (r <= 0 || n_a <= 0 || n_a >= L.nseg || g.nt > (four ? 64 : 8)) { pi_set_error("pi_mmq_launch2: not a two-type launch"); return -1; }
     g.dbg = 0;
-    mmq_2t_dispatch(type_b, r, g, groups_a, groups, stream, ea, eb);
+    mmq_2t_dispatch(type_b, r, rb, four, g, groups_a, groups, stream, ea, eb);
     PI_CHECK_LAUNCH();
     return 0;
 }
@@ -1082,7 +1140,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
     for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32, 64 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
-    for (int type_b : { PI_Q5_K, PI_Q6_K }) for (int r : { 1, 2, 3 }) mmq_2t_dispatch(type_b, r, g, 0, 0, nullptr, nullptr, nullptr);
+    for (int type_b : { PI_Q5_K, PI_Q6_K }) for (int r : { 1, 2, 3 }) for (int rb : { 1, r }) for (bool four : { false, true }) mmq_2t_dispatch(type_b, r, rb, four, g, 0, 0, nullptr, nullptr, nullptr);
     done = true;
     PI_CHECK_LAUNCH();
     return 0;

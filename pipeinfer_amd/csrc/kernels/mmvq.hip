@@ -933,9 +933,9 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     if (mixed && vdt == PI_Q8_K) {
         while (n_a < n_w && ws[n_a]->type == PI_Q4_K) n_a++;
         bool suffix = n_a > 0 && type_b_mask == (((1 << n_w) - 1) & ~((1 << n_a) - 1)), copies = true;
-        int64_t rows_a = 0;
-        for (int i = 0; i < n_w; i++) { copies = copies && ws[i]->mq != nullptr; if (i < n_a) rows_a += ws[i]->ne1; }
-        mixed_mfma = suffix && copies && n_tok >= pi_mmq_min_nt() && pi_mmq2_applies(type_b, n_tok, rows_a);
+        int64_t rows_a = 0, rows_b = 0;
+        for (int i = 0; i < n_w; i++) { copies = copies && ws[i]->mq != nullptr; if (i < n_a) rows_a += ws[i]->ne1; else rows_b += ws[i]->ne1; }
+        mixed_mfma = suffix && copies && n_tok >= pi_mmq_min_nt() && pi_mmq2_applies(type_b, n_tok, rows_a, rows_b);
     }
     if (type_b == -2 || (mixed && !mixed_mfma && !mmvq2_applies(PI_Q4_K, type_b, n_tok, (int) (w0->ne0 / 256)))) {
         bool same = true;
@@ -964,9 +964,12 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
     if (mfma || mixed_mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);
-    const int step = mfma ? (n_tok > 16 ? pi_mmq_max_nt() : 16) : 8;
-    for (int t0 = 0; t0 < n_tok; t0 += step) {
-        const int nt = n_tok - t0 < step ? n_tok - t0 : step;
+    const int step = mfma ? pi_mmq_step(w0->type, n_tok, rows_all) : 8;
+    for (int t0 = 0, adv = 0; t0 < n_tok; t0 += adv) {
+        // (a two-type matrix-core launch walks up to 8 tokens — a verify pass — or, in a prompt pass, 64: four chunks, the pass's last launch with whatever is left)
+        const int step_now = mixed_mfma ? (n_tok > 8 ? 64 : 8) : step;
+        const int nt = n_tok - t0 < step_now ? n_tok - t0 : step_now;
+        adv = nt;
         mmvq_launch L;
         L.nseg = n_w; L.m_total = 0; L.m_min = 1 << 30; L.wbytes = 0.0; L.any_res = false;
         L.g.K = (int) K; L.g.nb = (int) nbq;
@@ -998,7 +1001,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
             L.g.type_b_mask = 0;
             hipEvent_t ea = nullptr, eb = nullptr;
             const bool sample = kt_begin(PI_Q4_K, nt, L, ea, eb, PI_KT_MMQ);
-            rc = pi_mmq_launch2(type_b, n_a, L, stream, ea, eb);
+            rc = pi_mmq_launch2(type_b, n_a, n_tok > 8, L, stream, ea, eb);
             if (sample) kt_end(PI_Q4_K, nt, L, ea, eb, PI_KT_MMQ);
             if (rc) return rc;
             continue;
@@ -1074,9 +1077,9 @@ extern "C" int pi_op_mul_mat_qkv_rope(const pi_weight * wq, const pi_weight * wk
         int tb_type = -1, n_a = 0; bool ok2 = true;
         for (int j = 0; j < 3; j++) { if (ws[j]->type == PI_Q4_K) n_a++; else if (tb_type < 0 || tb_type == ws[j]->type) tb_type = ws[j]->type; else ok2 = false; }
         // (and from three tokens on the matrix cores, when the Q4_K matrices come first: k_mmq_kq2t)
-        int64_t rows_a = 0; bool copies = true, a_first = true;
-        for (int j = 0; j < 3; j++) { copies = copies && ws[j]->mq != nullptr; if (ws[j]->type == PI_Q4_K) { rows_a += ws[j]->ne1; a_first = a_first && j < n_a; } }
-        const bool on_mfma = a_first && copies && n_tok >= pi_mmq_min_nt() && pi_mmq2_applies(tb_type, n_tok, rows_a);
+        int64_t rows_a = 0, rows_b = 0; bool copies = true, a_first = true;
+        for (int j = 0; j < 3; j++) { copies = copies && ws[j]->mq != nullptr; if (ws[j]->type == PI_Q4_K) { rows_a += ws[j]->ne1; a_first = a_first && j < n_a; } else rows_b += ws[j]->ne1; }
+        const bool on_mfma = a_first && copies && n_tok >= pi_mmq_min_nt() && pi_mmq2_applies(tb_type, n_tok, rows_a, rows_b);
         if (ok2 && n_a > 0 && n_a < 3 && (mmvq2_applies(PI_Q4_K, tb_type, n_tok, (int) (wq->ne0 / 256)) || on_mfma)) {
             mmvq_rope r;
             r.pos = pos; r.cs = tb->cs; r.dyn = dyn_dev; r.kv_head = kv_head; r.hd = hd;

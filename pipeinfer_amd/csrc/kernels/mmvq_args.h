@@ -46,5 +46,5 @@ bool pi_mmq_wants(int type, int n_tok, int64_t rows);
 // launches k_mmq_kq for L (segments filled in, g.frag / g.aux / g.nt set); ea / eb: optional events bracketing the kernel (sampled timing)
 int  pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);
 // two weight types in one matrix-core launch (k_mmq_kq2t): n_a Q4_K segments followed by segments of type_b (Q5_K / Q6_K), 3..8 tokens
-bool pi_mmq2_applies(int type_b, int n_tok, int64_t rows_a);
-int  pi_mmq_launch2(int type_b, int n_a, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);
+bool pi_mmq2_applies(int type_b, int n_tok, int64_t rows_a, int64_t rows_b);
+int  pi_mmq_launch2(int type_b, int n_a, bool four_chunks, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);

@@ -68,6 +68,7 @@ const pi_tables & pi_get_tables();
 // planes from the same width on.  PI_MMQ_MIN_NT overrides (tuning / A-B tests; read once).
 int pi_mmq_min_nt();
 int pi_mmq_max_nt();
+int pi_mmq_step(int type, int n_tok, int64_t rows);             // tokens per matrix-core launch of a pass of n_tok tokens over matrices of `rows` rows in all
 
 static inline bool pi_type_is_legacy(int t) { return t == PI_Q4_1 || t == PI_Q5_0 || t == PI_Q5_1; }
 static inline int pi_type_blck(int t) {
