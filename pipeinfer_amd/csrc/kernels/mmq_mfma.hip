@@ -1066,15 +1066,18 @@ static void mmq_2t_go(const mmvq_args & g, int groups_a, int groups_all, hipStre
     if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
     else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
 }
-// four chunks: the second part always one row group per workgroup (a prompt launch is many rounds long anyway)
+// four chunks.  The kernel's register budget is that of its block size (R = 3: 168 VGPRs): the Q6_K body with ONE row group per workgroup wants 204 (nine staging
+// registers per thread instead of three) and spilled — 121 us for the fused launch against 48 + 41 apart — so the Q6_K part keeps R row groups per workgroup (144 VGPRs);
+// the Q5_K part runs one per workgroup (48.5 us fused against 48 + 37 apart).  A prompt launch is many rounds long anyway.
 template <int TB_, int R>
 static void mmq_2t_go4(const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int RB = TB_ == PI_Q6_K ? R : 1;
     constexpr size_t tiles = (size_t) 2 * 4 * (8 * 1024 + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
-    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, 1, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }
-    const int wgs_a = (groups_a + R - 1) / R, wgs_b = groups_all - groups_a;
-    if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, 1, 1, 1, 4>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
-    else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, 1, 1, 1, 4>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
+    if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }
+    const int wgs_a = (groups_a + R - 1) / R, wgs_b = (groups_all - groups_a + RB - 1) / RB;
+    if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, 1, 1, 4>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
+    else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, 1, 1, 4>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
 }
 template <int TB_>
 static void mmq_2t_dispatch_t(int r, int rb, bool four, const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {

@@ -1,5 +1,5 @@
-"""profiles/r04_pmc_fetch_size_<workload>.json from a rocprofv3 --pmc FETCH_SIZE run of bench.py:
-    python tools_dev/pmc_to_json.py <dir> "<command line that was profiled>" <bench json of THAT run> > profiles/r04_pmc_fetch_size_70b.json
+"""profiles/rNN_pmc_fetch_size_<workload>.json from a rocprofv3 --pmc FETCH_SIZE run of bench.py:
+    python tools_dev/pmc_to_json.py <dir> "<command line that was profiled>" <bench json of THAT run> > profiles/r05_pmc_fetch_size_70b.json
 bytes = FETCH_SIZE (KiB) * 1024 * 2 (gfx950 correction of MI355X_MICROARCH.md, HBM/rocprofv3 section).
 Per kernel family (bench.py: roofline.by_family) the file holds the bytes fetched per launch AND the algorithmic bytes per launch of the very same run (the profiled bench's own
 launch accounting), i.e. bytes fetched per algorithmic byte under the pass widths that schedule really uses.  It carries the sha of the kernel sources it was measured on
@@ -17,7 +17,7 @@ import bench as B  # noqa: E402
 
 TYPES = {"2": "Q4_0", "3": "Q4_1", "6": "Q5_0", "7": "Q5_1", "8": "Q8_0", "10": "Q2_K", "11": "Q3_K", "12": "Q4_K", "13": "Q5_K", "14": "Q6_K"}
 d, source = sys.argv[1], sys.argv[2]
-bench_json = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1]) if len(sys.argv) > 3 else None
+bench_json = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1]) if len(sys.argv) > 3 else None          # (the bench's DETAIL file: the full result)
 raw = collections.defaultdict(list)
 if os.path.isfile(d) and d.endswith(".json"):                                        # re-derive the family tables of an existing file from its by_symbol section
     for name, v in json.load(open(d))["by_symbol"].items():
@@ -32,8 +32,11 @@ def family(name):
     """bench.py's family of a kernel symbol, and a finer key (type, width class) for the mat kernels"""
     m = re.match(r"void k_mmq_kq<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)", name)
     if m:
-        width = "nt17-32" if m.group(6) == "2" else "nt3-8" if m.group(5) == "true" else "nt9-16"
+        width = "nt33-64" if m.group(6) == "4" else "nt17-32" if m.group(6) == "2" else "nt3-8" if m.group(5) == "true" else "nt9-16"
         return "matrix_cores", f"{TYPES.get(m.group(1), m.group(1))}_matrix_cores_{width}"
+    m = re.match(r"void k_mmq_kq2t<(\d+), (\d+), ", name)                           # two weight types in one matrix-core launch (q + k + v): counted with the first type
+    if m:
+        return "matrix_cores", f"{TYPES.get(m.group(1), m.group(1))}+{TYPES.get(m.group(2), m.group(2))}_matrix_cores_two_types"
     m = re.match(r"void k_mmq_g2<(\d+), (\d+)>", name)                               # two row groups per wave: Q4_K, <= 8 tokens
     if m:
         return "matrix_cores", "Q4_K_matrix_cores_nt3-8"

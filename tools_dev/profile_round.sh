@@ -9,19 +9,19 @@ export PI_NO_GRAPHS=1      # rocprofv3 on this image segfaults inside hipGraphLa
 B=$PWD/bench.py
 cd /tmp
 # 1. per-kernel time of the bench command (cpu_baseline leg off: it is CPU work; the other schedules on: they are part of the default run)
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $B --no-cpu-baseline --steps 2 --warmup 1 > $out/stats_bench.json 2> $out/stats_bench.err
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $B --no-cpu-baseline --steps 2 --warmup 1 --detail $out/stats_bench_detail.json > $out/stats_bench.json 2> $out/stats_bench.err
 echo "stats rc=$?"
 # 1b. the target alone (mode 2), for the per-kernel breakdown of one decode call
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_t -o target -- python3 $B --no-cpu-baseline --no-other-schedules --mode 2 --steps 1 --warmup 0 --n-predict 64 > $out/stats_target.json 2> $out/stats_target.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_t -o target -- python3 $B --no-cpu-baseline --no-other-schedules --mode 2 --steps 1 --warmup 0 --n-predict 64 --detail $out/stats_target_detail.json > $out/stats_target.json 2> $out/stats_target.err
 echo "stats target-only rc=$?"
 # 2. HBM bytes per launch (own pass, counters only); kernels are serialised under --pmc, so a short generation — of the DEFAULT schedule (mode 0, run coalescing on): the
 #    matrix-core launches then have the pass widths `value` really runs on (3..8 tokens and the 32-token prompt chunks).  The profiled bench prints its own launch accounting
 #    (roofline.by_family: algorithmic bytes per launch of every kernel family in THAT run); pmc_to_json.py divides the fetched bytes by it.
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o pmc -- python3 $B --no-cpu-baseline --no-other-schedules --steps 1 --warmup 0 --n-predict 48 > $out/pmc_bench.json 2> $out/pmc_bench.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc -o pmc -- python3 $B --no-cpu-baseline --no-other-schedules --steps 1 --warmup 0 --n-predict 48 --detail $out/pmc_bench_detail.json > $out/pmc_bench.json 2> $out/pmc_bench.err
 echo "pmc rc=$?"
 cd - > /dev/null
 find $out -name "*kernel_stats.csv" | head; find $out -name "*counter_collection.csv" | head -2
-python3 tools_dev/pmc_to_json.py $out/pmc "PI_NO_GRAPHS=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-other-schedules --steps 1 --warmup 0 --n-predict 48" $out/pmc_bench.json > $out/pmc_fetch_size.json
+python3 tools_dev/pmc_to_json.py $out/pmc "PI_NO_GRAPHS=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-other-schedules --steps 1 --warmup 0 --n-predict 48" $out/pmc_bench_detail.json > $out/pmc_fetch_size.json
 # keep what travels back small: the raw counter csv can be large
 find $out -name "*.db" -delete
 find $out/pmc -name "*counter_collection.csv" -size +8M -delete
