@@ -419,6 +419,7 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
                 bool fresh = hipDeviceSynchronize() == hipSuccess && hipMemcpy(got.data(), got_dev, PN * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(seen, word2, sizeof seen, hipMemcpyDeviceToHost) == hipSuccess && seen[1] == 0;
                 int bad_at = -1;
                 for (int i = 0; fresh && i < PN; i++) if (got[i] != (float) ((tp->rank - 1) * 7777 + i) + 0.5f) { fresh = false; bad_at = i; }
+                if (getenv("PIPEINFER_TEST_HOP_PROBE_FAIL")) { fresh = false; bad_at = 0; }          // tests: the fall-back every rank takes together when the probe fails
                 if (!fresh) {
                     (void) hipGetLastError();
                     fprintf(stderr, "[pipeinfer transport, rank %d] the hop probe FAILED (%s): a reader enqueued behind the device-side wait did not see the block the upstream device stored before its flag — "

@@ -1066,12 +1066,12 @@ static void mmq_2t_go(const mmvq_args & g, int groups_a, int groups_all, hipStre
     if (ea) hipExtLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, ea, eb, 0, g, groups_a, groups_all, wgs_a);
     else    hipLaunchKernelGGL((k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, TBA, TBB>), dim3((unsigned) (wgs_a + wgs_b)), dim3(64 * 4 * R), lds, stream, g, groups_a, groups_all, wgs_a);
 }
-// four chunks.  The kernel's register budget is that of its block size (R = 3: 168 VGPRs): the Q6_K body with ONE row group per workgroup wants 204 (nine staging
-// registers per thread instead of three) and spilled — 121 us for the fused launch against 48 + 41 apart — so the Q6_K part keeps R row groups per workgroup (144 VGPRs);
-// the Q5_K part runs one per workgroup (48.5 us fused against 48 + 37 apart).  A prompt launch is many rounds long anyway.
+// four chunks.  The kernel's register budget is that of its block size (R = 3: 168 VGPRs): a second part with ONE row group per workgroup stages nine 16-byte units per
+// thread instead of three and spills (Q5_K: 97 registers; the fused launch then took 120 us against 48 + 37 apart), so the second part keeps R row groups per workgroup
+// (measured, q + k + v of a 70B layer per 64 tokens: Q6_K 54 us fused against 117 apart).  A prompt launch is many rounds long anyway.
 template <int TB_, int R>
 static void mmq_2t_go4(const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int RB = TB_ == PI_Q6_K ? R : 1;
+    constexpr int RB = R;
     constexpr size_t tiles = (size_t) 2 * 4 * (8 * 1024 + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
     if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq2t<PI_Q4_K, TB_, 4, R, RB, 1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }
@@ -1126,8 +1126,9 @@ int pi_mmq_launch2(int type_b, int n_a, bool four, mmvq_launch & L, hipStream_t 
         else { g.seg[i] = g.seg[0]; g.seg[i].wave0 = 0x7fffffff; }
     }
     // (the second part's row groups are counted per matrix: each of its matrices starts a row group, like the first part's)
-    const int r = mmq_2t_rows_per_wg(rows_a);
-    int rb = four ? 1 : r > 0 ? mmq_2t_rows_per_wg_b(r, rows_a, rows_b) : 0;
+    int r = mmq_2t_rows_per_wg(rows_a);
+    if (four && type_b == PI_Q5_K && r == 3) r = 2;                                          // (the Q5_K body of the four-chunk form spills 62 registers under the 168 of a 12-wave workgroup; 8 waves: 229, none)
+    int rb = four ? r : r > 0 ? mmq_2t_rows_per_wg_b(r, rows_a, rows_b) : 0;
     if (r > 0 && rb <= 0) rb = r;                                                           // (more than one round: still correct, pi_mmq2_applies does not choose it)
     if (r <= 0 || n_a <= 0 || n_a >= L.nseg || g.nt > (four ? 64 : 8)) { pi_set_error("pi_mmq_launch2: not a two-type launch"); return -1; }
     g.dbg = 0;

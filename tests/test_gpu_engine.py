@@ -332,6 +332,9 @@ def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
 @pytest.mark.parametrize("tgt,dft,seed,ranges,host_rings", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", False), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 11, "0-1,1-2", False),
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", True),
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "host-headers"),   # peer stores, headers published by the host (round 3's hop)
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "probe-fail"),     # the real-pattern hop probe fails on a rank: every rank falls back to host-published headers
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "coarse-ring"),    # PIPEINFER_RING_ALLOC=coarse: the ring as plain hipMalloc memory (rounds 1-4)
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "uncached-ring"),
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-2,2-3", False),       # three stages: a middle stage waits AND publishes
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-3", False)])     # --gpus 2: one stage that is first and last
 def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt, dft, seed, ranges, host_rings):
@@ -348,12 +351,17 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranges.count(',') + 2}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "transport_gpu_worker.py"), str(out), tgt, dft, str(seed), ranges]
     env = dict(os.environ, PYTHONPATH=root, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    host_headers = host_rings == "host-headers"
-    host_rings = host_rings is True
+    mode = host_rings
+    host_headers = mode in ("host-headers", "probe-fail")
+    host_rings = mode is True
     if host_rings:
         env["PIPEINFER_TRANSPORT_HOST"] = "1"
-    if host_headers:
+    if mode == "host-headers":
         env["PIPEINFER_TRANSPORT_FLAGS"] = "0"
+    if mode == "probe-fail":
+        env["PIPEINFER_TEST_HOP_PROBE_FAIL"] = "1"
+    if mode in ("coarse-ring", "uncached-ring"):
+        env["PIPEINFER_RING_ALLOC"] = mode.split("-")[0]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     v = json.loads(out.read_text())
@@ -379,6 +387,15 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
     # device-side arrival flags (the default in device mode): every run is announced downstream before it is computed and the consuming stage's run is enqueued behind a
     # device-side wait; the flag written by the producing stage's STREAM (behind its peer store) is seen by the waiting kernel within microseconds — no host thread on the
     # critical path of a stage boundary (the reference: blocking MPI_Recv, ggml-mpi.c:451-487)
+    if mode == "probe-fail":
+        assert "hop probe FAILED" in r.stderr and "Headers are published by the host" in r.stderr
+    for s in v["stages"]:
+        # decided and logged at the transport's set-up, per rank: how the hop's store is done and what memory the stage's own ring is (round 5: fine-grained by default)
+        assert s["hop_store_kernel"] == (0 if host_rings else 1), s
+        if s["rank"] >= 2 and not host_rings:
+            assert s["ring_alloc"] == {"coarse-ring": 1, "uncached-ring": 3}.get(mode, 2), s
+    if not host_rings and not host_headers:
+        assert "hop probe ok" in r.stderr, r.stderr[-1500:]
     for s in v["stages"]:
         assert bool(s["device_flags"]) == (not host_rings and not host_headers), s
         if s["device_flags"] and s["rank"] >= 2:
