@@ -394,7 +394,7 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
         assert s["hop_store_kernel"] == (0 if host_rings else 1), s
         if s["rank"] >= 2 and not host_rings:
             assert s["ring_alloc"] == {"coarse-ring": 1, "uncached-ring": 3}.get(mode, 2), s
-    if not host_rings and not host_headers:
+    if not host_rings and not host_headers and len(v["stages"]) >= 2:                      # (a stage boundary exists: the real-pattern probe ran on it)
         assert "hop probe ok" in r.stderr, r.stderr[-1500:]
     for s in v["stages"]:
         assert bool(s["device_flags"]) == (not host_rings and not host_headers), s
