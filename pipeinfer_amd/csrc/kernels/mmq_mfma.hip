@@ -67,7 +67,7 @@ int pi_mmq_step(int type, int n_tok, int64_t rows) {
     const int64_t groups = (rows + 15) / 16 * 256 / pi_cu_count();
     return groups > 1152 ? (pi_mmq_max_nt() < 32 ? pi_mmq_max_nt() : 32) : pi_mmq_max_nt();
 }
-bool pi_mmq_supported(int type) { return type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
+bool pi_mmq_supported(int type) { return type == PI_Q3_K || type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
 // accumulator lane and only won from 5 tokens in round 2 (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
 // and on short matrices (attn_v of a GQA model: 64 row groups) only past the VALU kernel's 8 tokens per pass
@@ -110,15 +110,16 @@ template <int TYPE, int S> struct mq_w { uint32_t dd, rec, rec2; mq_q<S> q; mq_q
 // destination can address.  The reference decodes a prompt as ONE batch of up to n_batch = 512 tokens (llama.cpp:5493-5496, speculative.cpp:235-239).
 template <int TYPE, int S, int R, int TB, bool NT8, int NC = 1, bool PIPE = false, bool STG = false>
 static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const int n_groups, const int wg, const int group0) {
-    static_assert(!PIPE || (NC == 1 && S >= 2 && TYPE != PI_Q6_K), "pipelined form: one chunk, split row groups, Q4_K / Q5_K");
+    static_assert(!PIPE || (NC == 1 && S >= 2 && (TYPE == PI_Q4_K || TYPE == PI_Q5_K)), "pipelined form: one chunk, split row groups, Q4_K / Q5_K");
     static_assert(NC == 1 || ((NC == 2 || NC == 4) && !NT8), "several chunks only for full 16-token chunks");
     static_assert(STG == (NC == 4) && (!STG || (TB == 1 && !PIPE)), "four chunks: register-staged, one block per tile");
-    static_assert(TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
-    constexpr bool Q5 = TYPE == PI_Q5_K, Q6 = TYPE == PI_Q6_K;
-    constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : PI_MQ_TILE, QOFF = Q6 ? 1600 : Q5 ? 832 : 320;
+    static_assert(TYPE == PI_Q3_K || TYPE == PI_Q4_K || TYPE == PI_Q5_K || TYPE == PI_Q6_K, "types are added one by one");
+    constexpr bool Q5 = TYPE == PI_Q5_K, Q6 = TYPE == PI_Q6_K, Q3 = TYPE == PI_Q3_K;
+    constexpr uint32_t TILE = Q6 ? PI_MQ_TILE_Q6 : Q5 ? PI_MQ_TILE_Q5 : Q3 ? PI_MQ_TILE_Q3 : PI_MQ_TILE, QOFF = Q6 ? 1600 : (Q5 || Q3) ? 832 : 320;
+    constexpr uint32_t QPART = Q3 ? 512 : 1024;                                          // bytes between the two halves (k = 0..3 / 4..7) of the quants
     static_assert(S == 1 || S == 2 || S == 4, "waves per row group");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + (Q5 ? (S == 1 ? 2 : 1) : 0) + (Q6 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
+    constexpr int KS = 8 / S, CS = 4 / S, NW = S * R, D = 2 * TB, LW = (S == 1 ? 4 : 3) + ((Q5 || Q3) ? (S == 1 ? 2 : 1) : 0) + (Q6 ? (S == 1 ? 2 : 1) : 0);  // LW: vector loads per block of weights
     constexpr int FRAG = NT8 ? 512 : 1024, CH_LDS = 8 * FRAG + 1024, MQ_BLK_LDS = NC * CH_LDS, NP1 = NT8 ? 5 : 9, NP = NC * NP1;   // NP: DMA pieces of 1 KB per block (all chunks)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rgl = wave / S, s = wave % S;                                               // row group inside the workgroup, share of its accumulator lanes
@@ -160,17 +161,17 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
 
     // tile-major copy (runtime.hip: k_repack_mq_q4_K): tile (row group, block) = PI_MQ_TILE contiguous bytes
     const uint8_t * const wbase = sg.mq + (size_t) (rg - sg.wave0) * nb * TILE;
-    const uint32_t dd_off = 4 * r, rec_off = 64 + (Q6 ? 8 : 4) * lane, q_off = QOFF + 16 * lane + (S == 1 ? 0 : S == 2 ? 1024 * s : 1024 * (s >> 1) + 8 * (s & 1));
+    const uint32_t dd_off = 4 * r, rec_off = 64 + (Q6 ? 8 : 4) * lane, q_off = QOFF + 16 * (Q3 ? 2 * r + (gq >> 1) : lane) + (S == 1 ? 0 : S == 2 ? QPART * s : QPART * (s >> 1) + 8 * (s & 1));      // (Q3_K: the row's half gq >> 1 — both K-slices of a half read the same dwords)
     const uint32_t h_off = (Q6 ? 576 + 64 * r + 32 * (gq >> 1) : 320 + 32 * r) + (S == 1 ? 0 : S == 2 ? 16 * s : 8 * s);       // Q6_K: qh of the row's half n = gq >> 1;       // Q5_K: the row's qh bytes 4k..4k+3 of this wave's accumulator lanes (the same for the four K-slices)
     auto load_w = [&](int b, mq_w<TYPE, S> & W) __attribute__((always_inline)) {
         const uint32_t bo = (uint32_t) (b < nb ? b : nb - 1) * TILE;     // unconditional, clamped (see mmvq.hip on branches between a load and its use)
         W.dd = *(const uint32_t *) (wbase + (bo + dd_off));
         if constexpr (Q6) { const uint2 rr = *(const uint2 *) (wbase + (bo + rec_off)); W.rec = rr.x; W.rec2 = rr.y; }
         else W.rec = *(const uint32_t *) (wbase + (bo + rec_off));
-        if constexpr (S == 4) { W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off)); if constexpr (Q5 || Q6) W.h.v[0] = *(const uint2 *) (wbase + (bo + h_off)); }
+        if constexpr (S == 4) { W.q.v[0] = *(const uint2 *) (wbase + (bo + q_off)); if constexpr (Q5 || Q6 || Q3) W.h.v[0] = *(const uint2 *) (wbase + (bo + h_off)); }
         else {
 #pragma unroll
-            for (int i = 0; i < 2 / S; i++) { W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + 1024 * i)); if constexpr (Q5 || Q6) W.h.v[i] = *(const uint4 *) (wbase + (bo + h_off + 16 * i)); }
+            for (int i = 0; i < 2 / S; i++) { W.q.v[i] = *(const uint4 *) (wbase + (bo + q_off + QPART * i)); if constexpr (Q5 || Q6 || Q3) W.h.v[i] = *(const uint4 *) (wbase + (bo + h_off + 16 * i)); }
         }
     };
     auto hdword = [&](const mq_w<TYPE, S> & W, int kk) __attribute__((always_inline)) -> uint32_t {
@@ -212,6 +213,44 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
     //      so sc = 16 * sh + sl is split and the lane sum comes from TWO accumulating MFMAs with operands 16 sh (u - 32) and sl (u - 32) (both exact: |.| <= 4096 in
     //      steps of 16, and <= 480).  K-slice (n, hh) = the groups g = hh (low nibbles) and hh + 2 (high nibbles) of half n; the activation fragment pairs 32-groups
     //      (2c, 2c+1), so the two 8-byte halves of the operand come from two fragment lanes.  No mins (symmetric format). ----
+    // ---- Q3_K (ggml-quants.c:4443-4533): sumi[k] = sum over the eight 32-groups g of sc[2g + (k >> 2)] * sum_{i<4} w * y with w = (2 low bits | high bit << 2) - 4 in
+    //      [-4, 3] and sc in [-32, 31]: sc * w fits f16 exactly, ONE MFMA per (block, accumulator lane), no mins.  K-slice gq = groups 2gq, 2gq+1 = two bit pairs of ONE dword of
+    //      the row's half gq >> 1 (a qs byte holds four groups), high bits from bit (2gq + e) of the hmask bytes; the fragments pair groups (2c, 2c+1) like Q4_K's sub-blocks ----
+    auto operand_q3 = [&](const mq_w<TYPE, S> & W, int kk) __attribute__((always_inline)) -> uint4 {
+        const int half = S == 1 ? (kk >> 2) : S == 2 ? s : (s >> 1);                                       // accumulator lanes k < 4: the first 16 weights of a group, k >= 4: the second
+        const uint32_t selA = 0x04000400u + (uint32_t) half * 0x00010001u, selB = selA + 0x00020002u;     // record bytes: (group 2gq: sub 0, sub 1), (group 2gq+1: sub 0, sub 1), each value + 32
+        const uint32_t SA = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, selA), 0xE420E420u);           // (1024 + sc + 32) - 1056 = sc
+        const uint32_t SB = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, selB), 0xE420E420u);
+        const uint32_t q = qdword(W, kk) >> (4 * (gq & 1)), hm = hdword(W, kk) >> (2 * gq);
+        const uint32_t t0 = (q & 0x03030303u) | ((hm & 0x01010101u) << 2), t1 = ((q >> 2) & 0x03030303u) | ((hm & 0x02020202u) << 1);      // n = low bits | high bit << 2, per byte
+        // 1024 + n as f16 pairs (bytes i0, i2 / i1, i3), minus 1028 = n - 4, times the scale (<= 128 in magnitude: exact)
+        uint4 bw;
+        bw.x = pk_mul(pk_add((t0 & 0x00FF00FFu) | magic, 0xE404E404u), SA);
+        bw.y = pk_mul(pk_add(((t0 >> 8) & 0x00FF00FFu) | magic, 0xE404E404u), SA);
+        bw.z = pk_mul(pk_add((t1 & 0x00FF00FFu) | magic, 0xE404E404u), SB);
+        bw.w = pk_mul(pk_add(((t1 >> 8) & 0x00FF00FFu) | magic, 0xE404E404u), SB);
+        return bw;
+    };
+    auto compute_q3 = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
+        const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
+        const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+        uint4 bw[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) bw[kk] = operand_q3(W, kk);
+#pragma unroll
+        for (int ch = 0; ch < NC; ch++) {
+            const float4 dy4 = *(const float4 *) (blk + ch * CH_LDS + 8 * FRAG + 16 * gq);
+            const float d[4] = { dy4.x * dx, dy4.y * dx, dy4.z * dx, dy4.w * dx };                        // y[i].d * GGML_FP16_TO_FP32(x[i].d)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) {
+                const uint4 af = *(const uint4 *) (blk + ch * CH_LDS + (s * KS + kk) * FRAG + (NT8 ? (gq * 8 + (r & 7)) * 16 : lane * 16));
+                const pi_f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, af), __builtin_bit_cast(pi_half8, bw[kk]), z, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[ch][kk][i] = fmaf(d[i], c[i], acc[ch][kk][i]);
+            }
+            if constexpr (NC > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto compute_q6 = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
         const int n = gq >> 1, hh = gq & 1;
         const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
@@ -356,6 +395,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         }
     };
     auto compute = [&](const mq_w<TYPE, S> & W, const uint8_t * blk, bool live) __attribute__((always_inline)) {
+        if constexpr (Q3) { compute_q3(W, blk); return; }                   // (every width: the operands are built once per block, the chunks run one after the other)
         if constexpr (STG) { compute_pp(W, blk); return; }
         if constexpr (Q6) { compute_q6(W, blk); return; }
         // ---- block scalars: d, dmin of the row; this lane's two scales and two mins, bytes of one record ----
@@ -679,7 +719,7 @@ tiles_done:
                 for (int k = 0; k < 8; k++) a[k] = F[(k * 16 + rr) * 17 + t];
                 float v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
                 const float m0 = FM[(0 * 16 + rr) * 17 + t], m1 = FM[(1 * 16 + rr) * 17 + t], m2 = FM[(2 * 16 + rr) * 17 + t], m3 = FM[(3 * 16 + rr) * 17 + t];
-                v = Q6 ? v : Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
+                v = (Q6 || Q3) ? v : Q5 ? v + m0 : v + ((m0 + m2) + (m1 + m3));                                   // Q5_K: hsum_float_8(acc) + summs
                 if (rr < rows && t < ntc) {
                     if (sg.store) X[rr * 16 + t] = v;
                     else {
@@ -973,7 +1013,7 @@ static void mmq_go2(const mmvq_args & g, int groups, hipStream_t stream, hipEven
     // (Two blocks per scheduling region — the block-axis analogue of k_mmq_g2's two row groups — was built and measured too: no gain on any split-row-group shape,
     //  Q6_K 8192 x 28672 62.7 -> 67.5 us; removed.)
     // the pipelined block step pays at 9..16 tokens (same-box A/B, us per launch: 8192 x 8192 18.70 -> 17.66, 8192 x 28672 53.7 -> 50.2) and is a wash at <= 8 (17.02 / 17.17, 44.7 / 44.4)
-    if constexpr (!PIPE && NC == 1 && S >= 2 && TYPE != PI_Q6_K && !NT8) {
+    if constexpr (!PIPE && NC == 1 && S >= 2 && (TYPE == PI_Q4_K || TYPE == PI_Q5_K) && !NT8) {
         if (!g.frag || mmq_pipe_on()) { mmq_go2<TYPE, S, R, TB, NT8, NC, true>(g, groups, stream, ea, eb); if (g.frag) return; }      // (reserve: both forms set their attribute)
     }
     if (!g.frag) { (void) hipFuncSetAttribute((const void *) k_mmq_kq<TYPE, S, R, TB, NT8, NC, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); return; }   // pi_op_mul_mat_reserve
@@ -1051,6 +1091,7 @@ static void mmq_g2_dispatch(const mmvq_args & g, int groups, hipStream_t stream,
 }
 static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     if (type == PI_Q6_K) mmq_dispatch_t<PI_Q6_K>(g, groups, cfg, stream, ea, eb);
+    else if (type == PI_Q3_K) mmq_dispatch_t<PI_Q3_K>(g, groups, cfg, stream, ea, eb);
     else if (type == PI_Q5_K) mmq_dispatch_t<PI_Q5_K>(g, groups, cfg, stream, ea, eb);
     else mmq_dispatch_t<PI_Q4_K>(g, groups, cfg, stream, ea, eb);
 }
@@ -1143,7 +1184,7 @@ extern "C" int pi_op_mul_mat_reserve(void) {
     static bool done = false;
     if (done) return 0;
     mmvq_args g; memset(&g, 0, sizeof g);                      // g.frag == nullptr: the instances only set their attribute
-    for (int type : { PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32, 64 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
+    for (int type : { PI_Q3_K, PI_Q4_K, PI_Q5_K, PI_Q6_K }) for (int cfg : mmq_cfgs) for (int nt : { 8, 16, 32, 64 }) { g.nt = nt; mmq_dispatch(type, g, 0, cfg, nullptr, nullptr, nullptr); }
     for (int type_b : { PI_Q5_K, PI_Q6_K }) for (int r : { 1, 2, 3 }) for (int rb : { 1, r }) for (bool four : { false, true }) mmq_2t_dispatch(type_b, r, rb, four, g, 0, 0, nullptr, nullptr, nullptr);
     done = true;
     PI_CHECK_LAUNCH();

@@ -20,6 +20,7 @@
 //   F32 / F16     native rows
 #define PI_MQ_TILE 2368      /* bytes of one (16 rows x 256 values) tile of the tile-major Q4_K copy */
 #define PI_MQ_TILE_Q5 2880   /* Q5_K: + 16 rows x 32 bytes of fifth bits */
+#define PI_MQ_TILE_Q3 1856   /* Q3_K: 64 d | 256 scale records | 512 hmask | 1024 qs */
 #define PI_MQ_TILE_Q6 3648   /* Q6_K: 64 d | 512 scale records | 1024 qh | 2048 ql */
 
 struct pi_weight {

@@ -298,6 +298,36 @@ __global__ void k_repack_mq_q6_K(const uint8_t * __restrict__ src, uint8_t * __r
         for (int k = 0; k < 4; k++) { q0[(r + 16 * c) * 4 + k] = ld(64 * n + 32 * hh + 4 * k); q1[(r + 16 * c) * 4 + k] = ld(64 * n + 32 * hh + 16 + 4 * k); }
     }
 }
+// Q3_K, tile-major copy for the MFMA kernel: tile (row group, block) = PI_MQ_TILE_Q3 = 1856 bytes (block: hmask 32 | qs 64 | scales 12 | d, ggml-quants.h).
+//   [   0,   64)  16 rows x d (f16 in a dword)
+//   [  64,  320)  64 records of 4 bytes, record (r + 16 c): the four 6-bit scales of K-slice c as stored (value + 32, decoded like ggml-quants.c:1731-1736): groups 2c and
+//                 2c+1, their first / second 16 weights (sub-blocks 4c .. 4c+3)
+//   [ 320,  832)  16 rows x 32 bytes of hmask (bit g of byte l = high bit of weight l of 32-group g)
+//   [ 832, 1856)  part 0 / part 1: (row r, half h) x 16 bytes = dwords k = 0..3 / 4..7 of qs[32h + 4k ..] (a byte holds groups 4h .. 4h+3 in its four bit pairs)
+__global__ void k_repack_mq_q3_K(const uint8_t * __restrict__ src, uint8_t * __restrict__ dst, int64_t rows, int64_t nb) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;                  // (row group, block, row in group)
+    const int64_t n_rg = (rows + 15) / 16;
+    if (i >= n_rg * nb * 16) return;
+    const int r = (int) (i & 15); const int64_t gb = i >> 4, g = gb / nb, b = gb % nb, row = g * 16 + r;
+    uint8_t * tile = dst + gb * PI_MQ_TILE_Q3;
+    uint32_t * dd = (uint32_t *) tile, * rec = (uint32_t *) (tile + 64), * hm = (uint32_t *) (tile + 320), * q0 = (uint32_t *) (tile + 832), * q1 = (uint32_t *) (tile + 1344);
+    if (row >= rows) {
+        dd[r] = 0;
+        for (int k = 0; k < 8; k++) hm[r * 8 + k] = 0;
+        for (int c = 0; c < 4; c++) rec[r + 16 * c] = 0x20202020u;
+        for (int h = 0; h < 2; h++) for (int k = 0; k < 4; k++) { q0[(r * 2 + h) * 4 + k] = 0; q1[(r * 2 + h) * 4 + k] = 0; }
+        return;
+    }
+    const uint8_t * blk = src + (row * nb + b) * 110;                                    // 2-byte aligned only: assemble dwords from bytes
+    auto ld = [&](int off) { return (uint32_t) blk[off] | (uint32_t) blk[off + 1] << 8 | (uint32_t) blk[off + 2] << 16 | (uint32_t) blk[off + 3] << 24; };
+    dd[r] = (uint32_t) blk[108] | (uint32_t) blk[109] << 8;
+    for (int k = 0; k < 8; k++) hm[r * 8 + k] = ld(4 * k);
+    const uint32_t a0 = ld(96), a1 = ld(100), a2 = ld(104), kmask1 = 0x03030303u, kmask2 = 0x0f0f0f0fu;
+    const uint32_t aux[4] = { (a0 & kmask2) | (((a2 >> 0) & kmask1) << 4), (a1 & kmask2) | (((a2 >> 2) & kmask1) << 4),
+                              ((a0 >> 4) & kmask2) | (((a2 >> 4) & kmask1) << 4), ((a1 >> 4) & kmask2) | (((a2 >> 6) & kmask1) << 4) };
+    for (int c = 0; c < 4; c++) rec[r + 16 * c] = aux[c];                                 // scales 4c .. 4c+3 = sub-blocks (2 (2c) + 0, + 1), (2 (2c+1) + 0, + 1)
+    for (int h = 0; h < 2; h++) for (int k = 0; k < 4; k++) { q0[(r * 2 + h) * 4 + k] = ld(32 + 32 * h + 4 * k); q1[(r * 2 + h) * 4 + k] = ld(32 + 32 * h + 16 + 4 * k); }
+}
 __global__ void k_repack_q6_K(const uint8_t * __restrict__ src, uint8_t * a, uint8_t * sc, uint16_t * d, int64_t nblocks) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks) return;
@@ -384,10 +414,10 @@ __global__ void k_repack_legacy(const uint8_t * __restrict__ src, int type, uint
 static void make_mq_copy(pi_weight * w, const uint8_t * staging, hipStream_t stream) {
     static const bool mq_on = !(getenv("PI_MMQ_COPIES") && atoi(getenv("PI_MMQ_COPIES")) == 0);
     const int type = w->type;
-    if (!mq_on || w->mq || !(type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) return;
+    if (!mq_on || w->mq || !(type == PI_Q3_K || type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K)) return;
     const int threads = 256;
     const int64_t n_rg = (w->ne1 + 15) / 16;
-    const size_t tile_sz = type == PI_Q6_K ? PI_MQ_TILE_Q6 : type == PI_Q5_K ? PI_MQ_TILE_Q5 : PI_MQ_TILE;
+    const size_t tile_sz = type == PI_Q6_K ? PI_MQ_TILE_Q6 : type == PI_Q5_K ? PI_MQ_TILE_Q5 : type == PI_Q3_K ? PI_MQ_TILE_Q3 : PI_MQ_TILE;
     const size_t mq_bytes = (size_t) n_rg * w->nb * tile_sz + 512;
     if (hipMalloc(&w->mq_base, mq_bytes) != hipSuccess) {
         (void) hipGetLastError();
@@ -399,6 +429,7 @@ static void make_mq_copy(pi_weight * w, const uint8_t * staging, hipStream_t str
     w->mq = (const uint8_t *) w->mq_base; w->mq_nbytes = mq_bytes;
     const dim3 mgrid((unsigned) ((n_rg * w->nb * 16 + threads - 1) / threads));
     if (type == PI_Q6_K) hipLaunchKernelGGL(k_repack_mq_q6_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, w->ne1, w->nb);
+    else if (type == PI_Q3_K) hipLaunchKernelGGL(k_repack_mq_q3_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, w->ne1, w->nb);
     else hipLaunchKernelGGL(k_repack_mq_q45_K, mgrid, dim3(threads), 0, stream, staging, (uint8_t *) w->mq_base, w->ne1, w->nb, type == PI_Q5_K ? 1 : 0);
 }
 
