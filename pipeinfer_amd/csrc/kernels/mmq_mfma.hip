@@ -67,7 +67,10 @@ int pi_mmq_step(int type, int n_tok, int64_t rows) {
     const int64_t groups = (rows + 15) / 16 * 256 / pi_cu_count();
     return groups > 1152 ? (pi_mmq_max_nt() < 32 ? pi_mmq_max_nt() : 32) : pi_mmq_max_nt();
 }
-bool pi_mmq_supported(int type) { return type == PI_Q3_K || type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K; }
+bool pi_mmq_supported(int type) {
+    static const bool q3 = !(getenv("PI_MMQ_Q3") && atoi(getenv("PI_MMQ_Q3")) == 0);      // PI_MMQ_Q3=0: Q3_K batches stay on the VALU kernel (A/B)
+    return (type == PI_Q3_K && q3) || type == PI_Q4_K || type == PI_Q5_K || type == PI_Q6_K;
+}
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
 // accumulator lane and only won from 5 tokens in round 2 (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
 // and on short matrices (attn_v of a GQA model: 64 row groups) only past the VALU kernel's 8 tokens per pass
