@@ -948,6 +948,86 @@ int stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_
     return 0;
 }
 
+// ---- a pass of several runs on a stage that is the whole target (--gpus 2: draft + driver on GPU 0, the target alone on GPU 1) --------------------------------------
+// What run coalescing (feeder_main / compose_pass) does for the in-process target, for the transport's serve loop: the runs whose headers wait in the stage's ring — members
+// [0, n_members), in start order — are carried by ONE forward pass over the stage's weights; every member's rows go to its own result buffers.  Same rules: a member that would
+// write or expect older content in a cell another member touches stays out (stage_pass_conflict == pass_conflict on the metadata blocks), a token attends over the n_kv of ITS run,
+// every token keeps the bits it gets alone.  First-and-last stages only (no activations cross a boundary).  0 done, 1 cut short (every member cancelled), < 0 error.
+static void stage_member(pi_run & r, const void * meta, int n_tokens) {
+    const int32_t * m = (const int32_t *) meta;
+    r.meta_host = (uint8_t *) const_cast<void *>(meta); r.n_tokens = n_tokens; r.kv_head = m[2 * n_tokens]; r.n_kv = m[2 * n_tokens + 1];
+}
+bool stage_pass_conflict(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, const void * q_meta, int q_tokens) {
+    std::vector<pi_run> tmp((size_t) n_members + 1);                           // (pass_conflict reads n_tokens, kv_head, n_kv and the block itself)
+    std::vector<pi_run *> members;
+    for (int i = 0; i < n_members; i++) { stage_member(tmp[(size_t) i], metas[i], n_tokens[i]); members.push_back(&tmp[(size_t) i]); }
+    stage_member(tmp[(size_t) n_members], q_meta, q_tokens);
+    const bool c = pass_conflict(ctx, members, &tmp[(size_t) n_members]);
+    for (auto & r : tmp) r.meta_host = nullptr;                                // (borrowed blocks: nothing of these stand-ins is freed)
+    return c;
+}
+int stage_run_pass(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, float * const * logits_host, int32_t * const * topk_ids,
+                   float * const * topk_vals, float * const * topk_sum, int (*should_abort)(void *), void * abort_user) {
+    std::string err;
+    if (!context_prepare(ctx, err)) { ctx->last_error = err; return -1; }
+    if (!ctx->is_first || !ctx->is_last || n_members < 1) { ctx->last_error = "stage_run_pass: a pass of several runs needs a stage that is first and last"; return -1; }
+    if (n_members == 1) return stage_run(ctx, n_tokens[0], metas[0], (size_t) n_tokens[0] * 8 + 16 + (size_t) n_tokens[0] * ((ctx->n_ctx + 31) / 32) * 4, nullptr, nullptr,
+                                         logits_host[0], topk_ids[0], topk_vals[0], topk_sum[0], should_abort, abort_user, nullptr);
+    std::vector<pi_run> tmp((size_t) n_members);
+    std::vector<pi_run *> members;
+    int n = 0, n_kv = 0;
+    for (int i = 0; i < n_members; i++) { stage_member(tmp[(size_t) i], metas[i], n_tokens[i]); members.push_back(&tmp[(size_t) i]); n += n_tokens[i]; n_kv = std::max(n_kv, tmp[(size_t) i].n_kv); }
+    struct unborrow { std::vector<pi_run> & v; ~unborrow() { for (auto & r : v) r.meta_host = nullptr; } } ub{ tmp };
+    if (n > ctx->n_batch) { ctx->last_error = "stage_run_pass: the pass is wider than n_batch"; return -1; }
+    const void * meta = compose_pass(ctx, members, n);
+    if (!meta) return -1;
+    hipStream_t s = ctx->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    const int32_t rid = (++ctx->run_counter) & 0x3fffffff;
+    if (ctx->abort_host) ctx->abort_host[rid & 255] = 0;
+    ctx->stage_run_id.store(rid);
+    bool ok = true, cut = false;
+    (void) hipEventRecord(e0, s);
+    const int nseg = n_segments(ctx), kv_head = ((const int32_t *) meta)[2 * n];
+    if (nseg > 1 && !ctx->seg_events[0]) ok = hipEventCreateWithFlags(&ctx->seg_events[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ctx->seg_events[1], hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = launch_inputs(ctx, n, meta, nullptr);
+    int seg = 0;
+    for (; ok && seg < nseg; seg++) {
+        if (seg >= 2) (void) hipEventSynchronize(ctx->seg_events[seg & 1]);
+        if (seg > 0 && should_abort && should_abort(abort_user)) { cut = true; break; }
+        ok = launch_abort_begin(ctx, rid);
+        if (ok) ok = launch_segment(ctx, n, kv_head, seg, nullptr, true, false, n_kv);
+        if (ok && nseg > 1) ok = hipEventRecord(ctx->seg_events[seg & 1], s) == hipSuccess;
+    }
+    ctx->stat_segments += (uint64_t) seg; ctx->stat_segments_skipped += (uint64_t) (nseg - seg);
+    const size_t nv = ctx->model->hparams.n_vocab;
+    if (ok && !cut) {
+        size_t r0 = 0;
+        for (int i = 0; ok && i < n_members; i++) {                            // every member's rows into its own result slot
+            const size_t m = (size_t) n_tokens[i];
+            ok = hipMemcpyAsync(logits_host[i], ctx->logits_dev + r0 * nv, 4 * m * nv, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(topk_ids[i], ctx->topk_ids_dev + r0 * 8, 4 * m * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(topk_vals[i], ctx->topk_vals_dev + r0 * 8, 4 * m * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                 hipMemcpyAsync(topk_sum[i], ctx->topk_sum_dev + r0, 4 * m, hipMemcpyDeviceToHost, s) == hipSuccess;
+            r0 += m;
+        }
+    }
+    (void) hipEventRecord(e1, s);
+    if (!ok && ctx->abort_host) ctx->abort_host[rid & 255] = 1;
+    if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+    ctx->stage_run_id.store(0);
+    if (ok && !cut && ((ctx->abort_host && ctx->abort_host[rid & 255]) || (should_abort && should_abort(abort_user)))) cut = true;
+    float ms = 0.0f;
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->stat_gpu_ms += ms;
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "stage_run_pass failed"; return -1; }
+    if (cut) return 1;
+    ctx->stat_calls++; ctx->stat_alg_bytes += decode_alg_bytes(ctx, n, n_kv);
+    ctx->stat_passes++; ctx->stat_pass_runs += (uint64_t) n_members; ctx->stat_pass_tokens += (uint64_t) n; ctx->stat_coalesced_passes++;
+    return 0;
+}
+
 int context_finish(llama_context * ctx, pi_run * run) {
     if (!run) return -1;
     if (ctx->remote) {

@@ -236,6 +236,10 @@ struct pi_stage_hop { const void * in_flag = nullptr; uint32_t in_ticket = 0; vo
 int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta_bytes, const float * x_in, float * x_out,
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
                int (*should_abort)(void *) = nullptr, void * abort_user = nullptr, const pi_stage_hop * hop = nullptr);        // 0 done, 1 cut short (should_abort, a cancel, or upstream), < 0 error
+// a stage that is the whole target carries the runs waiting in its ring in ONE forward pass (context.cpp: run coalescing for the transport's serve loop)
+bool stage_pass_conflict(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, const void * q_meta, int q_tokens);
+int  stage_run_pass(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, float * const * logits_host, int32_t * const * topk_ids,
+                    float * const * topk_vals, float * const * topk_sum, int (*should_abort)(void *), void * abort_user);
 void stage_abort_run(llama_context * ctx, int32_t run_id);                  // any thread: run `run_id` (ctx->stage_run_id while stage_run computes it) returns from every kernel on entry from now on; no effect on any other run
 bool hop_store(void * dst, const void * src, size_t bytes, hipStream_t s);        // context.cpp: a stage's activations into the consumer's ring slot (kernel store for device memory)
 void hop_store_set_mode(int mode);                                               // 1: always the kernel (device rings), 2: always hipMemcpyAsync (host rings), 0: ask the runtime per call (no transport)

@@ -72,6 +72,10 @@ struct shm_layout {
     std::atomic<int32_t> flags_off;              // some rank cannot use device-side arrival flags: every rank publishes its headers from the host
     std::atomic<uint64_t> n_cancel;
     std::atomic<uint64_t> cancel[TP_CANCEL_CAP]; // (generation << 32) | batch id
+    // what a coalescing stage sees of the head's driver thread (context.cpp: wait_for_reaction, for the in-process feeder): calls it has made, whether it is blocked waiting
+    // for a result, and its call count right after it consumed its latest result
+    std::atomic<uint64_t> head_epoch, head_epoch_after_consume;
+    std::atomic<int32_t> head_waiting;
     ring_ctl res;
     stage_block st[TP_MAX_WORLD];
 };
@@ -104,6 +108,7 @@ struct pipeinfer_transport {
     pipeinfer_transport_stats head_stats{};
     // cancel view of a stage (compute thread only)
     uint64_t cancel_cursor = 0; std::unordered_set<uint64_t> cancelled; uint64_t cur_key = ~0ull;
+    std::vector<uint64_t> cur_keys;              // the members of the pass being computed (a stage that carries several runs at once)
 
     bool fail(const std::string & what) {
         error = what;
@@ -282,12 +287,14 @@ int head_start(void * user, int32_t run_seq, int32_t batch_id, int32_t n_tokens,
     msg_hdr & m = L->st[1].slots[h % TP_IN1_SLOTS];
     m.kind = KIND_RUN; m.run_seq = run_seq; m.batch_id = batch_id; m.n_tokens = n_tokens; m.flags = 0; m.gen = tp->gen;
     in.head.store(h + 1, std::memory_order_release);
+    L->head_epoch.fetch_add(1, std::memory_order_release);
     tp->started++;
     tp->head_stats.runs++;
     return 0;
 }
 int head_poll(void * user) {
     pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    tp->L->head_epoch.fetch_add(1, std::memory_order_release);
     return tp->L->res.head.load(std::memory_order_acquire) > tp->L->res.tail.load(std::memory_order_relaxed) ? 1 : 0;
 }
 int head_wait(void * user, int32_t run_seq, float * logits, int32_t * ids, float * vals, float * sums) {
@@ -295,7 +302,11 @@ int head_wait(void * user, int32_t run_seq, float * logits, int32_t * ids, float
     shm_layout * L = tp->L;
     const uint64_t t = L->res.tail.load(std::memory_order_relaxed);
     const int64_t t0 = now_us();
-    if (!tp->wait_for([&] { return L->res.head.load(std::memory_order_acquire) > t; }, tp->timeout_ms)) { tp->fail("no result for run " + std::to_string(run_seq) + " (a stage died or timed out)"); return -1; }
+    L->head_epoch.fetch_add(1, std::memory_order_release);
+    L->head_waiting.fetch_add(1, std::memory_order_release);
+    const bool arrived = tp->wait_for([&] { return L->res.head.load(std::memory_order_acquire) > t; }, tp->timeout_ms);
+    L->head_waiting.fetch_sub(1, std::memory_order_release);
+    if (!arrived) { tp->fail("no result for run " + std::to_string(run_seq) + " (a stage died or timed out)"); return -1; }
     tp->head_stats.wait_in_ms += (now_us() - t0) / 1e3;
     uint8_t * s = tp->res_slot(t);
     const msg_hdr m = *(const msg_hdr *) s;
@@ -307,6 +318,7 @@ int head_wait(void * user, int32_t run_seq, float * logits, int32_t * ids, float
         memcpy(logits, tp->res_logits(s), n * (size_t) tp->n_vocab * 4);
     } else tp->head_stats.skipped++;
     L->res.tail.store(t + 1, std::memory_order_release);
+    L->head_epoch_after_consume.store(L->head_epoch.fetch_add(1, std::memory_order_acq_rel) + 1, std::memory_order_release);
     tp->consumed++;
     tp->head_stats.received = tp->consumed;
     return computed ? 1 : 0;
@@ -325,6 +337,12 @@ int abort_probe(void * user) {                                                  
     pipeinfer_transport * tp = (pipeinfer_transport *) user;
     tp->scan_cancels();
     return tp->cancelled.count(tp->cur_key) > 0 ? 1 : 0;
+}
+int abort_probe_all(void * user) {                                              // ... of a pass that carries several runs: it stops when ALL of them are cancelled
+    pipeinfer_transport * tp = (pipeinfer_transport *) user;
+    tp->scan_cancels();
+    for (uint64_t k : tp->cur_keys) if (!tp->cancelled.count(k)) return 0;
+    return 1;
 }
 
 }  // namespace
@@ -524,7 +542,82 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
         if (is_last) { *(msg_hdr *) rs = m; L->res.head.store(h + 1, std::memory_order_release); }
         else { L->st[r + 1].slots[h % TP_X_SLOTS] = m; L->st[r + 1].in.head.store(h + 1, std::memory_order_release); }
     };
-    while (true) {
+    // Run coalescing on a stage that is the WHOLE target (world == 2: draft + driver on GPU 0, the target on GPU 1; pipeinfer_context_set_coalescing on the stage context):
+    // the runs whose headers wait in the ring are carried by ONE pass over the weights, exactly like the in-process feeder's (context.cpp: feeder_main) — the non-speculative
+    // run for a freshly sampled token and the speculative runs drafted meanwhile cost one weight stream instead of one each.  Members are consecutive headers (results leave in
+    // start order), at most TP_RES_SLOTS of them (each owns a result slot), up to coalesce_max tokens, none in conflict over a cell (stage_pass_conflict).  Before composing a
+    // pass the stage gives the head's driver the feeder's reaction window: until it blocks on a result, or has consumed one of the last pass's and called since, or 10 ms.
+    const bool coalescing = ctx && !backend && is_first && is_last && ctx->coalesce_max.load() > 1;
+    bool pass_pending = false; uint64_t pass_first_res = 0;
+    static const int64_t reaction_us = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
+    while (coalescing) {
+        const uint64_t t = in.tail.load(std::memory_order_relaxed);
+        int64_t t0 = now_us();
+        if (!tp->wait_for([&] { return in.head.load(std::memory_order_acquire) > t; }, -1)) { rc_all = -1; break; }
+        st.wait_in_ms += (now_us() - t0) / 1e3;
+        if (pass_pending) {
+            pass_pending = false;
+            const int64_t w0 = now_us();
+            for (int spin = 0; ; spin++) {
+                if (L->head_waiting.load(std::memory_order_acquire) > 0) break;
+                if (L->res.tail.load(std::memory_order_acquire) > pass_first_res && L->head_epoch.load(std::memory_order_acquire) > L->head_epoch_after_consume.load(std::memory_order_acquire)) break;
+                if (now_us() - w0 > reaction_us || L->fatal.load(std::memory_order_relaxed)) break;
+                if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        }
+        msg_hdr first = L->st[r].slots[t % cap];
+        if (first.kind == KIND_SHUTDOWN) { in.tail.store(t + 1, std::memory_order_release); break; }
+        // the members: consecutive headers that are here NOW
+        const int cmax = ctx->coalesce_max.load();
+        const size_t words = (size_t) (tp->n_ctx + 31) / 32;
+        std::vector<msg_hdr> hdr; std::vector<bool> live; std::vector<const void *> metas; std::vector<int32_t> ntok;
+        int tokens = 0;
+        const uint64_t avail = in.head.load(std::memory_order_acquire) - t;
+        for (uint64_t k = 0; k < avail && hdr.size() < (size_t) TP_RES_SLOTS; k++) {
+            const msg_hdr h = L->st[r].slots[(t + k) % cap];
+            if (h.kind != KIND_RUN) break;
+            const bool skip = (h.flags & F_SKIPPED) != 0 || tp->is_cancelled(h.gen, h.batch_id);
+            if (!skip) {
+                if (!metas.empty() && (tokens + h.n_tokens > cmax || pi::stage_pass_conflict(ctx, (int) metas.size(), metas.data(), ntok.data(), tp->meta_of(h.run_seq), h.n_tokens))) break;
+                metas.push_back(tp->meta_of(h.run_seq)); ntok.push_back(h.n_tokens); tokens += h.n_tokens;
+            }
+            hdr.push_back(h); live.push_back(!skip);
+        }
+        const size_t nm = hdr.size();
+        t0 = now_us();
+        const uint64_t oh = L->res.head.load(std::memory_order_relaxed);
+        if (!tp->wait_for([&] { return oh + nm - L->res.tail.load(std::memory_order_acquire) <= (uint64_t) TP_RES_SLOTS; }, -1)) { rc_all = -1; break; }
+        st.wait_out_ms += (now_us() - t0) / 1e3;
+        st.received += nm;
+        int rc = 1;                                                             // (no live member: nothing to compute)
+        if (!metas.empty()) {
+            std::vector<float *> lg, tv, ts; std::vector<int32_t *> ti;
+            tp->cur_keys.clear();
+            for (size_t k = 0; k < nm; k++) if (live[k]) {
+                uint8_t * rs = tp->res_slot(oh + k);
+                lg.push_back(tp->res_logits(rs)); ti.push_back(tp->res_ids(rs)); tv.push_back(tp->res_vals(rs)); ts.push_back(tp->res_sums(rs));
+                tp->cur_keys.push_back(((uint64_t) (uint32_t) hdr[k].gen << 32) | (uint32_t) hdr[k].batch_id);
+            }
+            if (tp->cur_keys.size() == 1) { tp->cur_key = tp->cur_keys[0]; watch_key.store(tp->cur_key, std::memory_order_release); }      // one run: kernel-granular cancel as before
+            t0 = now_us();
+            rc = pi::stage_run_pass(ctx, (int) metas.size(), metas.data(), ntok.data(), lg.data(), ti.data(), tv.data(), ts.data(), abort_probe_all, tp);
+            st.compute_ms += (now_us() - t0) / 1e3;
+            watch_key.store(~0ull, std::memory_order_release); tp->cur_key = ~0ull;
+            if (rc < 0) { tp->fail(std::string("stage run failed: ") + pipeinfer_context_error(ctx)); rc_all = -1; break; }
+            if (rc == 1) st.cut_short += metas.size(); else st.runs += metas.size();
+        }
+        in.tail.store(t + nm, std::memory_order_release);
+        for (size_t k = 0; k < nm; k++) {                                       // results leave in start order
+            msg_hdr m = hdr[k];
+            const bool computed = live[k] && rc == 0;
+            m.flags = computed ? 0 : F_SKIPPED;
+            if (!computed) st.skipped++;
+            *(msg_hdr *) tp->res_slot(oh + k) = m;
+            L->res.head.store(oh + k + 1, std::memory_order_release);
+        }
+        pass_pending = true; pass_first_res = oh;
+    }
+    while (!coalescing) {
         const uint64_t t = in.tail.load(std::memory_order_relaxed);
         int64_t t0 = now_us();
         if (!tp->wait_for([&] { return in.head.load(std::memory_order_acquire) > t; }, -1)) { rc_all = -1; break; }

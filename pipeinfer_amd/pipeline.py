@@ -359,6 +359,10 @@ def bench_main(args, rank, world):
             return (is_first and name.startswith("token_embd")) or (is_last and (name.startswith("output") or name.startswith("output_norm")))
         path = stage_file(f"stage{si}", mine)
         backend = HipStage(path, l0, l1, is_first, is_last, args.n_ctx, 512, device_index=local, seg_layers=int(os.environ.get("PIPEINFER_SEG_LAYERS", str(max(1, (l1 - l0 + 3) // 4)))))     # four segments per stage run: a cancelled run stops within a quarter of the stage
+        if n_stage == 1:
+            # --gpus 2: the one stage is the whole target — it carries the runs waiting in its ring in ONE pass over the weights, like the in-process target of N = 1
+            # (engine feature, transport.cpp: run coalescing in the serve loop; every token keeps the bits it gets alone)
+            backend.ctx.set_coalescing(int(os.environ.get("PIPEINFER_COALESCE", str(B.default_coalesce(args.n_draft)))))
     dist.barrier()                                  # (stage files of a 70B target take a while to write: open the transport together)
     tp = Transport(job_name(), rank, world, n_embd, n_vocab, 512, args.n_ctx, device=local)
     if rank == 0:
@@ -468,6 +472,7 @@ def bench_main(args, rank, world):
                       "n_prompt": args.n_prompt, "n_predict": args.n_predict, "n_draft": args.n_draft, "n_parallel": args.n_parallel, "p_accept": args.p_accept,
                       "p_split": args.p_split, "n_ctx": args.n_ctx, "sampling": "greedy", "layer_ranges": [list(r) for r in ranges],
                       "layer_split": "reference ggml_mpi_split_range, equal weights" if ref_split else "balanced by work (lm_head charged to the last stage)",
+                      "engine": {"stage_run_coalescing_max_tokens": int(os.environ.get("PIPEINFER_COALESCE", str(B.default_coalesce(args.n_draft)))) if n_stage == 1 else 0},
                       "synthetic_structure": f"bigram signal={args.signal} noise={args.noise}, draft wrong on {args.draft_miss:.0%} of the vocabulary"},
            "acceptance": {k: v for k, v in main_sum.items() if k != "tokens_per_s"},
            "lossless_vs_target_only": bool(lossless), "first_difference": first_diff,

@@ -336,7 +336,8 @@ def test_pipeline_stages_reproduce_the_single_process_path(stem, ranges):
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "coarse-ring"),    # PIPEINFER_RING_ALLOC=coarse: the ring as plain hipMalloc memory (rounds 1-4)
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-3", "uncached-ring"),
                                                             ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-1,1-2,2-3", False),       # three stages: a middle stage waits AND publishes
-                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-3", False)])     # --gpus 2: one stage that is first and last
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-3", False),      # --gpus 2: one stage that is first and last
+                                                            ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, "0-3", "coalesce")]) # ... and carries the runs waiting in its ring in ONE pass (run coalescing on the stage)
 def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt, dft, seed, ranges, host_rings):
     """head + two HIP stages as three processes on this one GPU (tests/transport_gpu_worker.py): run headers, metadata, results and cancel
     notes through the shared segment, activations as peer stores into the next stage's HBM ring (hipIpc).  The accepted tokens must be
@@ -362,6 +363,9 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
         env["PIPEINFER_TEST_HOP_PROBE_FAIL"] = "1"
     if mode in ("coarse-ring", "uncached-ring"):
         env["PIPEINFER_RING_ALLOC"] = mode.split("-")[0]
+    if mode == "coalesce":
+        env["PIPEINFER_TEST_STAGE_COALESCE"] = "16"
+        env["PI_DEBUG_RUN_LATENCY_US"] = "0"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     v = json.loads(out.read_text())
@@ -373,6 +377,10 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
     assert last["skipped"] <= last["cancel_notes"] <= sum(t["n_runs_canceled"] for t in v["trials"])
     assert any(t["n_runs_spec"] > 0 for t in v["trials"])
     assert all(s["device_mode"] == (not host_rings) for s in v["stages"]) and all(s["runs"] > 0 for s in v["stages"])
+    if mode == "coalesce":                                                                 # runs did travel together, and the tokens above are still the reference's
+        s0 = v["stages"][0]
+        print("stage coalescing:", {k: s0[k] for k in ("n_passes", "n_pass_runs", "n_coalesced_passes", "runs", "skipped")})
+        assert s0["n_coalesced_passes"] > 0 and s0["n_pass_runs"] > s0["n_coalesced_passes"], s0
     # conservation: every run the head started came back, and passed every stage exactly once (computed, or as a skipped header)
     assert last["received"] == last["runs"]
     for s in v["stages"]:

@@ -37,13 +37,15 @@ def main():
     else:
         l0, l1 = ranges[rank - 1]
         stage = P.HipStage(path, l0, l1, rank == 1, rank == world - 1, N_CTX, N_BATCH, device_index=0, seg_layers=1)
+        if os.environ.get("PIPEINFER_TEST_STAGE_COALESCE") and world == 2:         # the stage is the whole target: it carries the runs waiting in its ring in one pass
+            stage.ctx.set_coalescing(int(os.environ["PIPEINFER_TEST_STAGE_COALESCE"]))
         n_embd, n_vocab = stage.n_embd, stage.n_vocab
     dist.barrier()
     tp = P.Transport(P.job_name(), rank, world, n_embd, n_vocab, N_BATCH, N_CTX, device=0, timeout_ms=120000)
     if rank >= 1:
         st = tp.serve(ctx=stage.ctx)
         box = [None] * world
-        dist.gather_object({"rank": rank, "device_mode": tp.device_mode, **st, **{k: stage.stats()[k] for k in ("n_calls", "n_segments", "n_segments_skipped")}}, None, dst=0)
+        dist.gather_object({"rank": rank, "device_mode": tp.device_mode, **st, **{k: stage.stats()[k] for k in ("n_calls", "n_segments", "n_segments_skipped", "n_passes", "n_pass_runs", "n_coalesced_passes")}}, None, dst=0)
         dist.barrier()
         tp.close()
         stage.close()
