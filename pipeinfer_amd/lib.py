@@ -20,7 +20,7 @@ class PipeInferError(RuntimeError):
 def build(force=False):
     """compile the HIP extension in-tree (hipcc cross-compiles gfx950 without a GPU)"""
     if force or not os.path.exists(SO) or _stale():
-        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "-j8"], stdout=subprocess.DEVNULL)
     return SO
 
 
