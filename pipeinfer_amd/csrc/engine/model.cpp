@@ -234,7 +234,7 @@ extern "C" struct llama_model * llama_load_model_from_file(const char * path, st
         }
         if (b.rope == 2 && !b.qk_norm && (hp.n_rot <= 0 || hp.n_rot % 2 || hp.head_dim() % hp.n_rot)) { fprintf(stderr, "llama_load_model_from_file: n_rot %d does not divide head_dim %d\n", hp.n_rot, hp.head_dim()); return nullptr; }
     }
-    if (hp.head_dim() != 64 && hp.head_dim() != 128) { fprintf(stderr, "llama_load_model_from_file: head width %d (n_embd %d / n_head %d) is not supported: the attention kernel has instances for 64 and 128 only (e.g. StableLM-3B's 80 cannot load; the reference takes any width, llama.cpp:3698-3778)\n", hp.head_dim(), hp.n_embd, hp.n_head); return nullptr; }
+    if (hp.head_dim() <= 0 || hp.head_dim() > 256 || hp.head_dim() % 2 || hp.n_embd != hp.head_dim() * hp.n_head) { fprintf(stderr, "llama_load_model_from_file: head width %d (n_embd %d / n_head %d) is not supported: the attention kernels take even head widths up to 256 (64 and 128 tuned, the others through the plain kernel; the reference takes any width, llama.cpp:3698-3778)\n", hp.head_dim(), hp.n_embd, hp.n_head); return nullptr; }
     if (!m->vocab.load(f, err)) { fprintf(stderr, "llama_load_model_from_file: %s\n", err.c_str()); return nullptr; }
     if (hp.n_ff == 0) { const pi::gguf_tensor * t = f.tensor("blk.0.ffn_up.weight"); if (t) hp.n_ff = (int) t->ne[1]; }
     if (!params.vocab_only) {

@@ -316,6 +316,114 @@ __global__ void __launch_bounds__(256) k_attention(const att_args ga) {
     }
 }
 
+// =================================================================================================================
+// k_attention_any — every OTHER head width (even, <= 256; e.g. StableLM-3B's 80): the reference takes any n_embd_head (llama.cpp:3698-3778).  The same arithmetic written
+// plainly, not tuned: one workgroup per (kv head, query row); phase 1 one thread per cell, phase 3 one thread per output dimension, each running ggml_vec_dot_f16's 32
+// accumulators itself (4 registers x 8 lanes, fma in element order, folds (0 += 2, 1 += 3, 0 += 1), lanes l + (l + 4), two hadds) and — what the 64 / 128 instances never
+// need in phase 1 — the n % 32 leftover ELEMENTS of a head added in double (ggml.c:1221-1224); phase 2 is the tuned kernel's.
+// =================================================================================================================
+static __device__ __forceinline__ double att_fold32(const float (&sum)[4][8]) {        // the reduced sum as the double the leftovers are added to, one by one
+    float s0[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) s0[l] = (sum[0][l] + sum[2][l]) + (sum[1][l] + sum[3][l]);
+    const float t0 = s0[0] + s0[4], t1 = s0[1] + s0[5], t2 = s0[2] + s0[6], t3 = s0[3] + s0[7];
+    return (double) ((t0 + t1) + (t2 + t3));
+}
+template <bool ALIBI>
+__global__ void __launch_bounds__(256) k_attention_any(const att_args ga, const int hd) {
+    extern __shared__ float smem[];
+    __shared__ float redf[4];
+    __shared__ unsigned long long redu[4];
+    att_args g = ga;
+    const int s_stride = ga.n_kv;
+    const int hk = blockIdx.x, row = blockIdx.y;
+    const int r = g.n_head / g.n_head_kv, t = row / r, gq = row % r;
+    if (ga.dyn) g.n_kv = (ga.per_token && ga.dyn[3]) ? ga.dyn[4 + ga.dyn[2] + t] : ga.dyn[1];
+    const int n_gqa = g.n_head_kv * hd, n_embd = g.n_head * hd;
+    float * S = smem;                                                                // [n_kv] scores, then probabilities
+    uint32_t * M = (uint32_t *) (smem + s_stride);                                   // [mask_words]
+    float * Q = smem + s_stride + g.mask_words;                                      // [hd] the query row, f16-rounded
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int aborted = pi_abort_peek(ga.abort_w);
+    for (int i = tid; i < g.mask_words; i += 256) M[i] = g.mask[(int64_t) t * g.mask_words + i];
+    for (int i = tid; i < hd; i += 256) Q[i] = pi_h2f(g.q16[(int64_t) t * n_embd + (hk * r + gq) * hd + i]);
+    __syncthreads();
+    const float am = ALIBI ? ga.alibi_m[hk * r + gq] : 0.0f;
+    const int nph = hd & ~31;
+    // ---- phase 1: S[c] = scale * ggml_vec_dot_f16(hd, K[c], q) (+ ALiBi), masked cells -inf ----
+    for (int c = tid; c < g.n_kv; c += 256) {
+        const uint16_t * kp = g.kc + (int64_t) c * n_gqa + hk * hd;
+        float sum[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) sum[j][l] = 0.0f;
+        for (int i = 0; i < nph; i += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t * kd = (const uint32_t *) (kp + i + 8 * j);           // (an even head width keeps dwords aligned; 16-byte vectors would need hd % 8 == 0)
+                const uint32_t w4[4] = { kd[0], kd[1], kd[2], kd[3] };
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    sum[j][2 * u] = fmaf(pi_h2f((uint16_t) (w4[u] & 0xffff)), Q[i + 8 * j + 2 * u], sum[j][2 * u]);
+                    sum[j][2 * u + 1] = fmaf(pi_h2f((uint16_t) (w4[u] >> 16)), Q[i + 8 * j + 2 * u + 1], sum[j][2 * u + 1]);
+                }
+            }
+        }
+        double sd = att_fold32(sum);
+        for (int i = nph; i < hd; i++) sd += (double) (pi_h2f(kp[i]) * Q[i]);
+        const float x = (float) sd;
+        const bool vis = (M[c >> 5] >> (c & 31)) & 1;
+        float sc = x * g.scale;
+        if constexpr (ALIBI) sc = (float) c * am + sc;
+        S[c] = vis ? sc : -INFINITY;
+    }
+    __syncthreads();
+    // ---- phase 2: soft max (row max, fp16 exp table, exact integer sum, P rounded to f16) ----
+    {
+        float mx = -INFINITY;
+        for (int c = tid; c < g.n_kv; c += 256) mx = fmaxf(mx, S[c]);
+        mx = pi_wave_max(mx);
+        if (lane == 0) redf[wv] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        unsigned long long isum = 0;
+        for (int c = tid; c < g.n_kv; c += 256) {
+            const float x = S[c];
+            float v = 0.0f;
+            if (x != -INFINITY) { v = pi_h2f(g.exp_tab[pi_f2h(x - mx)]); isum += (unsigned long long) (v * 16777216.0f); }
+            S[c] = v;
+        }
+        pi_butterfly<32>([&](auto o) { isum += pi_partner<decltype(o)::value>(isum); });
+        if (lane == 0) redu[wv] = isum;
+        __syncthreads();
+        const double sum = (double) ((redu[0] + redu[1]) + (redu[2] + redu[3])) * (1.0 / 16777216.0);
+        const float inv = (float) (1.0 / sum);
+        for (int c = tid; c < g.n_kv; c += 256) S[c] = pi_h2f(pi_f2h(S[c] * inv));
+        __syncthreads();
+    }
+    // ---- phase 3: out[e] = ggml_vec_dot_f16(n_kv, V[:, e], P) ----
+    if (aborted & 1) { pi_abort_note(ga.abort_w, 5); return; }
+    for (int e = tid; e < hd; e += 256) {
+        const uint16_t * vp = g.vc + hk * hd + e;
+        const int np = g.n_kv & ~31;
+        float sum[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) sum[j][l] = 0.0f;
+        for (int c0 = 0; c0 < np; c0 += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int l = 0; l < 8; l++) { const int c = c0 + 8 * j + l; sum[j][l] = fmaf(pi_h2f(vp[(int64_t) c * n_gqa]), S[c], sum[j][l]); }
+        }
+        double sd = att_fold32(sum);
+        for (int c = np; c < g.n_kv; c++) sd += (double) (pi_h2f(vp[(int64_t) c * n_gqa]) * S[c]);
+        g.out[(int64_t) t * n_embd + (hk * r + gq) * hd + e] = (float) sd;
+    }
+}
+
 // raises the dynamic-LDS limit of the kernel for contexts longer than ~2000 cells; call once outside any graph capture
 template <int HD, int RW> static int att_set_lds(size_t lds) {
     PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention<HD, RW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
@@ -330,6 +438,13 @@ static size_t att_lds_cap(int rw) { return (size_t) (rw == 1 ? 146 : 156) * 1024
 extern "C" int pi_op_attention_max_cells(void) { int n = 36200; while (att_lds_bytes(1, n) > att_lds_cap(1)) n--; return n; }
 extern "C" int pi_op_attention_reserve(int hd, int n_kv_max) {
     if (att_lds_bytes(1, n_kv_max) > att_lds_cap(1)) { pi_set_error("pi_op_attention_reserve: n_kv=%d needs %zu B of LDS for ONE score row (> 146 KiB): contexts beyond %d cells are not supported", n_kv_max, att_lds_bytes(1, n_kv_max), pi_op_attention_max_cells()); return -1; }
+    if (hd != 64 && hd != 128) {                                          // the plain kernel of the other head widths: one score row + the mask words + the query row
+        const size_t b = att_lds_bytes(1, n_kv_max) + (size_t) hd * sizeof(float);
+        if (b <= 60 * 1024) return 0;
+        PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention_any<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (b < att_lds_cap(1) ? b : att_lds_cap(1))));
+        PI_CHECK_HIP(hipFuncSetAttribute((const void *) k_attention_any<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (b < att_lds_cap(1) ? b : att_lds_cap(1))));
+        return 0;
+    }
     if (att_lds_bytes(ATT_ROWS, n_kv_max) <= 60 * 1024) return 0;
     int rc = 0;
     auto want = [&](int rw) { const size_t b = att_lds_bytes(rw, n_kv_max), cap = att_lds_cap(rw); return b < cap ? b : cap; };
@@ -403,7 +518,16 @@ extern "C" int pi_op_attention_alibi(const uint16_t * q16, const uint16_t * kc, 
     if ((size_t) rw * (n_kv + g.mask_words) * sizeof(float) > att_lds_cap(rw)) { pi_set_error("pi_op_attention: n_kv=%d needs more than %d KiB of LDS", n_kv, rw == 1 ? 146 : 156); return -1; }
     if (hd == 128) att_launch<128>(g, rows, rw, (hipStream_t) stream);
     else if (hd == 64) att_launch<64>(g, rows, rw, (hipStream_t) stream);
-    else { pi_set_error("pi_op_attention: head_dim %d not supported (64 or 128)", hd); return -1; }
+    else if (hd > 0 && hd <= 256 && hd % 2 == 0) {                       // every other head width: the plain kernel, one workgroup per (kv head, query row)
+        const size_t lds = ((size_t) n_kv + g.mask_words + (size_t) hd) * sizeof(float);
+        if (lds > att_lds_cap(1)) { pi_set_error("pi_op_attention: n_kv=%d needs more than 146 KiB of LDS", n_kv); return -1; }
+        const int nt = n_tok > 0 ? n_tok : 1;
+        const int n_kv_priced = pi_account_n_kv() > 0 && pi_account_n_kv() < n_kv ? pi_account_n_kv() : n_kv;
+        const double bytes = (double) n_kv_priced * n_head_kv * hd * 2 * 2 + (double) nt * n_head * hd * (2 + 4);
+        if (alibi_slopes_dev) PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention_any<true>), dim3(n_head_kv, rows), dim3(256), lds, (hipStream_t) stream, g, hd);
+        else                  PI_KT_LAUNCH(PI_KT_ATT, 0, nt, bytes, (k_attention_any<false>), dim3(n_head_kv, rows), dim3(256), lds, (hipStream_t) stream, g, hd);
+    }
+    else { pi_set_error("pi_op_attention: head_dim %d not supported (even, <= 256)", hd); return -1; }
     PI_CHECK_LAUNCH();
     return 0;
 }

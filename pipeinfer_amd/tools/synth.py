@@ -25,6 +25,7 @@ SPECS = {
     # small shapes for tests
     "tiny-llama":     ("llama", 2, 256, 4, 2, 512, 512, 512),
     "tiny-llama-b":   ("llama", 3, 256, 4, 4, 768, 512, 512),
+    "tiny-llama-hd80": ("llama", 2, 320, 4, 2, 512, 512, 512),             # head width 80 (StableLM-3B's; neither 64 nor 128): the plain attention kernel; n_embd 320 -> 32-blocks only
     "tiny-falcon":    ("falcon", 2, 256, 4, 1, 1024, 512, 512),
     "tiny-falcon40":  ("falcon", 2, 256, 4, 2, 1024, 512, 512),   # two-norm (40B-style) variant
     # the other graph builders of the reference (llama.cpp:3985-4939); depths 32 / 40 are what build_baichuan tells its 7B (RoPE) from its 13B (ALiBi) by

@@ -28,6 +28,7 @@ MODELS = [  # (file stem, spec, ftype, seed)
     ("tiny_llama_q5_1", "tiny-llama", "q5_1", 18),             # legacy 32-blocks with min and fifth bit (x Q8_1 activations), Q6_K head
     ("tiny_llama_q5_0", "tiny-llama", "q5_0", 19),             # signed 5-bit (x Q8_0)
     ("tiny_llama_q4_1", "tiny-llama", "q4_1", 20),
+    ("tiny_llama_hd80_q4_0", "tiny-llama-hd80", "q4_0", 29),   # head width 80: ggml_vec_dot_f16's leftover elements (n % 32) in the K.Q products
     # the other architectures: expected logits from the reference's OWN loader + build_* graph (O.RefLlama = oracle/_ref/libref_kv.so), not from our graph over its kernels
     ("tiny_baichuan7_q4_0", "tiny-baichuan7", "q4_0", 21),     # 32 layers: build_baichuan's RoPE arm
     ("tiny_baichuan13_q4_0", "tiny-baichuan13", "q4_0", 22),   # 40 layers: its ALiBi arm
@@ -229,6 +230,8 @@ if __name__ == "__main__":
         model_vectors(only=["tiny_persimmon_q4_k_m"])
     elif sys.argv[1:] == ["archs"]:                  # round 3: the generic-block architectures
         model_vectors(only=[m[0] for m in MODELS if synth.SPECS[m[1]][0] in REF_BUILDERS])
+    elif sys.argv[1:] == ["hd80"]:                   # round 5: a head width that is neither 64 nor 128
+        model_vectors(only=["tiny_llama_hd80_q4_0"])
     elif sys.argv[1:] == ["q2k"]:
         kernel_vectors_q3k(O.Q2_K, "kernels_q2k.npz")
         model_vectors(only=["tiny_llama_q2_k"])

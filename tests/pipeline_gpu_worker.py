@@ -11,7 +11,7 @@ from pipeinfer_amd import llama as LL, pipeline as P          # noqa: E402
 from tests import gpu_util as U, scenarios as S               # noqa: E402      (no torch anywhere: device buffers through the C ABI)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20,
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20, "tiny_llama_hd80_q4_0": 29,
          "tiny_starcoder_q4_0": 23, "tiny_bloom_q4_0": 25, "tiny_mpt_q4_k_m": 26, "tiny_stablelm_q4_k_m": 27, "tiny_persimmon_q4_k_m": 28}
 
 

@@ -300,7 +300,7 @@ def mask_bits(mask):
 
 
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok,max_bias", [(64, 4, 4, 45, 3, 8.0), (128, 6, 6, 70, 2, 8.0), (64, 12, 1, 33, 1, 8.0), (128, 32, 32, 300, 9, 8.0), (64, 6, 2, 200, 5, 4.0),
-                                                                      (64, 71, 1, 64, 16, 8.0), (128, 8, 8, 6000, 3, 8.0)])
+                                                                      (64, 71, 1, 64, 16, 8.0), (128, 8, 8, 6000, 3, 8.0), (80, 6, 2, 70, 3, 8.0), (96, 5, 5, 130, 2, 4.0)])
 def test_attention_with_alibi_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok, max_bias):
     """llm_build_kqv with max_alibi_bias > 0 (Baichuan-13B, Refact, Bloom, MPT; llama.cpp:3735-3740): score = i * m_k + kq * scale with the slopes of
     ggml_compute_forward_alibi_f32 (ggml.c:10768-10789; head counts that are not a power of two take the second series), then the mask and the soft-max"""
@@ -337,7 +337,9 @@ def test_attention_with_alibi_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok,
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,n_tok", [(128, 8, 8, 45, 3), (64, 32, 4, 70, 2), (64, 71, 1, 33, 1), (128, 64, 8, 300, 9), (64, 8, 2, 1024, 4),
                                                              (64, 4, 1, 32, 7), (64, 4, 4, 32, 8), (128, 32, 32, 256, 1), (128, 16, 2, 97, 5), (64, 4, 2, 64, 16),
                                                              (128, 64, 8, 256, 9), (128, 64, 8, 300, 2), (64, 64, 8, 300, 9),    # many rows: hit f16 ties of the fp32 product
-                                                             (64, 64, 8, 6000, 32), (128, 8, 8, 20000, 1), (128, 64, 8, 9000, 3)])  # long contexts: fewer score rows per workgroup (8 -> 4 / 1 / 2 rows in LDS)
+                                                             (64, 64, 8, 6000, 32), (128, 8, 8, 20000, 1), (128, 64, 8, 9000, 3),   # long contexts: fewer score rows per workgroup (8 -> 4 / 1 / 2 rows in LDS)
+                                                             # other head widths (the plain kernel): 80 = StableLM-3B's (16 leftover elements per K.Q product), 96, 48, 32, 256, 100
+                                                             (80, 8, 2, 70, 3), (96, 4, 4, 33, 1), (80, 32, 32, 300, 9), (48, 6, 2, 200, 5), (256, 4, 1, 45, 2), (80, 4, 2, 6000, 2), (32, 4, 4, 64, 8), (100, 2, 2, 97, 4)])
 def test_attention_vs_oracle(gpu, hd, n_head, n_head_kv, n_kv, n_tok):
     lib, U = gpu
     from pipeinfer_amd import lib as L

@@ -10,7 +10,7 @@ from tests import scenarios as S
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 K = np.load(os.path.join(GOLD, "kernels.npz"))
-SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20,
+SEEDS = {"tiny_llama_q4_k_m": 11, "tiny_llama_q4_0": 12, "tiny_llama_b_q4_k_m": 13, "tiny_falcon_q4_0": 14, "tiny_falcon40_q4_k_m": 15, "tiny_llama_q3_k_m": 16, "tiny_llama_q2_k": 17, "tiny_llama_q5_1": 18, "tiny_llama_q5_0": 19, "tiny_llama_q4_1": 20, "tiny_llama_hd80_q4_0": 29,
          # the generic-block architectures (goldens made by the reference's own build_* graphs)
          "tiny_baichuan7_q4_0": 21, "tiny_baichuan13_q4_0": 22, "tiny_starcoder_q4_0": 23, "tiny_refact_q4_0": 24, "tiny_bloom_q4_0": 25, "tiny_mpt_q4_k_m": 26, "tiny_stablelm_q4_k_m": 27, "tiny_persimmon_q4_k_m": 28}
 MODELS = list(SEEDS)
