@@ -115,6 +115,7 @@ struct pipeinfer_transport_stats {
     double   flag_seen_us;                             /* stage: sum over those runs of (flag seen by the waiting kernel - flag stamped by the producing stream), device clock: valid between stages on ONE device */
     int32_t  hop_store_kernel;                         /* stage: 1 = the activations are stored by a kernel of the producing stream (device rings), 0 = by hipMemcpyAsync (host rings, PIPEINFER_HOP_STORE=memcpy); decided and logged at set-up */
     int32_t  ring_alloc;                               /* stage: this stage's activation ring: 0 none (first stage / host rings), 1 coarse-grained hipMalloc, 2 fine-grained, 3 uncached device memory */
+    uint64_t passes_of_several_runs;                   /* stage that is the whole target, run coalescing on: forward passes that carried more than one run */
 };
 /* stage compute behind the transport when it is not a llama_context of this library (the CPU tests plug the oracle in here):
  * 0 = computed, 1 = dropped, < 0 error; x_in / x_out are host pointers when the transport runs on host rings */

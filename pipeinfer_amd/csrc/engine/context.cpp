@@ -505,8 +505,8 @@ static bool pass_cancelled(const pi_pass & p) { return runs_cancelled(p.runs); }
 // token and hands it to the non-speculative run of the same token while the speculative run is still queued (speculative.cpp:1252-1255, find_slot llama.cpp:1593-1644).
 // One case is exact all the same, and it is that one: the two tokens are the SAME computation — same token id, position, cell, n_kv and visibility row — so they store
 // identical bits, and whoever reads the cell reads those bits whichever store lands last.
-static bool pass_conflict(const llama_context * ctx, const std::vector<pi_run *> & members, const pi_run * q) {
-    const int words = (ctx->n_ctx + 31) / 32;
+static bool pass_conflict_n(int n_ctx, const std::vector<pi_run *> & members, const pi_run * q) {
+    const int words = (n_ctx + 31) / 32;
     auto tok = [](const pi_run * r) { return (const int32_t *) r->meta_host; };
     auto msk = [&](const pi_run * r, int t) { return (const uint32_t *) ((const int32_t *) r->meta_host + 2 * r->n_tokens + 4) + (size_t) t * words; };
     for (int j = 0; j < q->n_tokens; j++) {
@@ -526,6 +526,8 @@ static bool pass_conflict(const llama_context * ctx, const std::vector<pi_run *>
     }
     return false;
 }
+
+static bool pass_conflict(const llama_context * ctx, const std::vector<pi_run *> & members, const pi_run * q) { return pass_conflict_n(ctx->n_ctx, members, q); }
 
 // one input block for a pass of several runs: their tokens, positions and mask rows one after the other, the cell of every token, n_kv = the widest run's
 // (cells past a run's own n_kv are masked for its tokens and contribute exact zeros, like every masked cell inside it)
@@ -957,12 +959,12 @@ static void stage_member(pi_run & r, const void * meta, int n_tokens) {
     const int32_t * m = (const int32_t *) meta;
     r.meta_host = (uint8_t *) const_cast<void *>(meta); r.n_tokens = n_tokens; r.kv_head = m[2 * n_tokens]; r.n_kv = m[2 * n_tokens + 1];
 }
-bool stage_pass_conflict(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, const void * q_meta, int q_tokens) {
+bool stage_pass_conflict(int n_ctx, int n_members, const void * const * metas, const int32_t * n_tokens, const void * q_meta, int q_tokens) {
     std::vector<pi_run> tmp((size_t) n_members + 1);                           // (pass_conflict reads n_tokens, kv_head, n_kv and the block itself)
     std::vector<pi_run *> members;
     for (int i = 0; i < n_members; i++) { stage_member(tmp[(size_t) i], metas[i], n_tokens[i]); members.push_back(&tmp[(size_t) i]); }
     stage_member(tmp[(size_t) n_members], q_meta, q_tokens);
-    const bool c = pass_conflict(ctx, members, &tmp[(size_t) n_members]);
+    const bool c = pass_conflict_n(n_ctx, members, &tmp[(size_t) n_members]);
     for (auto & r : tmp) r.meta_host = nullptr;                                // (borrowed blocks: nothing of these stand-ins is freed)
     return c;
 }

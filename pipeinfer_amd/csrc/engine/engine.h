@@ -237,7 +237,7 @@ int  stage_run(llama_context * ctx, int n_tokens, const void * meta, size_t meta
                float * logits_host, int32_t * topk_ids, float * topk_vals, float * topk_sum,
                int (*should_abort)(void *) = nullptr, void * abort_user = nullptr, const pi_stage_hop * hop = nullptr);        // 0 done, 1 cut short (should_abort, a cancel, or upstream), < 0 error
 // a stage that is the whole target carries the runs waiting in its ring in ONE forward pass (context.cpp: run coalescing for the transport's serve loop)
-bool stage_pass_conflict(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, const void * q_meta, int q_tokens);
+bool stage_pass_conflict(int n_ctx, int n_members, const void * const * metas, const int32_t * n_tokens, const void * q_meta, int q_tokens);
 int  stage_run_pass(llama_context * ctx, int n_members, const void * const * metas, const int32_t * n_tokens, float * const * logits_host, int32_t * const * topk_ids,
                     float * const * topk_vals, float * const * topk_sum, int (*should_abort)(void *), void * abort_user);
 void stage_abort_run(llama_context * ctx, int32_t run_id);                  // any thread: run `run_id` (ctx->stage_run_id while stage_run computes it) returns from every kernel on entry from now on; no effect on any other run

@@ -547,7 +547,10 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
     // run for a freshly sampled token and the speculative runs drafted meanwhile cost one weight stream instead of one each.  Members are consecutive headers (results leave in
     // start order), at most TP_RES_SLOTS of them (each owns a result slot), up to coalesce_max tokens, none in conflict over a cell (stage_pass_conflict).  Before composing a
     // pass the stage gives the head's driver the feeder's reaction window: until it blocks on a result, or has consumed one of the last pass's and called since, or 10 ms.
-    const bool coalescing = ctx && !backend && is_first && is_last && ctx->coalesce_max.load() > 1;
+    // (A backend that is not a context of this library — the CPU tests' oracle — computes a pass member by member, in start order: the same results by construction; what the
+    //  tests then exercise is the gathering, the conflict rule, the result order and the reaction window.  PIPEINFER_STAGE_COALESCE=<tokens> switches it on for such a backend.)
+    const int cmax_backend = backend && getenv("PIPEINFER_STAGE_COALESCE") ? atoi(getenv("PIPEINFER_STAGE_COALESCE")) : 0;
+    const bool coalescing = is_first && is_last && ((ctx && !backend && ctx->coalesce_max.load() > 1) || cmax_backend > 1);
     bool pass_pending = false; uint64_t pass_first_res = 0;
     static const int64_t reaction_us = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
     while (coalescing) {
@@ -568,7 +571,7 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
         msg_hdr first = L->st[r].slots[t % cap];
         if (first.kind == KIND_SHUTDOWN) { in.tail.store(t + 1, std::memory_order_release); break; }
         // the members: consecutive headers that are here NOW
-        const int cmax = ctx->coalesce_max.load();
+        const int cmax = backend ? cmax_backend : ctx->coalesce_max.load();
         const size_t words = (size_t) (tp->n_ctx + 31) / 32;
         std::vector<msg_hdr> hdr; std::vector<bool> live; std::vector<const void *> metas; std::vector<int32_t> ntok;
         int tokens = 0;
@@ -578,7 +581,7 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
             if (h.kind != KIND_RUN) break;
             const bool skip = (h.flags & F_SKIPPED) != 0 || tp->is_cancelled(h.gen, h.batch_id);
             if (!skip) {
-                if (!metas.empty() && (tokens + h.n_tokens > cmax || pi::stage_pass_conflict(ctx, (int) metas.size(), metas.data(), ntok.data(), tp->meta_of(h.run_seq), h.n_tokens))) break;
+                if (!metas.empty() && (tokens + h.n_tokens > cmax || pi::stage_pass_conflict(tp->n_ctx, (int) metas.size(), metas.data(), ntok.data(), tp->meta_of(h.run_seq), h.n_tokens))) break;
                 metas.push_back(tp->meta_of(h.run_seq)); ntok.push_back(h.n_tokens); tokens += h.n_tokens;
             }
             hdr.push_back(h); live.push_back(!skip);
@@ -600,11 +603,18 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
             }
             if (tp->cur_keys.size() == 1) { tp->cur_key = tp->cur_keys[0]; watch_key.store(tp->cur_key, std::memory_order_release); }      // one run: kernel-granular cancel as before
             t0 = now_us();
-            rc = pi::stage_run_pass(ctx, (int) metas.size(), metas.data(), ntok.data(), lg.data(), ti.data(), tv.data(), ts.data(), abort_probe_all, tp);
+            if (backend) {
+                rc = 0;
+                for (size_t k = 0; k < metas.size() && rc == 0; k++) {
+                    const size_t mb = (size_t) ntok[k] * 8 + 16 + (size_t) ntok[k] * words * 4;
+                    rc = backend->run(backend->user, ntok[k], metas[k], mb, nullptr, nullptr, lg[k], ti[k], tv[k], ts[k]);
+                    if (rc == 1) rc = -1;                                       // (a backend does not drop single members of a pass)
+                }
+            } else rc = pi::stage_run_pass(ctx, (int) metas.size(), metas.data(), ntok.data(), lg.data(), ti.data(), tv.data(), ts.data(), abort_probe_all, tp);
             st.compute_ms += (now_us() - t0) / 1e3;
             watch_key.store(~0ull, std::memory_order_release); tp->cur_key = ~0ull;
-            if (rc < 0) { tp->fail(std::string("stage run failed: ") + pipeinfer_context_error(ctx)); rc_all = -1; break; }
-            if (rc == 1) st.cut_short += metas.size(); else st.runs += metas.size();
+            if (rc < 0) { tp->fail(std::string("stage run failed: ") + (ctx ? pipeinfer_context_error(ctx) : "backend error")); rc_all = -1; break; }
+            if (rc == 1) st.cut_short += metas.size(); else { st.runs += metas.size(); if (metas.size() > 1) st.passes_of_several_runs++; }
         }
         in.tail.store(t + nm, std::memory_order_release);
         for (size_t k = 0; k < nm; k++) {                                       // results leave in start order

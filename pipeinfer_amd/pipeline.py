@@ -51,7 +51,7 @@ class TransportStats(C.Structure):
     _fields_ = [("runs", C.c_uint64), ("skipped", C.c_uint64), ("cut_short", C.c_uint64), ("cancel_notes", C.c_uint64),
                 ("wait_in_ms", C.c_double), ("compute_ms", C.c_double), ("send_ms", C.c_double),
                 ("received", C.c_uint64), ("wait_out_ms", C.c_double), ("hop_gpu_ms", C.c_double), ("peer_access", C.c_int32), ("device_flags", C.c_int32),
-                ("flag_runs", C.c_uint64), ("flag_wait_gpu_ms", C.c_double), ("flag_seen_us", C.c_double), ("hop_store_kernel", C.c_int32), ("ring_alloc", C.c_int32)]
+                ("flag_runs", C.c_uint64), ("flag_wait_gpu_ms", C.c_double), ("flag_seen_us", C.c_double), ("hop_store_kernel", C.c_int32), ("ring_alloc", C.c_int32), ("passes_of_several_runs", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

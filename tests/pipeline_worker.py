@@ -128,7 +128,15 @@ def main():
             comp = probe
         else:
             comp = CheckedOracle(tgt) if rank == 2 else Relay(n_embd)
-        st = tp.serve(backend=comp.run)
+        run_fn = comp.run
+        lat = float(os.environ.get("PI_TEST_STAGE_LATENCY_MS", "0"))
+        if lat > 0:                                         # a slow stage: the head's runs queue up in the ring behind the one being computed (coalescing test)
+            import time
+
+            def run_fn(n, meta, x_in=None, x_out=None, _f=comp.run):
+                time.sleep(lat / 1e3)
+                return _f(n, meta, x_in, x_out)
+        st = tp.serve(backend=run_fn)
         dist.gather_object(st, None, dst=0)                 # the stage's counters go into the verdict: conservation is asserted by the test
         dist.barrier()
         tp.close()

@@ -26,12 +26,17 @@ def test_split_layers_matches_reference_rule():
 
 
 @pytest.mark.parametrize("tgt,dft,seed,world", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, 2), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 11, 2),
-                                                ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, 3)])      # 3: head + two stages (header and activation hop between stages)
+                                                ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, 3),       # 3: head + two stages (header and activation hop between stages)
+                                                ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, -2)])     # -2: world 2 with run coalescing in the stage's serve loop (the stage is the whole target)
 def test_head_and_stage_over_gloo_are_lossless(tmp_path, tgt, dft, seed, world):
     """rank 0: C++ driver + proxy target context; rank 1 (and 2): pipeinfer_transport_serve.  The accepted tokens must equal the reference
     greedy continuation, every started run must come back (computed or skipped after a cancel) and cancels must reach the stages."""
     out = tmp_path / "verdict.json"
     env = dict(os.environ, OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+    coalesce = world < 0
+    world = abs(world)
+    if coalesce:                                                                 # the serve loop gathers the runs waiting in its ring, applies the conflict rule, answers in start order
+        env.update(PIPEINFER_STAGE_COALESCE="16", PI_TEST_STAGE_LATENCY_MS="3")  # (a slow stage: runs do queue up behind the one being computed)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "pipeline_worker.py"), str(out), tgt, dft, str(seed)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -44,6 +49,9 @@ def test_head_and_stage_over_gloo_are_lossless(tmp_path, tgt, dft, seed, world):
         assert t["received"] == t["runs"], t                                   # conservation at the head: every started run came back (computed or as a skipped header)
     last = v["trials"][-1]
     assert len(v["stages"]) == world - 1
+    if coalesce:
+        print("stage coalescing over gloo:", {k: v["stages"][0][k] for k in ("runs", "skipped", "passes_of_several_runs")})
+        assert v["stages"][0]["passes_of_several_runs"] > 0, v["stages"][0]
     for st in v["stages"]:
         # conservation at every stage: each run the head started passed through it exactly once, as a computed run or as a skipped header (a run cut short inside the
         # stage counts as skipped); nothing lost, nothing duplicated
