@@ -373,7 +373,7 @@ def bench_main(args, rank, world):
         st = tp.serve(ctx=backend.ctx)
         stats = backend.stats()
         t = torch.tensor([stats["gpu_ms_1"], float(stats["n_calls_1"]), float(stats["alg_bytes_1"]), float(st["skipped"]), float(st["cut_short"]), st["wait_in_ms"], st["compute_ms"], st["send_ms"] + st["hop_gpu_ms"], float(st["runs"]), st["wait_out_ms"], float(st["peer_access"]),
-                          float(st["device_flags"]), float(st["flag_runs"]), st["flag_wait_gpu_ms"], st["flag_seen_us"], float(st["hop_store_kernel"]), float(st["ring_alloc"])], dtype=torch.float64)    # single-token calls
+                          float(st["device_flags"]), float(st["flag_runs"]), st["flag_wait_gpu_ms"], st["flag_seen_us"], float(st["hop_store_kernel"]), float(st["ring_alloc"]), float(st["passes_of_several_runs"])], dtype=torch.float64)    # single-token calls
         dist.gather(t, None, dst=0)
         # this stage's rows of the by-family roofline (counts of everything it served x durations of a graphs-off replay on its own GPU)
         try:
@@ -418,8 +418,8 @@ def bench_main(args, rank, world):
     tp.shutdown()
     tp_device_mode = tp.device_mode
     head_stats = tp.stats()
-    gathered = [torch.zeros(17, dtype=torch.float64) for _ in range(world)]
-    dist.gather(torch.zeros(17, dtype=torch.float64), gathered, dst=0)
+    gathered = [torch.zeros(18, dtype=torch.float64) for _ in range(world)]
+    dist.gather(torch.zeros(18, dtype=torch.float64), gathered, dst=0)
     stage_rows = [None] * world
     dist.gather_object(None, stage_rows, dst=0)
     dist.barrier()
@@ -443,7 +443,8 @@ def bench_main(args, rank, world):
                     "device_flags": bool(gathered[r][11]), "flag_runs": int(gathered[r][12]), "wait_for_input_gpu_ms": round(float(gathered[r][13]), 1),
                     "flag_seen_us_per_run": round(float(gathered[r][14]) / max(1.0, float(gathered[r][12])), 2) if gathered[r][12] > 0 else None,
                     # decided and logged at the transport's set-up, per rank: how this stage stores its activations into the next stage's ring, and what memory its own ring is
-                    "hop_store": "kernel" if gathered[r][15] else "memcpy", "ring_alloc": RING_ALLOC.get(int(gathered[r][16]), "?")} for r in range(1, world)]
+                    "hop_store": "kernel" if gathered[r][15] else "memcpy", "ring_alloc": RING_ALLOC.get(int(gathered[r][16]), "?"),
+                    "passes_of_several_runs": int(gathered[r][17])} for r in range(1, world)]                      # (run coalescing on a stage that is the whole target: --gpus 2)
     slow = max(stage_stats, key=lambda s: s["gpu_ms_per_call"])
     # the same by-family roofline as N = 1: every stage's launch counts (graphs x replays, aborted launches apart) priced with the durations of a graphs-off replay on its
     # own GPU; families add up over the stages; the dominant family is the one the stages spent most GPU time in.  HBM traffic: the committed single-GPU PMC pass of the same
