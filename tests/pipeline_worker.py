@@ -68,7 +68,10 @@ class Relay:
         self.n_embd = n_embd
 
     def run(self, n, meta, x_in=None, x_out=None):
-        x_out[:] = self.pattern(n, meta, self.n_embd)
+        want = self.pattern(n, meta, self.n_embd)
+        if x_in is not None:                                # a relay behind a relay (world_size >= 4): what the stage before it stored must have arrived intact
+            assert np.array_equal(np.asarray(x_in), want), "activation block changed on its way between two relays"
+        x_out[:] = want
         return None
 
 
@@ -118,7 +121,7 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     world = dist.get_world_size()
-    assert world in (2, 3)
+    assert 2 <= world <= 5
     probe = OracleCompute(tgt)
     n_embd, n_vocab = probe.o.o_model_info(probe.h, 1), probe.n_vocab
     tp = P.Transport(P.job_name(), rank, world, n_embd, n_vocab, 64, N_CTX, device=-1, timeout_ms=60000)
@@ -127,7 +130,7 @@ def main():
         if world == 2:
             comp = probe
         else:
-            comp = CheckedOracle(tgt) if rank == 2 else Relay(n_embd)
+            comp = CheckedOracle(tgt) if rank == world - 1 else Relay(n_embd)     # every stage but the last relays (the oracle runs whole models): headers, activations and skips still cross every hop
         run_fn = comp.run
         lat = float(os.environ.get("PI_TEST_STAGE_LATENCY_MS", "0"))
         if lat > 0:                                         # a slow stage: the head's runs queue up in the ring behind the one being computed (coalescing test)

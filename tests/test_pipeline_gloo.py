@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size 2 and 3 (torchrun + gloo for the rendezvous; the runs travel through the library's shared-memory transport
+"""N > 1 path on CPU: world_size 2, 3 and 4 (torchrun + gloo for the rendezvous; the runs travel through the library's shared-memory transport
 on host rings, the oracle stands in for the stage kernels).  The peer-store flavour of the same transport runs in tests/test_gpu_engine.py."""
 import json
 import os
@@ -27,6 +27,7 @@ def test_split_layers_matches_reference_rule():
 
 @pytest.mark.parametrize("tgt,dft,seed,world", [("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, 2), ("tiny_llama_q4_k_m", "tiny_llama_q4_k_m", 11, 2),
                                                 ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, 3),       # 3: head + two stages (header and activation hop between stages)
+                                                ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, 4),       # 4: one layer per stage — a run crosses two stage-to-stage hops; skips propagate through two forwards
                                                 ("tiny_llama_b_q4_k_m", "tiny_llama_q4_k_m", 13, -2)])     # -2: world 2 with run coalescing in the stage's serve loop (the stage is the whole target)
 def test_head_and_stage_over_gloo_are_lossless(tmp_path, tgt, dft, seed, world):
     """rank 0: C++ driver + proxy target context; rank 1 (and 2): pipeinfer_transport_serve.  The accepted tokens must equal the reference
