@@ -91,6 +91,15 @@ static __device__ __forceinline__ uint32_t h2_bits(pi_half2 v) { return __builti
 static __device__ __forceinline__ uint32_t pk_fma(uint32_t a, uint32_t b, uint32_t c) { return h2_bits(__builtin_elementwise_fma(h2_from_bits(a), h2_from_bits(b), h2_from_bits(c))); }
 static __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return h2_bits(h2_from_bits(a) * h2_from_bits(b)); }
 static __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return h2_bits(h2_from_bits(a) + h2_from_bits(b)); }
+// the mins product: its operands are four f16 per lane — (bs[4c] .. bs[4c+3]) of a token and (m, m, m', m') of a row — so it is the K = 16 instruction (the K = 32 form carried four
+// zeros per lane in each operand: moves to build them, and twice the matrix-core time).  Lane (i, g) holds k = 4g .. 4g+3 there and k = 8g .. 8g+3 (+ zeros) here: the same pairs
+// meet, and the sum of exact integers below 2^24 does not depend on their order.
+using pi_f32x2 = __attribute__((ext_vector_type(2))) float;
+static __device__ __forceinline__ pi_f32x2 mq_pair(float a, float b) { pi_f32x2 v = { a, b }; asm volatile("" : "+v"(v)); return v; }
+using pi_half4 = __attribute__((ext_vector_type(4))) _Float16;
+static __device__ __forceinline__ pi_f32x4 mq_mfma_k16(uint2 a, uint2 b, pi_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(pi_half4, a), __builtin_bit_cast(pi_half4, b), c, 0, 0, 0);
+}
 
 // LDS image of one block of activations: 8 fragments + 1 KB aux.  A fragment is 1 KB (16 tokens) or, for batches of <= 8 tokens (NT8), the 512 bytes
 // of tokens 0..7: lane (token, g) at (8 g + token) * 16
@@ -235,7 +244,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         return bw;
     };
     auto compute_q3 = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
-        const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
+        const float dx_h = pi_h2f((uint16_t) (W.dd & 0xffff)); const pi_f32x2 dP = mq_pair(dx_h, dx_h); const float dx = dP.x;
         const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
         uint4 bw[KS];
 #pragma unroll
@@ -256,7 +265,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
     };
     auto compute_q6 = [&](const mq_w<TYPE, S> & W, const uint8_t * blk) __attribute__((always_inline)) {
         const int n = gq >> 1, hh = gq & 1;
-        const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
+        const float dx_h = pi_h2f((uint16_t) (W.dd & 0xffff)); const pi_f32x2 dP = mq_pair(dx_h, dx_h); const float dx = dP.x;
         float d[NC][4];
 #pragma unroll
         for (int ch = 0; ch < NC; ch++) {
@@ -300,7 +309,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         const pi_f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
         if constexpr (Q6) {
             const int n = gq >> 1, hh = gq & 1;
-            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff));
+            const float dx_h = pi_h2f((uint16_t) (W.dd & 0xffff)); const pi_f32x2 dP = mq_pair(dx_h, dx_h); const float dx = dP.x;
             const uint32_t aoff = (uint32_t) (r + 32 * n) * 16 + 8 * hh;
             uint4 b1[KS], b2[KS];
 #pragma unroll
@@ -337,7 +346,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff)), dminx = pi_h2f((uint16_t) (W.dd >> 16));
+            const pi_f32x2 dP = mq_pair(pi_h2f((uint16_t) (W.dd & 0xffff)), pi_h2f((uint16_t) (W.dd >> 16))); const float dx = dP.x, dminx = dP.y;
             const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);
             const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);
             const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);
@@ -375,11 +384,11 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
                     for (int i = 0; i < 4; i++) acc[ch][kk][i] = fmaf(d[i], c[i], acc[ch][kk][i]);
                 }
                 const uint2 bs = *(const uint2 *) (blk + ch * CH_LDS + 8 * FRAG + 64 + lane * 8);
-                const uint4 am = make_uint4(bs.x, bs.y, 0u, 0u);
+                const uint2 am = make_uint2(bs.x, bs.y);
                 if constexpr (Q5) {
                     if (s == 0) {
-                        const uint4 bm = make_uint4(M0, M1, 0u, 0u);
-                        const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+                        const uint2 bm = make_uint2(M0, M1);
+                        const pi_f32x4 cm = mq_mfma_k16(am, bm, z);
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const float prod = nd[i] * cm[i]; accm[ch][0][i] = accm[ch][0][i] + prod; }
                     }
@@ -387,8 +396,8 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
 #pragma unroll
                     for (int cc = 0; cc < CS; cc++) {
                         const int c = s * CS + cc;
-                        const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);
-                        const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+                        const uint2 bm = make_uint2(M0 & own[c], M1 & own[c]);
+                        const pi_f32x4 cm = mq_mfma_k16(am, bm, z);
 #pragma unroll
                         for (int i = 0; i < 4; i++) accm[ch][cc][i] = fmaf(nd[i], cm[i], accm[ch][cc][i]);
                     }
@@ -403,7 +412,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         if constexpr (Q6) { compute_q6(W, blk); return; }
         // ---- block scalars: d, dmin of the row; this lane's two scales and two mins, bytes of one record ----
         const uint32_t ddl = live ? W.dd : 0u;
-        const float dx = pi_h2f((uint16_t) (ddl & 0xffff)), dminx = pi_h2f((uint16_t) (ddl >> 16));
+        const pi_f32x2 dP = mq_pair(pi_h2f((uint16_t) (ddl & 0xffff)), pi_h2f((uint16_t) (ddl >> 16))); const float dx = dP.x, dminx = dP.y;
         // integer -> f16 pair without a conversion: bytes (v, 0x64, v, 0x64) = (1024 + v, 1024 + v)
         const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);                       // (s, s) of sub-block 2gq   (low nibbles)
         const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);          // (1024 + s) / 16 - 64 = s / 16 of sub-block 2gq+1 (high nibbles)
@@ -451,7 +460,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
 #pragma unroll
         for (int ch = 0; ch < NC; ch++) {
         const uint2 bs = *(const uint2 *) (blk + ch * CH_LDS + 8 * FRAG + 64 + (NT8 ? (gq * 16 + (r & 7)) : lane) * 8);  // f16 (bs[4gq] .. bs[4gq+3]) of token r
-        const uint4 am = make_uint4(bs.x, bs.y, 0u, 0u);
+        const uint2 am = make_uint2(bs.x, bs.y);
         float nd[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) nd[i] = -dy[ch][i] * dminx;
@@ -459,8 +468,8 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
             // Q5_K (ggml-quants.c:5998-6002): ONE scalar chain, summs += dmin * (float) sum_j m_j * (bs[2j] + bs[2j+1]) — a multiply, then an add; every K-slice
             // contributes to the one product, so B is unmasked.  Wave 0 of the row group carries it.
             if (s == 0) {
-                const uint4 bm = make_uint4(M0, M1, 0u, 0u);
-                const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+                const uint2 bm = make_uint2(M0, M1);
+                const pi_f32x4 cm = mq_mfma_k16(am, bm, z);
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const float prod = nd[i] * cm[i]; accm[ch][0][i] = accm[ch][0][i] + prod; }
             }
@@ -468,8 +477,8 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
 #pragma unroll
         for (int cc = 0; cc < CS; cc++) {
             const int c = s * CS + cc;
-            const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);                                 // only K-slice c contributes to chain c
-            const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+            const uint2 bm = make_uint2(M0 & own[c], M1 & own[c]);                                 // only K-slice c contributes to chain c
+            const pi_f32x4 cm = mq_mfma_k16(am, bm, z);
 #pragma unroll
             for (int i = 0; i < 4; i++) accm[ch][cc][i] = fmaf(nd[i], cm[i], accm[ch][cc][i]);             // the products are integers below 2^24: exact in any form
         }
@@ -493,7 +502,7 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
     };
     auto front = [&](const mq_w<TYPE, S> & W, const mq_act & A, bool live, mq_pend & P) __attribute__((always_inline)) {
         const uint32_t ddl = live ? W.dd : 0u;
-        const float dx = pi_h2f((uint16_t) (ddl & 0xffff)), dminx = pi_h2f((uint16_t) (ddl >> 16));
+        const pi_f32x2 dP = mq_pair(pi_h2f((uint16_t) (ddl & 0xffff)), pi_h2f((uint16_t) (ddl >> 16))); const float dx = dP.x, dminx = dP.y;
         const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);
         const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);
         const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);
@@ -521,18 +530,18 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         }
         const uint32_t M0 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04020402u), 0xE400E400u);
         const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);
-        const uint4 am = make_uint4(A.bs.x, A.bs.y, 0u, 0u);
+        const uint2 am = make_uint2(A.bs.x, A.bs.y);
         if constexpr (Q5) {
             if (s == 0) {
-                const uint4 bm = make_uint4(M0, M1, 0u, 0u);
-                P.cm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+                const uint2 bm = make_uint2(M0, M1);
+                P.cm[0] = mq_mfma_k16(am, bm, z);
             } else P.cm[0] = z;
         } else {
 #pragma unroll
             for (int cc = 0; cc < CS; cc++) {
                 const int c = s * CS + cc;
-                const uint4 bm = make_uint4(M0 & own[c], M1 & own[c], 0u, 0u);
-                P.cm[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+                const uint2 bm = make_uint2(M0 & own[c], M1 & own[c]);
+                P.cm[cc] = mq_mfma_k16(am, bm, z);
             }
         }
     };
@@ -630,65 +639,89 @@ static __device__ __forceinline__ void mmq_kq_body(const mmvq_args & g, const in
         for (int cc = 0; cc < CS; cc++) P1.cm[cc] = pi_f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int i = 0; i < 4; i++) { P1.d[i] = 0.0f; P1.nd[i] = 0.0f; }
-        for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
+        auto pipe_tile = [&](const int T, const int j) __attribute__((always_inline)) {
+            dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
+            const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
+            fetch(buf, A0);                                            // (the tile landed before the barrier that ended the previous tile)
 #pragma unroll
-            for (int j = 0; j < 2 * NB; j++) {
-                const int T = T0 + j;
-                if (T >= ntile) goto pipe_done;
-                dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
-                const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
-                fetch(buf, A0);                                            // (the tile landed before the barrier that ended the previous tile)
-#pragma unroll
-                for (int u = 0; u < TB; u++) {
-                    const int b = T * TB + u;
-                    mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
-                    mq_act & Ac = (u & 1) ? A1 : A0;
-                    mq_act & An = (u & 1) ? A0 : A1;
-                    if (u + 1 < TB) fetch(buf + (u + 1) * MQ_BLK_LDS, An);
-                    // (the uniform branch is deliberate, as in the plain form: a basic-block boundary per block step — without it the steps of a tile are one scheduling
-                    //  region, the scheduler overlaps them all and spills.  b == nb still enters: it retires block nb - 1 beside a dead block.)
-                    // (two pending sets used alternately — TB is even, so a block's parity is its u's — instead of a copy per block)
-                    mq_pend & Pc = (u & 1) ? P1 : P0;
-                    mq_pend & Pp = (u & 1) ? P0 : P1;
-                    if (b <= nb) {
-                        front(W, Ac, b < nb, Pc);
-                        back(Pp);
-                    }
-                    load_w(b + D, W);
+            for (int u = 0; u < TB; u++) {
+                const int b = T * TB + u;
+                mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
+                mq_act & Ac = (u & 1) ? A1 : A0;
+                mq_act & An = (u & 1) ? A0 : A1;
+                if (u + 1 < TB) fetch(buf + (u + 1) * MQ_BLK_LDS, An);
+                // (the uniform branch is deliberate, as in the plain form: a basic-block boundary per block step — without it the steps of a tile are one scheduling
+                //  region, the scheduler overlaps them all and spills.  b == nb still enters: it retires block nb - 1 beside a dead block.)
+                // (two pending sets used alternately — TB is even, so a block's parity is its u's — instead of a copy per block)
+                mq_pend & Pc = (u & 1) ? P1 : P0;
+                mq_pend & Pp = (u & 1) ? P0 : P1;
+                if (b <= nb) {
+                    front(W, Ac, b < nb, Pc);
+                    back(Pp);
                 }
-                if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);
-                wg_barrier();
+                load_w(b + D, W);
             }
+            if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);
+            wg_barrier();
+        };
+        // whole trips in a loop with ONE exit, the last ntile % (2 NB) tiles as straight-line code behind it (see the plain form below: an exit in the middle of a trip
+        // makes the wait-count pass drain the ring at the top of every trip)
+        const int nfull = ntile / (2 * NB) * (2 * NB);
+        for (int T0 = 0; T0 < nfull; T0 += 2 * NB) {
+#pragma unroll
+            for (int j = 0; j < 2 * NB; j++) pipe_tile(T0 + j, j);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * NB - 1; j++) {
+            if (nfull + j >= ntile) goto pipe_done;
+            pipe_tile(nfull + j, j);
         }
 pipe_done:
         // the last block's chains: block step nb retired them when the row's last tile had room for it (what is pending then is a dead set); a row of whole tiles ends on an
         // odd block, whose set is still pending
         if (nb % TB == 0) back(P1);
-    } else
-    for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
+    } else {
+        // One tile: DMA request for tile T + NB - 1, TB block steps (compute, then the slot's refill for block b + D), the wave's wait for tile T + 1's DMAs, the barrier.
+        auto tile_step = [&](const int T, const int j) __attribute__((always_inline)) {
+            dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
+            const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
 #pragma unroll
-        for (int j = 0; j < 2 * NB; j++) {
-            const int T = T0 + j;
-            // One chunk: LEAVE at the first tile past the end instead of skipping it — a tile is then only ever entered from the tile before it, and the wait-count pass sees
-            // every refill that tile issued.  With `if (T < ntile) { ... }` it assumed the path that skipped the tile and waited for all but ~3 blocks of the 8-block ring
-            // (vmcnt(12..14) in front of a block's first use instead of vmcnt(28..31)): half the ring was never in flight.  Two chunks keep the skip form: without the join the
-            // scheduler pipelines across their one-block tiles and runs out of registers (256 + spills).
-            if constexpr (NC == 1) { if (T >= ntile) goto tiles_done; }
-            if (NC == 1 || T < ntile) {
-                dma_tile(T + NB - 1, lds0 + ((j + NB - 1) % NB) * TB * MQ_BLK_LDS);
-                const uint8_t * buf = lds + (j % NB) * TB * MQ_BLK_LDS;
+            for (int u = 0; u < TB; u++) {
+                const int b = T * TB + u;
+                mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
+                if (dbg & 1) acc[0][0][0] += __builtin_bit_cast(float, W.dd ^ W.rec ^ qdword(W, 0) ^ qdword(W, KS - 1));
+                else if (b < nb) compute(W, buf + u * MQ_BLK_LDS, true);
+                load_w(b + D, W);
+            }
+            if (!(dbg & 2)) {
+                if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);      // (the last tiles request nothing new)
+            }
+            wg_barrier();
+        };
+        if constexpr (NC == 1) {
+            // One chunk.  The compiler's wait-count pass works on merged states: every edge INTO a block contributes what may still be in flight there.  A trip of 2 NB tiles
+            // that can be left in the middle (`if (T >= ntile) goto done`, which the structuriser routes through the loop header) handed the header the ring as the allocator
+            // had it named at that exit — other registers than at the bottom of the trip — and the first blocks of every trip then waited for "pending" loads into registers
+            // they use as temporaries: vmcnt(1), (4), (7), (10) ... in front of their LDS reads, a drain of the 8-block ring per trip (ISA of round 5; tools_dev/scan_vmcnt.py
+            // lists such waits).  So: whole trips in a loop that has ONE exit, the bottom, and the row's last ntile % (2 NB) tiles as straight-line code behind it.
+            const int nfull = ntile / (2 * NB) * (2 * NB);
+            for (int T0 = 0; T0 < nfull; T0 += 2 * NB) {
 #pragma unroll
-                for (int u = 0; u < TB; u++) {
-                    const int b = T * TB + u;
-                    mq_w<TYPE, S> & W = ring[(j % 2) * TB + u];
-                    if (dbg & 1) acc[0][0][0] += __builtin_bit_cast(float, W.dd ^ W.rec ^ qdword(W, 0) ^ qdword(W, KS - 1));
-                    else if (b < nb) compute(W, buf + u * MQ_BLK_LDS, true);
-                    load_w(b + D, W);
+                for (int j = 0; j < 2 * NB; j++) tile_step(T0 + j, j);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * NB - 1; j++) {
+                if (nfull + j >= ntile) goto tiles_done;
+                tile_step(nfull + j, j);
+            }
+        } else {
+            // Two chunks keep the skip form: without the join the scheduler pipelines across their one-block tiles and runs out of registers (256 + spills).
+            for (int T0 = 0; T0 < ntile; T0 += 2 * NB) {
+#pragma unroll
+                for (int j = 0; j < 2 * NB; j++) {
+                    const int T = T0 + j;
+                    if (T < ntile) tile_step(T, j);
                 }
-                if (!(dbg & 2)) {
-                    if (T + NB - 1 < ntile) MQ_WAIT_VM(WAIT_N); else MQ_WAIT_VM((NB - 1) * TB * LW);      // (the last tiles request nothing new)
-                }
-                wg_barrier();
             }
         }
     }
@@ -906,7 +939,7 @@ __global__ void __launch_bounds__(64 * R) k_mmq_g2(const mmvq_args g, const int 
 #pragma unroll
         for (int x = 0; x < 2; x++) {
             const g2_w & W = x ? Wb : Wa;
-            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff)), dminx = pi_h2f((uint16_t) (W.dd >> 16));
+            const float dx = pi_h2f((uint16_t) (W.dd & 0xffff)), dminx = pi_h2f((uint16_t) (W.dd >> 16));       // (not through mq_pair: this kernel's registers are hand-counted)
             const uint32_t S1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04000400u), 0xE400E400u);
             const uint32_t S2 = pk_fma(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04010401u), 0x2C002C00u, 0xD400D400u);
             const uint32_t C1 = pk_mul(S1, 0xE400E400u), C2 = pk_mul(S2, 0xE400E400u);
@@ -935,9 +968,9 @@ __global__ void __launch_bounds__(64 * R) k_mmq_g2(const mmvq_args g, const int 
             const uint32_t M1 = pk_add(__builtin_amdgcn_perm(0x64646464u, W.rec, 0x04030403u), 0xE400E400u);
 #pragma unroll
             for (int m = 0; m < 2; m++) {
-                const uint4 am = make_uint4(AM[m].x, AM[m].y, 0u, 0u);
-                const uint4 bm = make_uint4(M0 & pairmask[m], M1 & pairmask[m], 0u, 0u);
-                const pi_f32x4 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pi_half8, am), __builtin_bit_cast(pi_half8, bm), z, 0, 0, 0);
+                const uint2 am = make_uint2(AM[m].x, AM[m].y);
+                const uint2 bm = make_uint2(M0 & pairmask[m], M1 & pairmask[m]);
+                const pi_f32x4 cm = mq_mfma_k16(am, bm, z);
 #pragma unroll
                 for (int i = 0; i < 4; i++) accm[x][m][i] = fmaf(nd[i], cm[i], accm[x][m][i]);
             }
@@ -1055,9 +1088,9 @@ static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t
         case 14: mmq_go<TYPE, 1, 4, 2, T8>(g, groups, stream, ea, eb); break;
         case 22: mmq_go<TYPE, 2, 2, 2, T8>(g, groups, stream, ea, eb); break;
         case 24: mmq_go<TYPE, 2, 4, 2, T8>(g, groups, stream, ea, eb); break;
-        case 41: mmq_go<TYPE, 4, 1, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
-        case 43: mmq_go<TYPE, 4, 3, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
-        default: mmq_go<TYPE, 4, 2, 2, TYPE == PI_Q6_K ? 2 : 4>(g, groups, stream, ea, eb); break;
+        case 41: mmq_go<TYPE, 4, 1, 2, 4>(g, groups, stream, ea, eb); break;
+        case 43: mmq_go<TYPE, 4, 3, 2, 4>(g, groups, stream, ea, eb); break;
+        default: mmq_go<TYPE, 4, 2, 2, 4>(g, groups, stream, ea, eb); break;
     }
 }
 // two row groups per wave (k_mmq_g2): R waves per workgroup so that the launch is ONE round of <= 256 workgroups
@@ -1101,7 +1134,7 @@ static void mmq_dispatch(int type, const mmvq_args & g, int groups, int cfg, hip
 // ---- two weight types in one launch (k_mmq_kq2t): Q4_K segments followed by Q5_K or Q6_K segments, 3..8 tokens, S = 4 (the short-matrix configurations) ----
 template <int TB_, int R, int RB>
 static void mmq_2t_go(const mmvq_args & g, int groups_a, int groups_all, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int TBA = 4, TBB = TB_ == PI_Q6_K ? 2 : 4;                                    // blocks per tile at <= 8 tokens, as in mmq_dispatch_t's S = 4 rows
+    constexpr int TBA = 4, TBB = 4;                                    // blocks per tile at <= 8 tokens, as in mmq_dispatch_t's S = 4 rows
     constexpr size_t tiles = (size_t) 3 * (TBA > TBB ? TBA : TBB) * (8 * 512 + 1024), fold = (size_t) R * (8 * 16 * 17 + 4 * 16 * 17 + 256) * 4;
     constexpr size_t lds = tiles > fold ? tiles : fold;
     static_assert(tiles <= 65536, "LDS-DMA targets stay inside the first 64 KB");
