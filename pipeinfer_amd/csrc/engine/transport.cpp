@@ -553,11 +553,14 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
     const bool coalescing = is_first && is_last && ((ctx && !backend && ctx->coalesce_max.load() > 1) || cmax_backend > 1);
     bool pass_pending = false; uint64_t pass_first_res = 0;
     static const int64_t reaction_us = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
+    // tests: a stage that is slow to pick its input up, so that the head's runs DO queue behind one another (a tiny model on a fast GPU may never see two headers waiting)
+    static const int64_t test_latency_us = getenv("PIPEINFER_TEST_STAGE_LATENCY_US") ? atoll(getenv("PIPEINFER_TEST_STAGE_LATENCY_US")) : 0;
     while (coalescing) {
         const uint64_t t = in.tail.load(std::memory_order_relaxed);
         int64_t t0 = now_us();
         if (!tp->wait_for([&] { return in.head.load(std::memory_order_acquire) > t; }, -1)) { rc_all = -1; break; }
         st.wait_in_ms += (now_us() - t0) / 1e3;
+        if (test_latency_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(test_latency_us));
         if (pass_pending) {
             pass_pending = false;
             const int64_t w0 = now_us();

@@ -365,7 +365,7 @@ def test_three_processes_on_one_gpu_through_the_library_transport(tmp_path, tgt,
         env["PIPEINFER_RING_ALLOC"] = mode.split("-")[0]
     if mode == "coalesce":
         env["PIPEINFER_TEST_STAGE_COALESCE"] = "16"
-        env["PI_DEBUG_RUN_LATENCY_US"] = "0"
+        env["PIPEINFER_TEST_STAGE_LATENCY_US"] = "2000"      # the stage picks its input up late: the head's runs queue behind one another whatever the GPU's speed (without it 1 start in ~10 saw no two headers waiting)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     v = json.loads(out.read_text())
