@@ -163,12 +163,18 @@ struct pipeinfer_stats {
     double   cancel_gpu_ms;      /* GPU time (first to last event) those started-then-cancelled runs still took */
     uint64_t n_passes, n_pass_runs, n_pass_tokens, n_coalesced_passes;   /* feeder contexts: forward passes computed in full, the runs / tokens they carried, passes of more than one run */
     uint64_t weight_copy_bytes;  /* HBM held by the tile-major copies of the matrix-core kernel (0 for contexts with n_batch <= 2: they are not made) */
+    uint64_t n_lone_waits, n_lone_joined;  /* feeder contexts with run coalescing: times a lone one-token run was held back for the speculative run drafted behind it / times that run arrived in time */
+    double   gap_ema_ms, t1_ema_ms;        /* ... what the decision rests on: how long after a lone one-token run's start the next live run joins it (as the waits observe it), the GPU time of a one-token pass (moving averages) */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
 LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);    /* call with no run in flight (it also zeroes the device-side running sums) */
 /* launches since pipeinfer_reset_stats that found their run cancelled (llama_cancel_run after the start, llama.cpp:9981-9993) and returned on entry — what a cancelled run
  * stops doing (llama.cpp:5665-5687) — per kernel family (index = pi_kt_row.family in pipeinfer_ops.h).  Returns the families written (<= cap), -1 on error */
 LLAMA_API int  pipeinfer_get_aborted_launches(struct llama_context * ctx, uint64_t * out, int cap);
+/* schedule timeline (a measurement aid; recording is on only when the process was started with PI_TIMELINE set): host-clock events of the caller's thread and the target's
+ * feeder — start / probe / finish / cancel of runs, what each forward pass carried, when it left the GPU, why the feeder's reaction window ended — written as
+ * "t_us,tag,a,b,c" lines; the events are forgotten afterwards.  Returns the number of events (path NULL: only forgets them), -1 when the file cannot be written */
+LLAMA_API int  pipeinfer_timeline_dump(const char * path);
 
 /* ---- host KV-cell table on its own (no GPU needed): used by the CPU tests ---- */
 typedef struct pi_kvcells pi_kvcells;

@@ -556,10 +556,16 @@ static const void * compose_pass(llama_context * ctx, const std::vector<pi_run *
     dyn[0] = cell[0]; dyn[1] = n_kv; dyn[2] = n; dyn[3] = 1;
     return blk;
 }
+// Round 6 (tools_dev/timeline.py, profiles/r06_timeline_*): a cancelled run at the HEAD of the queue used to travel as a pass of its own, and the feeder then sat in the
+// reaction window of that empty pass until the caller finished the cancelled run - which the PipeInfer driver does only between two speculative runs (three blocking draft
+// steps, ~4-6 ms): every cancelled run cost the target one spec-run's drafting time of idle GPU.  Now they are completed on the spot (events only) and the feeder goes on
+// to the first live run.  PIPEINFER_FEED_SKIP_CANCELLED=0: the old behaviour (A/B).
+static bool feed_skips_cancelled() { static const bool on = !(getenv("PIPEINFER_FEED_SKIP_CANCELLED") && atoi(getenv("PIPEINFER_FEED_SKIP_CANCELLED")) == 0); return on; }
 // enqueues one pass (one run, or several runs the feeder took together) on the context's stream; every member's events and state are final afterwards
 static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass) {
     // the members as they are NOW: once a member reaches state 2 the caller may finish it, which erases it from pass->runs (under fmu) and recycles the object —
     // the loops below walk this copy, and the last thing the feeder does with a member is that very store
+    const int64_t t_feed0 = time_us();
     std::vector<pi_run *> runs;
     { std::lock_guard<std::mutex> lk(ctx->fmu); runs = pass->runs; }
     for (pi_run * r : runs) r->state.store(1);
@@ -567,7 +573,9 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
     for (pi_run * r : runs) ok = hipEventRecord(r->begin, ctx->stream) == hipSuccess && ok;
     hipEvent_t seg_done[2] = { ctx->seg_events[0], ctx->seg_events[1] };
     const int n = pass->n_tokens;
+    bool gpu_work = false;
     if (!runs_cancelled(runs)) {
+        gpu_work = true;
         const void * meta = runs.size() == 1 ? (const void *) runs[0]->meta_host : compose_pass(ctx, runs, pass->n_tokens);
         ok = ok && meta != nullptr;
         const int nseg = n_segments(ctx), kv_head = ok ? ((const int32_t *) meta)[2 * n] : 0;
@@ -591,7 +599,8 @@ static void feed_pass(llama_context * ctx, const std::shared_ptr<pi_pass> & pass
         r->launched = ok && full;
         if (hipEventRecord(r->done, ctx->stream) != hipSuccess) ok = false;
     }
-    if (ctx->coalesce_max.load() > 1 && ctx->pass_event && hipEventRecord(ctx->pass_event, ctx->stream) == hipSuccess) { ctx->pass_pending = true; ctx->pass_first_id = runs[0]->run_id; }
+    // (a pass that put no work on the GPU - every member was cancelled before its first segment - is nothing the caller reacts to: no reaction window behind it)
+    if ((gpu_work || !feed_skips_cancelled()) && ctx->coalesce_max.load() > 1 && ctx->pass_event && hipEventRecord(ctx->pass_event, ctx->stream) == hipSuccess) { ctx->pass_pending = true; ctx->pass_first_id = runs[0]->run_id; ctx->pass_fed_us = t_feed0; }
     if (!ok) {                                                                 // NOT the same thing as a cancelled run: finish reports it (the driver ends the generation)
         for (pi_run * r : runs) r->failed = true;
         fprintf(stderr, "llama_decode (feeder): %s\n", ctx->last_error.str().c_str());
@@ -607,21 +616,63 @@ static void wait_for_reaction(llama_context * ctx) {
     if (!ctx->pass_pending) return;
     (void) hipEventSynchronize(ctx->pass_event);
     ctx->pass_pending = false;
-    static const int64_t tmo = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
+    tl("pass_done", ctx->pass_first_id);
+    // bounded by PIPEINFER_REACTION_US (10 ms) and by three quarters of what the pass took from its hand-over to here (a context whose passes take a millisecond does not sit
+    // out ten for a caller that is busy rather than blocked); the variable, when set, is the bound whatever the pass took
+    static const bool tmo_fixed = getenv("PIPEINFER_REACTION_US") != nullptr;
+    static const int64_t tmo_max = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
     const int64_t t0 = time_us();
+    const int64_t tmo = tmo_fixed ? tmo_max : std::min<int64_t>(tmo_max, std::max<int64_t>(500, (t0 - ctx->pass_fed_us) * 3 / 4));
     for (int spin = 0; ; spin++) {
-        if (ctx->waiters.load() > 0) return;
-        if (ctx->last_finished_id.load() >= ctx->pass_first_id && ctx->caller_epoch.load() > ctx->epoch_after_finish.load()) return;
-        if (time_us() - t0 > tmo) return;
+        if (ctx->waiters.load() > 0) { tl("react_end", 1); return; }
+        if (ctx->last_finished_id.load() >= ctx->pass_first_id && ctx->caller_epoch.load() > ctx->epoch_after_finish.load()) { tl("react_end", 2); return; }
+        if (time_us() - t0 > tmo) { tl("react_end", 3); return; }
         { std::lock_guard<std::mutex> lk(ctx->fmu); if (ctx->fstop) return; }
         if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
+}
+// A lone one-token run (the driver's non-speculative run for a freshly sampled token, right after a mismatch cancelled everything else) costs a whole pass over the
+// weights; the speculative run drafted from that token follows G = (1 + n_draft) draft steps later and would ride in the same pass for ~35 % more.  The feeder waits for it
+// when that pays: G below PIPEINFER_LONE_WAIT_ALPHA (0.7) x the GPU time of a one-token pass (t1_ema_us, measured at finish).  G is what the wait itself observes
+// (gap_idle_ema_us: the run's start -> a live run joins, with the target idle, i.e. draft steps at their undisturbed rate; the caller's gaps beside a RUNNING target pass are
+// twice as long and would talk the feeder out of waiting for good - that was the first version): the first lone run and every 32nd one after a failure probe for it with a
+// wait of up to one pass time; a wait that times out counts as G = 2 x that.  70B + TinyLlama: G 5 ms against 11 ms - wait; 7B + TinyLlama: G 5 ms against 2.3 ms - launch at once.
+// Ends early when a live run joins the queue, the caller blocks on a run or polls instead of drafting (nothing will follow), or the run is cancelled.
+static void lone_wait(llama_context * ctx, const pi_run * first) {
+    static const double alpha = getenv("PIPEINFER_LONE_WAIT_ALPHA") ? atof(getenv("PIPEINFER_LONE_WAIT_ALPHA")) : 0.7;
+    const int t1 = ctx->t1_ema_us.load();
+    if (alpha <= 0.0 || t1 <= 0) return;
+    const int gap = ctx->gap_idle_ema_us;
+    const bool probe = gap == 0 || (++ctx->lone_seen % 32) == 0;
+    if (!probe && (double) gap >= alpha * (double) t1) return;
+    const int64_t tmo = probe ? (int64_t) t1 : std::min<int64_t>(2 * (int64_t) gap, t1), t0 = time_us();
+    const uint64_t e0 = ctx->caller_epoch.load();
+    int why = 0;
+    for (int spin = 0; !why; spin++) {
+        if (ctx->waiters.load() > 0) why = 1;
+        else if (first->cancel_req.load()) why = 2;
+        else if (ctx->caller_epoch.load() - e0 > 16) why = 3;                  // the caller polls this context instead of drafting: nothing more is coming
+        else if (time_us() - t0 > tmo) why = 4;
+        else {
+            std::lock_guard<std::mutex> lk(ctx->fmu);
+            if (ctx->fstop) why = 5;
+            for (const pi_run * q : ctx->fqueue) if (!q->canceled && !q->cancel_req.load()) { why = 6; break; }
+        }
+        if (!why) { if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+    }
+    const int64_t now = time_us();
+    ctx->stat_lone_waits++;
+    if (why == 6) { ctx->stat_lone_joined++; const int g = (int) std::min<int64_t>(now - first->t_start_us, 200000); ctx->gap_idle_ema_us = gap ? (3 * gap + g) / 4 : g; }
+    else if (why == 3 || why == 4) ctx->gap_idle_ema_us = gap ? (3 * gap + 2 * t1) / 4 : 2 * t1;
+    ctx->gap_ema_us.store(ctx->gap_idle_ema_us);
+    tl("lone_wait", first->run_id, why, (int) (now - t0));
 }
 static void feeder_main(llama_context * ctx) {
     (void) hipSetDevice(ctx->model->device);
     while (true) {
         {
             std::unique_lock<std::mutex> lk(ctx->fmu);
+            if (ctx->fqueue.empty()) tl("feeder_idle");
             ctx->fcv.wait(lk, [&] { return ctx->fstop || !ctx->fqueue.empty(); });
             if (ctx->fqueue.empty()) return;                                   // fstop and drained
         }
@@ -630,11 +681,25 @@ static void feeder_main(llama_context * ctx) {
         if (coalesce && !ctx->pass_event && hipEventCreateWithFlags(&ctx->pass_event, hipEventDisableTiming) != hipSuccess) { ctx->pass_event = nullptr; coalesce = false; }
         if (coalesce) wait_for_reaction(ctx); else ctx->pass_pending = false;
         std::vector<std::shared_ptr<pi_pass>> todo;                            // cancelled runs met on the way (no GPU work, events only), then the pass itself
+        auto single = [&](pi_run * r) { auto p = std::make_shared<pi_pass>(); p->runs.push_back(r); p->id = r->run_id; p->n_tokens = r->n_tokens; p->n_kv = r->n_kv; r->pass = p; r->row0 = 0; r->pass_leader = true; r->pass_tokens = r->n_tokens; return p; };
+        auto feed = [&](std::vector<std::shared_ptr<pi_pass>> & v) { for (auto & p : v) { tl("pass", p->id, (int) p->runs.size(), p->n_tokens); feed_pass(ctx, p); tl("fed", p->id); } v.clear(); };
+        pi_run * first = nullptr;
+        std::shared_ptr<pi_pass> pass;
         {
             std::lock_guard<std::mutex> lk(ctx->fmu);
-            auto single = [&](pi_run * r) { auto p = std::make_shared<pi_pass>(); p->runs.push_back(r); p->id = r->run_id; p->n_tokens = r->n_tokens; p->n_kv = r->n_kv; r->pass = p; r->row0 = 0; r->pass_leader = true; r->pass_tokens = r->n_tokens; return p; };
-            pi_run * first = ctx->fqueue.front(); ctx->fqueue.pop_front();
-            std::shared_ptr<pi_pass> pass = single(first);
+            if (coalesce && feed_skips_cancelled())                             // cancelled runs at the head: completed on the spot, no reaction window of their own
+                while (!ctx->fqueue.empty() && (ctx->fqueue.front()->canceled || ctx->fqueue.front()->cancel_req.load())) { todo.push_back(single(ctx->fqueue.front())); ctx->fqueue.pop_front(); }
+            if (!ctx->fqueue.empty()) { first = ctx->fqueue.front(); ctx->fqueue.pop_front(); pass = single(first); }
+        }
+        feed(todo);
+        if (!first) continue;
+        if (coalesce && first->n_tokens == 1 && !first->canceled && !first->cancel_req.load()) {
+            bool alone;
+            { std::lock_guard<std::mutex> lk(ctx->fmu); alone = true; for (const pi_run * q : ctx->fqueue) if (!q->canceled && !q->cancel_req.load()) { alone = false; break; } }
+            if (alone) lone_wait(ctx, first);
+        }
+        {
+            std::lock_guard<std::mutex> lk(ctx->fmu);
             if (coalesce && !first->canceled && !first->cancel_req.load()) {
                 std::vector<pi_run *> dropped;
                 while (!ctx->fqueue.empty()) {
@@ -650,7 +715,8 @@ static void feeder_main(llama_context * ctx) {
             }
             todo.push_back(pass);
         }
-        for (auto & p : todo) feed_pass(ctx, p);
+        feed(todo);
+        if (g_timeline_on && coalesce && ctx->pass_pending) { (void) hipEventSynchronize(ctx->pass_event); tl("pass_gpu_done", ctx->pass_first_id); }   // (timeline only: the host clock of the pass leaving the GPU; the feeder would wait for it before its next pass anyway)
     }
 }
 
@@ -728,6 +794,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         return run;
     }
     run->state.store(0); run->cancel_req.store(false); run->segments_run = 0;
+    tl("start", ctx->stream_priority, run->run_id, n_tokens);
     urgent_begin(ctx);
     if (ctx->seg_layers > 0) {                                                // segmented: the feeder thread launches (and may cut short) the run
         if (!ctx->feeder.joinable()) {
@@ -785,6 +852,7 @@ void context_cancel_run(llama_context * ctx, pi_run * r) {
     // pass's next pi_op_abort_begin, the compare-and-swap hits the pass if it is the one executing (kernel granularity, like the reference's poll between graph nodes:
     // ggml.c:15748-15811); a segmented context also stops launching its remaining segments.  A pass that carries several runs stops when ALL of them are cancelled.
     r->cancel_req.store(true);
+    tl("cancel", ctx->stream_priority, r->run_id, r->state.load());
     int32_t id = r->run_id; bool all = true, handed = r->state.load() != 0;
     {
         std::lock_guard<std::mutex> lk(ctx->fmu);
@@ -814,7 +882,9 @@ bool context_poll_oldest(llama_context * ctx) {
     static const int64_t dbg_delay_us = getenv("PI_DEBUG_RUN_LATENCY_US") ? atoll(getenv("PI_DEBUG_RUN_LATENCY_US")) : 0;   // tests: pretend every run takes at least this long
     if (dbg_delay_us > 0 && time_us() - ctx->inflight.front()->t_start_us < dbg_delay_us) return false;
     if (ctx->inflight.front()->state.load() != 2) return false;                // the feeder has not recorded its completion event yet
-    return hipEventQuery(ctx->inflight.front()->done) == hipSuccess;
+    const bool back = hipEventQuery(ctx->inflight.front()->done) == hipSuccess;
+    if (back) tl("probe_back", ctx->stream_priority, ctx->inflight.front()->run_id);
+    return back;
 }
 
 bool context_wait(llama_context * ctx, pi_run * run) {
@@ -1041,9 +1111,11 @@ int context_finish(llama_context * ctx, pi_run * run) {
     } else {
         {
             struct waiting { llama_context * c; waiting(llama_context * c_) : c(c_) { c->waiters.fetch_add(1); } ~waiting() { c->waiters.fetch_sub(1); } } w(ctx);
+            tl("finish_wait", ctx->stream_priority, run->run_id, run->state.load());
             while (run->state.load() != 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
             if (hipEventSynchronize(run->done) != hipSuccess) { ctx->last_error = "hipEventSynchronize failed"; urgent_end(ctx); return -1; }
         }
+        tl("finish", ctx->stream_priority, run->run_id, (run->canceled || run->cancel_req.load()) ? 1 : 0);
         if (run->run_id > ctx->last_finished_id.load()) ctx->last_finished_id.store(run->run_id);
         ctx->epoch_after_finish.store(ctx->caller_epoch.fetch_add(1) + 1);
         // experiment knob (tools_dev/draft_sensitivity.sh): what does the schedule lose per microsecond of draft latency?  > 0: the priority context's run holds the
@@ -1098,7 +1170,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
         ctx->stat_calls++; ctx->stat_alg_bytes += decode_alg_bytes(ctx, pn, n_kv);
         if (pn == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (pn == 1) ctx->stat_gpu_ms_1 += ms; }
+        if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (pn == 1) { ctx->stat_gpu_ms_1 += ms; const int e = ctx->t1_ema_us.load(), v = (int) (ms * 1000.0f); ctx->t1_ema_us.store(e ? (3 * e + v) / 4 : v); } tl("gpu_us", ctx->stream_priority, run->run_id, (int) (ms * 1000.0f)); }
     }
     if (run->pass) {                                                          // the object is about to be recycled: it leaves its pass
         std::lock_guard<std::mutex> lk(ctx->fmu);

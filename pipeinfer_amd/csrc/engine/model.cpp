@@ -3,12 +3,33 @@
 #include "engine.h"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace pi {
 int64_t time_us() {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+bool g_timeline_on = getenv("PI_TIMELINE") != nullptr;
+namespace { struct tl_event { int64_t t; const char * tag; int a, b, c; }; std::mutex tl_mu; std::vector<tl_event> tl_events; }
+void timeline_note(const char * tag, int a, int b, int c) {
+    const int64_t t = time_us();
+    std::lock_guard<std::mutex> lk(tl_mu);
+    tl_events.push_back(tl_event{ t, tag, a, b, c });
+}
+}
+
+// writes "t_us,tag,a,b,c" lines (events since the last dump) and forgets them; returns the number of events, -1 when the file cannot be written
+extern "C" LLAMA_API int pipeinfer_timeline_dump(const char * path) {
+    std::vector<pi::tl_event> ev;
+    { std::lock_guard<std::mutex> lk(pi::tl_mu); ev.swap(pi::tl_events); }
+    if (!path) return (int) ev.size();
+    FILE * f = fopen(path, "w");
+    if (!f) return -1;
+    for (const auto & e : ev) fprintf(f, "%lld,%s,%d,%d,%d\n", (long long) e.t, e.tag, e.a, e.b, e.c);
+    fclose(f);
+    return (int) ev.size();
 }
 
 llama_model::~llama_model() {

@@ -316,6 +316,7 @@ struct driver {
     // first draft token, and tests need the accept / cancel paths exercised.
     void run_speculation_loop() {
         bool is_waiting = llama_mpi_iprobe(tgt);
+        pi::tl("specloop", is_waiting ? 1 : 0, (int) tgt_runs.size());
         loop_found_target_back = is_waiting;                              // (adaptive draft pause: the only reason it counts)
         const int forced = P.min_spec_iters;
         bool returned_offset = false;
@@ -481,6 +482,7 @@ struct driver {
                 }
             }
 
+            pi::tl("sampled", n_past_tgt, any_match ? 1 : 0, current.speculative ? 1 : 0);
             if (failed) continue;
             if (!any_match) {
                 if (current.speculative) free_offsets.push_back(current.seq_offset);

@@ -88,7 +88,7 @@ int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(
 struct pipeinfer_transport {
     std::string name, error;
     int rank = 0, world = 0, n_embd = 0, n_vocab = 0, n_batch = 0, n_ctx = 0, device = -1, timeout_ms = 120000;
-    bool creator = false, device_mode = false;
+    bool creator = false, device_mode = false, set_hop_mode = false;
     uint8_t * base = nullptr; size_t total = 0;
     shm_layout * L = nullptr;
     // stage side
@@ -373,7 +373,7 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
         // the hop's store, decided here once and said per rank: a kernel of the producing stream when both ends are device memory (this stage's HBM -> the peer mapping of
         // the next stage's ring), hipMemcpyAsync when the rings are in host memory.  Nothing is left to hipPointerGetAttributes on an IPC mapping.
         const bool by_memcpy = getenv("PIPEINFER_HOP_STORE") && !strcmp(getenv("PIPEINFER_HOP_STORE"), "memcpy");
-        pi::hop_store_set_mode(tp->device_mode ? 1 : 2);
+        pi::hop_store_set_mode(tp->device_mode ? 1 : 2); tp->set_hop_mode = true;
         fprintf(stderr, "[pipeinfer transport, rank %d] hop store: %s (%s rings%s)\n", tp->rank, tp->device_mode && !by_memcpy ? "kernel of the producing stream (k_hop_store)" : "hipMemcpyAsync",
                 tp->device_mode ? "device" : "host", by_memcpy ? ", PIPEINFER_HOP_STORE=memcpy" : "");
     }
@@ -462,6 +462,7 @@ extern "C" pipeinfer_transport * pipeinfer_transport_open(const struct pipeinfer
 
 extern "C" void pipeinfer_transport_close(pipeinfer_transport * tp) {
     if (!tp) return;
+    if (tp->set_hop_mode) pi::hop_store_set_mode(0);                          // the process-wide store mode was this transport's: later stage chains / transports ask the runtime (or set their own) again
     if (tp->res_registered) (void) hipHostUnregister(tp->base + tp->L->off_res);
     if (tp->ctl_registered) (void) hipHostUnregister(tp->base);
     if (tp->peer_ring) (void) hipIpcCloseMemHandle(tp->peer_ring);
@@ -551,7 +552,10 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
     //  tests then exercise is the gathering, the conflict rule, the result order and the reaction window.  PIPEINFER_STAGE_COALESCE=<tokens> switches it on for such a backend.)
     const int cmax_backend = backend && getenv("PIPEINFER_STAGE_COALESCE") ? atoi(getenv("PIPEINFER_STAGE_COALESCE")) : 0;
     const bool coalescing = is_first && is_last && ((ctx && !backend && ctx->coalesce_max.load() > 1) || cmax_backend > 1);
-    bool pass_pending = false; uint64_t pass_first_res = 0;
+    bool pass_pending = false; uint64_t pass_first_res = 0; int64_t last_pass_us = 0;
+    // the reaction window is bounded by PIPEINFER_REACTION_US (10 ms) AND by three quarters of what the last pass took: a stage whose passes take a millisecond does not sit
+    // out ten waiting for a driver that is busy rather than blocked (set explicitly, the variable is the bound whatever the pass takes)
+    static const bool reaction_fixed = getenv("PIPEINFER_REACTION_US") != nullptr;
     static const int64_t reaction_us = getenv("PIPEINFER_REACTION_US") ? atoll(getenv("PIPEINFER_REACTION_US")) : 10000;
     // tests: a stage that is slow to pick its input up, so that the head's runs DO queue behind one another (a tiny model on a fast GPU may never see two headers waiting)
     static const int64_t test_latency_us = getenv("PIPEINFER_TEST_STAGE_LATENCY_US") ? atoll(getenv("PIPEINFER_TEST_STAGE_LATENCY_US")) : 0;
@@ -564,10 +568,11 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
         if (pass_pending) {
             pass_pending = false;
             const int64_t w0 = now_us();
+            const int64_t window_us = reaction_fixed ? reaction_us : std::min<int64_t>(reaction_us, std::max<int64_t>(500, last_pass_us * 3 / 4));
             for (int spin = 0; ; spin++) {
                 if (L->head_waiting.load(std::memory_order_acquire) > 0) break;
                 if (L->res.tail.load(std::memory_order_acquire) > pass_first_res && L->head_epoch.load(std::memory_order_acquire) > L->head_epoch_after_consume.load(std::memory_order_acquire)) break;
-                if (now_us() - w0 > reaction_us || L->fatal.load(std::memory_order_relaxed)) break;
+                if (now_us() - w0 > window_us || L->fatal.load(std::memory_order_relaxed)) break;
                 if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
         }
@@ -614,21 +619,27 @@ extern "C" int pipeinfer_transport_serve(pipeinfer_transport * tp, struct llama_
                     if (rc == 1) rc = -1;                                       // (a backend does not drop single members of a pass)
                 }
             } else rc = pi::stage_run_pass(ctx, (int) metas.size(), metas.data(), ntok.data(), lg.data(), ti.data(), tv.data(), ts.data(), abort_probe_all, tp);
-            st.compute_ms += (now_us() - t0) / 1e3;
+            last_pass_us = now_us() - t0;
+            st.compute_ms += last_pass_us / 1e3;
             watch_key.store(~0ull, std::memory_order_release); tp->cur_key = ~0ull;
             if (rc < 0) { tp->fail(std::string("stage run failed: ") + (ctx ? pipeinfer_context_error(ctx) : "backend error")); rc_all = -1; break; }
-            if (rc == 1) st.cut_short += metas.size(); else { st.runs += metas.size(); if (metas.size() > 1) st.passes_of_several_runs++; }
+            if (rc == 1) st.cut_short += metas.size(); else if (metas.size() > 1) st.passes_of_several_runs++;
         }
         in.tail.store(t + nm, std::memory_order_release);
         for (size_t k = 0; k < nm; k++) {                                       // results leave in start order
             msg_hdr m = hdr[k];
-            const bool computed = live[k] && rc == 0;
+            // A member the head cancelled AFTER the gather was computed with the pass (a pass of several runs stops only when all of them are cancelled) - but it is reported like
+            // the one-run-per-pass loop reports a run its cancel reached: skipped.  The head never reads a cancelled run's rows, and the stage's runs / skipped counters and the
+            // head's skipped count then mean the same thing in both loops (what differs is GPU time: the one-run loop stops that run's kernels, a pass carries it to the end).
+            const bool computed = live[k] && rc == 0 && !(metas.size() > 1 && tp->is_cancelled(m.gen, m.batch_id));
             m.flags = computed ? 0 : F_SKIPPED;
-            if (!computed) st.skipped++;
+            if (computed) st.runs++; else st.skipped++;
             *(msg_hdr *) tp->res_slot(oh + k) = m;
             L->res.head.store(oh + k + 1, std::memory_order_release);
         }
-        pass_pending = true; pass_first_res = oh;
+        // (a gather whose members were all cancelled already put nothing on the GPU: there is nothing for the driver to react to, and no window behind it -
+        //  the in-process feeder's rule, context.cpp: feed_skips_cancelled)
+        pass_pending = !metas.empty(); pass_first_res = oh;
     }
     while (!coalescing) {
         const uint64_t t = in.tail.load(std::memory_order_relaxed);

@@ -15,14 +15,14 @@ args=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do args+=("$1"); shift; done
 out=gpurun_out/sweep_$tag; mkdir -p $out
 for spec in "$@"; do
     name=${spec%%:*}; envs=(); [ "$spec" != "$name" ] && IFS=, read -ra envs <<< "${spec#*:}"
-    env "${envs[@]}" timeout 1200 python3 bench.py "${args[@]}" > $out/$name.json 2> $out/$name.err || tail -3 $out/$name.err
+    env "${envs[@]}" timeout 1200 python3 bench.py "${args[@]}" --detail $out/$name.detail.json > $out/$name.json 2> $out/$name.err || tail -3 $out/$name.err
     python3 - "$out/$name.json" "$name" <<'PY'
 import json, sys
 try:
-    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r = d["roofline"]
+    d = json.load(open(sys.argv[1].replace(".json", ".detail.json"))); r = d["roofline"]
     print(sys.argv[2], "value", d["value"], "lossless", d.get("lossless_vs_target_only"), {k: v["tokens_per_s"] for k, v in d.get("other_schedules", {}).items()},
           "passes", r.get("target_passes"), "target call ms", r["target_decode_call"]["gpu_ms_per_call"], "draft call ms", r["draft_decode_call"]["gpu_ms_per_call"],
-          "family", r.get("family"), r.get("frac"), "cancelled", r["target_cancelled_runs"]["cancelled_after_start"])
+          "all calls ms", r["target_all_calls"]["gpu_ms_per_call"], "family", r.get("family"), r.get("frac"), "cancelled", r["target_cancelled_runs"]["cancelled_after_start"], "lone", r.get("target_lone_waits"))
 except Exception as e:
     print(sys.argv[2], "failed:", e)
 PY
