@@ -648,8 +648,7 @@ def main():
                                          "gpu_ms_still_spent": round(st_t["cancel_gpu_ms"], 2), "gpu_ms_of_as_many_complete_calls": round(st_t["n_cancel_runs_started"] * avg_call_ms, 2),
                                          "skipped_frac": round(1.0 - st_t["cancel_gpu_ms"] / max(1e-9, st_t["n_cancel_runs_started"] * avg_call_ms), 4) if st_t["n_cancel_runs_started"] else None,
                                          "kernel_abort_word": os.environ.get("PI_NO_ABORT_WORD") is None}
-    roofline["target_passes"] = {"passes": st_t["n_passes"], "runs": st_t["n_pass_runs"], "tokens": st_t["n_pass_tokens"], "passes_of_several_runs": st_t["n_coalesced_passes"]}
-    roofline["target_lone_waits"] = {"waits": st_t["n_lone_waits"], "joined_by_a_run": st_t["n_lone_joined"], "gap_ema_ms": round(st_t["gap_ema_ms"], 3), "one_token_pass_ema_ms": round(st_t["t1_ema_ms"], 3)}
+    roofline["target_passes"] = {"passes": st_t["n_passes"], "runs": st_t["n_pass_runs"], "tokens": st_t["n_pass_tokens"], "passes_of_several_runs": st_t["n_coalesced_passes"], "reaction_windows": st_t["n_reaction_windows"]}
     roofline["draft_decode_call"] = {"calls": st_d["n_calls_1"], "gpu_ms_per_call": round(st_d["gpu_ms_1"] / max(1, st_d["n_calls_1"]), 4),
                                      "GBps": round(st_d["alg_bytes_1"] / max(1e-9, st_d["gpu_ms_1"] * 1e-3) / 1e9, 1)}
 

@@ -163,8 +163,7 @@ struct pipeinfer_stats {
     double   cancel_gpu_ms;      /* GPU time (first to last event) those started-then-cancelled runs still took */
     uint64_t n_passes, n_pass_runs, n_pass_tokens, n_coalesced_passes;   /* feeder contexts: forward passes computed in full, the runs / tokens they carried, passes of more than one run */
     uint64_t weight_copy_bytes;  /* HBM held by the tile-major copies of the matrix-core kernel (0 for contexts with n_batch <= 2: they are not made) */
-    uint64_t n_lone_waits, n_lone_joined;  /* feeder contexts with run coalescing: times a lone one-token run was held back for the speculative run drafted behind it / times that run arrived in time */
-    double   gap_ema_ms, t1_ema_ms;        /* ... what the decision rests on: how long after a lone one-token run's start the next live run joins it (as the waits observe it), the GPU time of a one-token pass (moving averages) */
+    uint64_t n_reaction_windows;          /* feeder contexts with run coalescing: reaction windows opened behind a pass (only passes that put work on the GPU open one; cancelled runs at the queue head are completed on the spot) */
 };
 LLAMA_API void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer_stats * out);
 LLAMA_API void pipeinfer_reset_stats(struct llama_context * ctx);    /* call with no run in flight (it also zeroes the device-side running sums) */

@@ -616,6 +616,7 @@ static void wait_for_reaction(llama_context * ctx) {
     if (!ctx->pass_pending) return;
     (void) hipEventSynchronize(ctx->pass_event);
     ctx->pass_pending = false;
+    ctx->stat_reaction_windows++;
     tl("pass_done", ctx->pass_first_id);
     // bounded by PIPEINFER_REACTION_US (10 ms) and by three quarters of what the pass took from its hand-over to here (a context whose passes take a millisecond does not sit
     // out ten for a caller that is busy rather than blocked); the variable, when set, is the bound whatever the pass took
@@ -630,42 +631,6 @@ static void wait_for_reaction(llama_context * ctx) {
         { std::lock_guard<std::mutex> lk(ctx->fmu); if (ctx->fstop) return; }
         if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
-}
-// A lone one-token run (the driver's non-speculative run for a freshly sampled token, right after a mismatch cancelled everything else) costs a whole pass over the
-// weights; the speculative run drafted from that token follows G = (1 + n_draft) draft steps later and would ride in the same pass for ~35 % more.  The feeder waits for it
-// when that pays: G below PIPEINFER_LONE_WAIT_ALPHA (0.7) x the GPU time of a one-token pass (t1_ema_us, measured at finish).  G is what the wait itself observes
-// (gap_idle_ema_us: the run's start -> a live run joins, with the target idle, i.e. draft steps at their undisturbed rate; the caller's gaps beside a RUNNING target pass are
-// twice as long and would talk the feeder out of waiting for good - that was the first version): the first lone run and every 32nd one after a failure probe for it with a
-// wait of up to one pass time; a wait that times out counts as G = 2 x that.  70B + TinyLlama: G 5 ms against 11 ms - wait; 7B + TinyLlama: G 5 ms against 2.3 ms - launch at once.
-// Ends early when a live run joins the queue, the caller blocks on a run or polls instead of drafting (nothing will follow), or the run is cancelled.
-static void lone_wait(llama_context * ctx, const pi_run * first) {
-    static const double alpha = getenv("PIPEINFER_LONE_WAIT_ALPHA") ? atof(getenv("PIPEINFER_LONE_WAIT_ALPHA")) : 0.7;
-    const int t1 = ctx->t1_ema_us.load();
-    if (alpha <= 0.0 || t1 <= 0) return;
-    const int gap = ctx->gap_idle_ema_us;
-    const bool probe = gap == 0 || (++ctx->lone_seen % 32) == 0;
-    if (!probe && (double) gap >= alpha * (double) t1) return;
-    const int64_t tmo = probe ? (int64_t) t1 : std::min<int64_t>(2 * (int64_t) gap, t1), t0 = time_us();
-    const uint64_t e0 = ctx->caller_epoch.load();
-    int why = 0;
-    for (int spin = 0; !why; spin++) {
-        if (ctx->waiters.load() > 0) why = 1;
-        else if (first->cancel_req.load()) why = 2;
-        else if (ctx->caller_epoch.load() - e0 > 16) why = 3;                  // the caller polls this context instead of drafting: nothing more is coming
-        else if (time_us() - t0 > tmo) why = 4;
-        else {
-            std::lock_guard<std::mutex> lk(ctx->fmu);
-            if (ctx->fstop) why = 5;
-            for (const pi_run * q : ctx->fqueue) if (!q->canceled && !q->cancel_req.load()) { why = 6; break; }
-        }
-        if (!why) { if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20)); }
-    }
-    const int64_t now = time_us();
-    ctx->stat_lone_waits++;
-    if (why == 6) { ctx->stat_lone_joined++; const int g = (int) std::min<int64_t>(now - first->t_start_us, 200000); ctx->gap_idle_ema_us = gap ? (3 * gap + g) / 4 : g; }
-    else if (why == 3 || why == 4) ctx->gap_idle_ema_us = gap ? (3 * gap + 2 * t1) / 4 : 2 * t1;
-    ctx->gap_ema_us.store(ctx->gap_idle_ema_us);
-    tl("lone_wait", first->run_id, why, (int) (now - t0));
 }
 static void feeder_main(llama_context * ctx) {
     (void) hipSetDevice(ctx->model->device);
@@ -693,11 +658,6 @@ static void feeder_main(llama_context * ctx) {
         }
         feed(todo);
         if (!first) continue;
-        if (coalesce && first->n_tokens == 1 && !first->canceled && !first->cancel_req.load()) {
-            bool alone;
-            { std::lock_guard<std::mutex> lk(ctx->fmu); alone = true; for (const pi_run * q : ctx->fqueue) if (!q->canceled && !q->cancel_req.load()) { alone = false; break; } }
-            if (alone) lone_wait(ctx, first);
-        }
         {
             std::lock_guard<std::mutex> lk(ctx->fmu);
             if (coalesce && !first->canceled && !first->cancel_req.load()) {
@@ -1170,7 +1130,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
         ctx->stat_calls++; ctx->stat_alg_bytes += decode_alg_bytes(ctx, pn, n_kv);
         if (pn == 1) { ctx->stat_calls_1++; ctx->stat_alg_bytes_1 += decode_alg_bytes(ctx, 1, n_kv); }
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (pn == 1) { ctx->stat_gpu_ms_1 += ms; const int e = ctx->t1_ema_us.load(), v = (int) (ms * 1000.0f); ctx->t1_ema_us.store(e ? (3 * e + v) / 4 : v); } tl("gpu_us", ctx->stream_priority, run->run_id, (int) (ms * 1000.0f)); }
+        if (hipEventElapsedTime(&ms, run->begin, run->done) == hipSuccess) { ctx->stat_gpu_ms += ms; if (pn == 1) ctx->stat_gpu_ms_1 += ms; tl("gpu_us", ctx->stream_priority, run->run_id, (int) (ms * 1000.0f)); }
     }
     if (run->pass) {                                                          // the object is about to be recycled: it leaves its pass
         std::lock_guard<std::mutex> lk(ctx->fmu);

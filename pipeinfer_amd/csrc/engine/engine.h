@@ -190,10 +190,7 @@ struct llama_context {
     hipEvent_t pass_event = nullptr; bool pass_pending = false; int32_t pass_first_id = 0; int64_t pass_fed_us = 0;      // feeder thread only
     uint8_t * pass_host[4] = { nullptr, nullptr, nullptr, nullptr }; size_t pass_host_cap = 0; int pass_slot = 0;   // pinned staging blocks of composed passes
     std::atomic<uint64_t> stat_passes{0}, stat_pass_runs{0}, stat_pass_tokens{0}, stat_coalesced_passes{0};     // feeder thread writes, caller reads
-    // lone_wait (context.cpp): moving averages of the time from a lone one-token run's start to the next live run joining it (measured by the waits themselves, feeder thread)
-    // and of the GPU time of a one-token pass (caller's thread, at finish); waits done / joined by a run
-    std::atomic<int> gap_ema_us{0}, t1_ema_us{0}; int gap_idle_ema_us = 0; uint32_t lone_seen = 0;
-    std::atomic<uint64_t> stat_lone_waits{0}, stat_lone_joined{0};
+    std::atomic<uint64_t> stat_reaction_windows{0};          // reaction windows opened behind a pass (feeder thread writes, caller reads)
     int32_t * abort_dev = nullptr; int32_t * abort_host = nullptr; hipStream_t ctl_stream = nullptr; int32_t run_counter = 0;
     std::atomic<int32_t> stage_run_id{0};    // pipeline stages (stage_run): id of the run being computed, 0 between runs (read by the transport's cancel watcher)
     double stat_hop_ms = 0.0;                // pipeline stages: GPU time of the in-stream store of the activations into the next stage's ring

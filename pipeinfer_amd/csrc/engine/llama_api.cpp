@@ -383,9 +383,9 @@ extern "C" void pipeinfer_get_stats(struct llama_context * ctx, struct pipeinfer
     out->n_cancel_runs = ctx->stat_cancel_runs; out->n_cancel_runs_started = ctx->stat_cancel_runs_started; out->cancel_gpu_ms = ctx->stat_cancel_gpu_ms;
     out->n_passes = ctx->stat_passes; out->n_pass_runs = ctx->stat_pass_runs; out->n_pass_tokens = ctx->stat_pass_tokens; out->n_coalesced_passes = ctx->stat_coalesced_passes;
     out->weight_copy_bytes = ctx->model->hbm_copy_bytes;
-    out->n_lone_waits = ctx->stat_lone_waits; out->n_lone_joined = ctx->stat_lone_joined; out->gap_ema_ms = ctx->gap_ema_us.load() / 1e3; out->t1_ema_ms = ctx->t1_ema_us.load() / 1e3;
+    out->n_reaction_windows = ctx->stat_reaction_windows;
 }
-extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0; ctx->stat_lone_waits = 0; ctx->stat_lone_joined = 0;
+extern "C" void pipeinfer_reset_stats(struct llama_context * ctx) { ctx->stat_calls = 0; ctx->stat_gpu_ms = 0.0; ctx->stat_alg_bytes = 0; ctx->stat_calls_1 = 0; ctx->stat_gpu_ms_1 = 0.0; ctx->stat_alg_bytes_1 = 0; ctx->stat_segments = 0; ctx->stat_segments_skipped = 0; ctx->stat_cancel_runs = 0; ctx->stat_cancel_runs_started = 0; ctx->stat_cancel_gpu_ms = 0.0; ctx->stat_passes = 0; ctx->stat_pass_runs = 0; ctx->stat_pass_tokens = 0; ctx->stat_coalesced_passes = 0; ctx->stat_reaction_windows = 0;
     { std::lock_guard<std::mutex> glk(ctx->graphs_mu); for (auto & kv : ctx->graphs) kv.second.replays.store(0); }
     // device-side running sums: aborted launches per kernel family (words 8..14 of the abort block), the arrival-flag clock ticks of a pipeline stage.  Call with no run in flight.
     if (ctx->abort_dev && ctx->stream) { (void) hipMemsetAsync(ctx->abort_dev + 8, 0, 8 * sizeof(int32_t), ctx->stream); (void) hipStreamSynchronize(ctx->stream); }

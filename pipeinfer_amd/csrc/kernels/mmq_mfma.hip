@@ -1065,7 +1065,8 @@ static void mmq_go(const mmvq_args & g, int groups, hipStream_t stream, hipEvent
     else if (g.nt <= 16) mmq_go2<TYPE, S, R, TB16, false>(g, groups, stream, ea, eb);
     else if (g.nt <= 32) mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);
     else if constexpr (S == 4) mmq_go2<TYPE, S, R, 1, false, 4>(g, groups, stream, ea, eb);   // prompt passes: four chunks over one weight stream, register-staged activations
-    else mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);                         // (not reached: mmq_dispatch_t sends launches of > 32 tokens to the four-wave configurations)
+    else if (!g.frag) mmq_go2<TYPE, S, R, 1, false, 2>(g, groups, stream, ea, eb);            // (pi_op_mul_mat_reserve walks every (cfg, width): nothing is launched)
+    else pi_set_error("mmq: a launch of %d tokens reached a %d-wave configuration (only four-wave row groups walk four chunks)", g.nt, S);   // not reached: mmq_dispatch_t sends launches of > 32 tokens to 41 / 42 / 43; an error, never half a result
 }
 
 template <int TYPE>
@@ -1080,8 +1081,13 @@ static void mmq_dispatch_t(const mmvq_args & g, int groups, int cfg, hipStream_t
     // four chunks (33..64 tokens): a one-wave row group would carry 4 x 48 chain registers; two-wave row groups (4 x 24) keep them in registers
     // four chunks: four-wave row groups (48 chain registers per wave; two-wave row groups need 96 + the staged block image: 256 VGPRs and ~90 spilled inside the loop).
     // Tall launches (one-wave row groups) do not come here: pi_mmq_step keeps them at 32 tokens per launch.  PI_MMQ_PP_CFG overrides (A/B).
-    static const int pp_cfg = getenv("PI_MMQ_PP_CFG") ? atoi(getenv("PI_MMQ_PP_CFG")) : 0;
-    if (g.nt > 32) { if (pp_cfg) cfg = pp_cfg; else if (cfg == 17 || cfg == 18 || cfg == 14 || cfg == 24 || cfg == 22) cfg = 43; }
+    // (only the four-wave configurations walk four chunks: any other value would compute the first 32 tokens of a 33..64-token launch and leave the rest unwritten — refused, loudly, once)
+    static const int pp_cfg = [] {
+        const int v = getenv("PI_MMQ_PP_CFG") ? atoi(getenv("PI_MMQ_PP_CFG")) : 0;
+        if (v && v != 41 && v != 42 && v != 43) { fprintf(stderr, "PI_MMQ_PP_CFG=%d ignored: launches of more than 32 tokens need a four-wave configuration (41, 42, 43)\n", v); return 0; }
+        return v;
+    }();
+    if (g.nt > 32) { if (pp_cfg) cfg = pp_cfg; else if (cfg != 41 && cfg != 42 && cfg != 43) cfg = 43; }
     switch (cfg) {                                             // (S waves per row group)(R row groups per workgroup); blocks per tile for 16 / <= 8 tokens
         case 17: mmq_go<TYPE, 1, 7, 2, T8>(g, groups, stream, ea, eb); break;
         case 18: mmq_go<TYPE, 1, 8, 2, T8>(g, groups, stream, ea, eb); break;

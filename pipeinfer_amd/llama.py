@@ -50,8 +50,7 @@ class pipeinfer_stats(C.Structure):
     _fields_ = [("n_calls", C.c_uint64), ("gpu_ms", C.c_double), ("alg_bytes", C.c_uint64), ("weight_bytes", C.c_uint64), ("kv_bytes_per_cell", C.c_uint64),
                 ("n_calls_1", C.c_uint64), ("gpu_ms_1", C.c_double), ("alg_bytes_1", C.c_uint64), ("n_segments", C.c_uint64), ("n_segments_skipped", C.c_uint64),
                 ("n_cancel_runs", C.c_uint64), ("n_cancel_runs_started", C.c_uint64), ("cancel_gpu_ms", C.c_double),
-                ("n_passes", C.c_uint64), ("n_pass_runs", C.c_uint64), ("n_pass_tokens", C.c_uint64), ("n_coalesced_passes", C.c_uint64), ("weight_copy_bytes", C.c_uint64),
-                ("n_lone_waits", C.c_uint64), ("n_lone_joined", C.c_uint64), ("gap_ema_ms", C.c_double), ("t1_ema_ms", C.c_double)]
+                ("n_passes", C.c_uint64), ("n_pass_runs", C.c_uint64), ("n_pass_tokens", C.c_uint64), ("n_coalesced_passes", C.c_uint64), ("weight_copy_bytes", C.c_uint64), ("n_reaction_windows", C.c_uint64)]
 
 
 _api = None

@@ -431,7 +431,9 @@ def test_every_run_of_a_speculative_generation_equals_the_oracle(tgt, dft, n_lay
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("workload,n_predict,n_draft,n_parallel,p_accept", [("7b", 12, 3, 3, 0.1), ("70b-l4", 32, 3, 3, 0.1), ("falcon40b-l4", 24, 3, 3, 0.002), ("goliath-l4", 16, 8, 2, 0.002)])
+# (the second set: round 4's generation lengths — every accept / cancel / adopt path many times over; behind PIPEINFER_SLOW_TESTS=1, tests/conftest.py)
+@pytest.mark.parametrize("workload,n_predict,n_draft,n_parallel,p_accept", [("7b", 12, 3, 3, 0.1), ("70b-l4", 32, 3, 3, 0.1), ("falcon40b-l4", 24, 3, 3, 0.002), ("goliath-l4", 16, 8, 2, 0.002)] + [
+    pytest.param(*a, marks=pytest.mark.slow) for a in (("7b", 48, 3, 3, 0.1), ("70b-l4", 48, 3, 3, 0.1), ("falcon40b-l4", 40, 3, 3, 0.002), ("goliath-l4", 40, 8, 2, 0.002))])
 def test_every_run_equals_the_oracle_at_full_size_shapes(workload, n_predict, n_draft, n_parallel, p_accept):
     """the same per-run comparison at the shapes of BASELINE's configurations: the whole Llama-2-7B Q4_K_M (K = 4096 / 11008, 32 layers), and
     Llama-2-70B shapes (GQA 64/8, K = 8192 / 28672: the tile-per-wave decode instances, the matrix-core kernel on verify batches and prompt
@@ -447,7 +449,9 @@ def test_every_run_equals_the_oracle_at_full_size_shapes(workload, n_predict, n_
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "TRACE-PARITY OK" in r.stdout, r.stdout[-2000:]
     spec_runs = int(r.stdout.split("TRACE-PARITY OK spec_runs")[1].split()[0])
-    assert spec_runs > 0, r.stdout[-1500:]                       # speculative batches were among the runs that were compared
+    accepted = int(r.stdout.split("TRACE-PARITY OK spec_runs")[1].split("accepted")[1].split()[0])
+    # the short generations must still walk the paths the long ones were there for: speculative batches among the compared runs, and drafted tokens that were adopted
+    assert spec_runs >= 2 and accepted >= 1, r.stdout[-1500:]
 
 
 def test_full_size_properties_llama_7b(LL, tmp_path_factory):
@@ -767,6 +771,46 @@ def test_coalesced_runs_equal_runs_decoded_one_by_one(LL):
     assert st["n_coalesced_passes"] >= 3 and st["n_pass_runs"] > st["n_passes"]
 
 
+def test_cancelled_runs_at_the_queue_head_open_no_reaction_window(LL):
+    """round 6 (profiles/r06_timeline_70b_before.txt): a cancelled run at the head of the feeder's queue used to travel as an empty pass of its own, and the feeder then sat in
+    that pass's reaction window until the caller finished the cancelled run - which the PipeInfer driver does only between two speculative runs.  Now such runs are completed on
+    the spot: only passes that put work on the GPU open a window.  Runs 21 and 22 are born cancelled (llama_cancel_run before their start: llama.cpp:5614-5628), so what the
+    feeder meets does not depend on timing: [live, cancelled, cancelled, live]."""
+    m = LL.Model(os.path.join(GOLD, "tiny_llama_b_q4_k_m.gguf"))
+    c, ref = LL.Context(m, n_ctx=256, n_batch=64), LL.Context(m, n_ctx=256, n_batch=64)
+    c.set_segments(1)
+    c.prepare(); ref.prepare()
+    c.set_coalescing(16)
+    rng = np.random.default_rng(17)
+    prompt = [int(x) for x in rng.integers(3, m.n_vocab, 10)]
+    c.decode(prompt, list(range(10)), [[0, 1, 2]] * 10); ref.decode(prompt, list(range(10)), [[0, 1, 2]] * 10)
+    for rnd in range(4):
+        c.reset_stats()
+        t = [int(x) for x in rng.integers(3, m.n_vocab, 7)]
+        p0 = 10 + 2 * rnd
+        c.cancel([21, 22])
+        runs = [([t[0]], [p0], [[0, 1, 2]], 0), ([t[1], t[2], t[3]], [p0 + 1, p0 + 2, p0 + 3], [[1]] * 3, 21), ([t[4], t[5]], [p0 + 1, p0 + 2], [[2]] * 2, 22), ([t[6]], [p0 + 1], [[0]], 0)]              # (the last run lives in sequence 0 only: it must not attend to the cancelled runs' never-written cells)
+        tickets = [c.start(tok, pos, seq, batch_id=bid) for tok, pos, seq, bid in runs]
+        got0 = c.finish(tickets[0])
+        for i in (1, 2):
+            assert c.lib.llama_finish_async_decode(c.h, tickets[i][1].c, tickets[i][0]) == 1
+        got3 = c.finish(tickets[3])
+        st = c.stats()
+        assert st["n_passes"] in (1, 2) and st["n_pass_runs"] == 2, st                       # the two live runs, in one pass or two
+        assert st["n_reaction_windows"] <= st["n_passes"], st                             # (the old feeder: a window behind each of the two empty passes as well)
+        assert st["n_cancel_runs"] == 2, st
+        for tok, pos, seq, bid in runs:                                                    # the cancelled runs keep their cells (llama.cpp:5627-5716): the reference context walks the same cells
+            want = ref.decode(tok, pos, seq)
+            if bid == 0:
+                got = got0 if pos[0] == p0 else got3
+                assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (rnd, pos)
+        for cc in (c, ref):
+            cc.seq_rm(1, p0 + 1, -1); cc.seq_rm(2, p0 + 1, -1)
+    for cc in (c, ref):
+        cc.free()
+    m.free()
+
+
 @pytest.mark.parametrize("workload", ["70b", "7b"])
 def test_coalesced_runs_equal_single_runs_at_full_size_shapes(LL, workload):
     """the same at the shapes of the bench target (Llama-2-70B Q4_K_M cut to 4 layers: GQA 64/8, K = 8192 / 28672, Q4_K + Q5_K / Q6_K attention projections in one launch,
@@ -779,7 +823,7 @@ def test_coalesced_runs_equal_single_runs_at_full_size_shapes(LL, workload):
     assert st["n_coalesced_passes"] >= 3
 
 
-@pytest.mark.parametrize("workload,n_predict", [("70b-l4", 40), ("7b", 16)])              # (the oracle replays every run on the host: the whole 7B model is what a token costs there)
+@pytest.mark.parametrize("workload,n_predict", [("70b-l4", 40), ("7b", 16), pytest.param("70b-l4", 64, marks=pytest.mark.slow), pytest.param("7b", 40, marks=pytest.mark.slow)])              # (the oracle replays every run on the host: the whole 7B model is what a token costs there)
 def test_headline_schedule_equals_the_oracle_run_by_run(workload, n_predict):
     """bench.py's `value` configuration itself — PipeInfer driver, target segmented behind its feeder with run coalescing (bench.default_coalesce: 8 tokens), priority draft, one GPU — with every run of the
     generation (prompt passes, single tokens, speculative batches; most of them members of a pass shared with other runs, some cancelled inside one) replayed one by one through
@@ -789,6 +833,10 @@ def test_headline_schedule_equals_the_oracle_run_by_run(workload, n_predict):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "headline_trace_worker.py"), workload, str(n_predict)], capture_output=True, text=True, timeout=1500, env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-3000:])
     assert "HEADLINE-TRACE OK" in r.stdout, r.stdout[-2000:]
+    tail = r.stdout.split("HEADLINE-TRACE OK")[1]
+    coalesced, compared = int(tail.split("coalesced_passes")[1].split()[0]), int(tail.split("compared")[1].split()[0])
+    # what the comparison is there for: passes that carried several runs, and enough runs behind the bit-for-bit check
+    assert coalesced >= 2 and compared >= n_predict // 2, r.stdout[-1500:]
     print(r.stdout[-600:])
 
 

@@ -22,7 +22,7 @@ try:
     d = json.load(open(sys.argv[1].replace(".json", ".detail.json"))); r = d["roofline"]
     print(sys.argv[2], "value", d["value"], "lossless", d.get("lossless_vs_target_only"), {k: v["tokens_per_s"] for k, v in d.get("other_schedules", {}).items()},
           "passes", r.get("target_passes"), "target call ms", r["target_decode_call"]["gpu_ms_per_call"], "draft call ms", r["draft_decode_call"]["gpu_ms_per_call"],
-          "all calls ms", r["target_all_calls"]["gpu_ms_per_call"], "family", r.get("family"), r.get("frac"), "cancelled", r["target_cancelled_runs"]["cancelled_after_start"], "lone", r.get("target_lone_waits"))
+          "all calls ms", r["target_all_calls"]["gpu_ms_per_call"], "family", r.get("family"), r.get("frac"), "cancelled", r["target_cancelled_runs"]["cancelled_after_start"])
 except Exception as e:
     print(sys.argv[2], "failed:", e)
 PY

@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 tag=${1:-r05}; out=gpurun_out/${tag}z; mkdir -p $out
 if [ "$2" != "skip-tests" ]; then
-    timeout 2700 python3 -m pytest tests -m gpu -q --durations=5 > $out/gpu_tests.log 2>&1; tail -6 $out/gpu_tests.log
+    PIPEINFER_SLOW_TESTS=1 timeout 3300 python3 -m pytest tests -m gpu -q --durations=5 > $out/gpu_tests.log 2>&1; tail -6 $out/gpu_tests.log      # (with the long oracle replays the driver's `-m gpu` run skips)
 fi
 bash tools_dev/profile_round.sh ${tag}prof > $out/profile_round.log 2>&1; tail -3 $out/profile_round.log | cut -c1-300
 line() { # name, bench args...
