@@ -506,11 +506,17 @@ extern "C" int pi_op_attention_alibi(const uint16_t * q16, const uint16_t * kc, 
     g.scale = 1.0f / sqrtf((float) hd);                      // KQ_scale, llama.cpp:5189-5193
     g.dyn = dyn_dev; g.abort_w = pi_abort_word(); g.per_token = per_token_kv && dyn_dev ? 1 : 0;
     const int rows = n_tok * (n_head / n_head_kv);
-    // rows per workgroup: K/V are re-read (from L2) by every chunk of a kv head, so chunks stay as large as the launch can
-    // afford while still putting up to one workgroup on each of the 256 CUs
-    constexpr int wg_max = 256;          // (128 -> 256: a 4-token verify batch of the 70B model gets one row per workgroup, 16.4 -> ~11 us per layer; +1 % on the synchronous schedule)
+    // rows per workgroup.  K/V are re-read (from L2) by every workgroup of a kv head, so more rows per workgroup mean fewer bytes through L2 — but a workgroup walks its rows'
+    // phases one after the other, and at the contexts of a generation (a few hundred cells) it is that chain, not L2, that a launch waits for.  Round 6, 70B (8 kv heads x 8 query
+    // heads), n_kv ~ 250, us per launch, one row per workgroup against the old rule (<= 256 workgroups): 7 tokens (448 workgroups) 12.8 against 16.1, 6 tokens 12.6 / 15.9, a
+    // 127-token prompt pass (8 128 workgroups) 75.5 / 88.6; accepted tok/s 110.6 / 110.9 against 107.2 / 109.7 (profiles/r06_attention_rows_per_workgroup.log).  So: ONE row per
+    // workgroup for as long as the launch's K/V re-reads stay under a budget (1.5 GB through L2 ~ 50 us: a 127-token prompt at 250 cells is 1 GB), rows doubled beyond it —
+    // long contexts and wide prompts keep their large chunks.  PI_ATT_L2_MB moves the budget (0: the old rule, <= 256 workgroups).
+    static const int64_t l2_budget = (getenv("PI_ATT_L2_MB") ? atoll(getenv("PI_ATT_L2_MB")) : 1536) << 20;
+    constexpr int wg_max = 256;          // (the old rule; 128 -> 256 in round 3: a 4-token verify batch of the 70B model gets one row per workgroup, 16.4 -> ~11 us per layer)
     int rw = 1;
-    while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > wg_max) rw *= 2;
+    if (l2_budget > 0) { while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) * n_kv * hd * 4 > l2_budget) rw *= 2; }
+    else while (rw < ATT_ROWS && (int64_t) n_head_kv * ((rows + rw - 1) / rw) > wg_max) rw *= 2;
     static const int rw_env = getenv("PI_ATT_RW") ? atoi(getenv("PI_ATT_RW")) : 0;      // tuning / tests
     if (rw_env == 1 || rw_env == 2 || rw_env == 4 || rw_env == 8) rw = rw_env;
     if (g.per_token) { const int r = n_head / n_head_kv; while (rw > 1 && r % rw) rw >>= 1; }      // a workgroup's rows stay inside one token (rows are token-major)
