@@ -16,6 +16,7 @@ namespace { struct tl_event { int64_t t; const char * tag; int a, b, c; }; std::
 void timeline_note(const char * tag, int a, int b, int c) {
     const int64_t t = time_us();
     std::lock_guard<std::mutex> lk(tl_mu);
+    if (tl_events.size() >= (size_t) 4 << 20) return;                      // (a caller that polls in a tight loop must not grow this without bound: the first 4 M events are what is kept)
     tl_events.push_back(tl_event{ t, tag, a, b, c });
 }
 }
