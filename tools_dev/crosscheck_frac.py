@@ -1,9 +1,9 @@
 """roofline.frac of the bench line against the committed rocprofv3 summaries: sum over the matrix-core kernels of (calls x PMC bytes per launch of the symbol) / sum of their durations
-    python3 tools_dev/crosscheck_frac.py [profiles/r05_bench_70b_default_eager_kernel_stats.csv] [profiles/r05_pmc_fetch_size_70b.json] [profiles/r05_bench_70b_n1.json]"""
+    python3 tools_dev/crosscheck_frac.py [profiles/r06_bench_70b_default_eager_kernel_stats.csv] [profiles/r06_pmc_fetch_size_70b.json] [profiles/r06_bench_70b_n1.json]"""
 import csv, json, re, sys
-stats = sys.argv[1] if len(sys.argv) > 1 else "profiles/r05_bench_70b_default_eager_kernel_stats.csv"
-pmc = json.load(open(sys.argv[2] if len(sys.argv) > 2 else "profiles/r05_pmc_fetch_size_70b.json"))["by_symbol"]
-line = json.load(open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r05_bench_70b_n1.json"))
+stats = sys.argv[1] if len(sys.argv) > 1 else "profiles/r06_bench_70b_default_eager_kernel_stats.csv"
+pmc = json.load(open(sys.argv[2] if len(sys.argv) > 2 else "profiles/r06_pmc_fetch_size_70b.json"))["by_symbol"]
+line = json.load(open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r06_bench_70b_n1.json"))
 tot_b = tot_t = 0
 for r in csv.DictReader(open(stats)):
     name = re.sub(r"\(.*", "", r["Name"])
