@@ -74,10 +74,15 @@ bool pi_mmq_supported(int type) {
 // does a batch of n_tok tokens over matrices of `rows` rows in all go to the matrix cores?  Q4_K / Q5_K from pi_mmq_min_nt() tokens; Q6_K builds two operands per
 // accumulator lane and only won from 5 tokens in round 2 (8192 x 28672: VALU 56.9 / 64.9 / 105 / 206 us at 3 / 4 / 8 / 16 tokens, matrix cores 76 at any width up to 16),
 // and on short matrices (attn_v of a GQA model: 64 row groups) only past the VALU kernel's 8 tokens per pass
-bool pi_mmq_wants(int type, int n_tok, int64_t rows) {
+bool pi_mmq_wants(int type, int n_tok, int64_t rows, int64_t k) {
     if (!pi_mmq_supported(type) || n_tok < pi_mmq_min_nt()) return false;
     // (round 4: from 4 tokens on matrices of >= 4096 rows — in the bench the VALU kernel took 72.3 us for the 193 MB ffn_down at 4 tokens, the matrix cores take 65.7)
-    if (type == PI_Q6_K) return n_tok >= 4 && (rows >= 4096 || n_tok > 8);
+    // (round 6, re-measured per shape — profiles/r06_pass_width_dispatch.log, us per launch VALU / matrix cores: long rows win from 3 tokens (8192 x 28672: 65.2 / 59.7 at 3,
+    //  8192 x 32768: 73.0 / 65.9), K <= 11008 only from 5 (9216 x 8192: 25.3 / 29.4 at 4, 41.2 / 27.7 at 5; 8192 x 8192: 23.1 / 24.3, 30.7 / 22.4; 4096 x 11008: 19.3 / 21.2,
+    //  23.1 / 20.5).  PI_MMQ_Q6_MIN=n: one threshold for every shape, as until round 5 with n = 4)
+    static const int q6_min = getenv("PI_MMQ_Q6_MIN") ? atoi(getenv("PI_MMQ_Q6_MIN")) : 0;
+    // tall launches (one-wave row groups: > 1152 row groups, the output heads): from 3 as well — 32000 x 8192 58.4 / 55.4 at 3, 59.5 / 53.6 at 4; 32000 x 4096 31.0 / 32.7, 33.1 / 31.2
+    if (type == PI_Q6_K) return n_tok >= (q6_min ? q6_min : (k >= 16384 || rows > 18432) ? 3 : 5) && (rows >= 4096 || n_tok > 8);
     // short launches: a row group walks its K / 256 blocks one after the other (13.4 us at K = 8192 however few rows there are), while the VALU kernel's
     // tile-per-wave instances put every tile of a short matrix in flight at once.  Measured (us, 3 / 4 / 8 tokens, matrix cores vs VALU): 1024 x 8192 Q5_K (attn_v of
     // a GQA model) 14.5 / 14.5 / 14.5 vs 6.4 / 7.0 / 9.9; 2048 x 8192 13.7 / 13.5 / 13.6 vs 8.5 / 10.4 / 14.9; 4096 x 8192 14.4 / 14.1 / 13.9 vs 12.0 / 13.6 / 21.3;
@@ -1196,7 +1201,7 @@ bool pi_mmq2_applies(int type_b, int n_tok, int64_t rows_a, int64_t rows_b) {
     if (!on || (type_b != PI_Q5_K && type_b != PI_Q6_K) || (n_tok > 8 && n_tok <= 32)) return false;
     const int r = mmq_2t_rows_per_wg(rows_a);
     if (n_tok > 32) return r > 0 && pi_mmq_max_nt() >= 64;
-    return pi_mmq_wants(PI_Q4_K, n_tok, rows_a) && r > 0 && mmq_2t_rows_per_wg_b(r, rows_a, rows_b) > 0;
+    return pi_mmq_wants(PI_Q4_K, n_tok, rows_a, 0) && r > 0 && mmq_2t_rows_per_wg_b(r, rows_a, rows_b) > 0;
 }
 // L: segments [0, n_a) Q4_K, [n_a, nseg) of type_b, all with tile-major copies; g.frag / g.aux / g.nt set.  four: a launch of a prompt pass (g.nt <= 64 tokens, a multiple
 // of 64 tokens into the pass: the four-chunk instance, whatever is left of the pass); else g.nt <= 8

@@ -828,7 +828,10 @@ static int launch_mmvq(mmvq_launch & L, hipStream_t stream) {
                     const int ntiles = (g.nb + KQ_TB - 1) / KQ_TB;
                     static const bool no_tpw = getenv("PI_MMVQ_NO_TPW") != nullptr;    // tuning / tests
                     if constexpr (NT <= 4) {                                           // measured per width: up to 4 tiles at NT <= 2, two tiles at NT 3-4 (70B K = 8192: -15 %), the loop otherwise
-                        if (ntiles > 1 && ntiles <= (NT <= 2 ? 4 : 2) && !no_tpw) {                 // measured: 2-3 tiles win (K = 8192: 11.3 vs 14.5 us), 7 tiles lose (K = 28672: 36.9 vs 34.0; NT = 2: 57 vs 43) — wave 0's serial chain grows with the row
+                        // (Q5_K at TWO tokens is the exception — round 6, us per launch, tile per wave against the loop: 9216 x 8192 27.6 / 23.0, 8192 x 8192 24.0 / 18.3,
+                        //  32768 x 8192 71.1 / 53.9; at one token the tile-per-wave form wins as for the other types: 14.1 / 19.8.  profiles/r06_pass_width_dispatch.log)
+                        constexpr bool tpw_loses = TYPE == PI_Q5_K && NT == 2;
+                        if (ntiles > 1 && ntiles <= (NT <= 2 ? 4 : 2) && !no_tpw && !tpw_loses) {                 // measured: 2-3 tiles win (K = 8192: 11.3 vs 14.5 us), 7 tiles lose (K = 28672: 36.9 vs 34.0; NT = 2: 57 vs 43) — wave 0's serial chain grows with the row
                             const size_t lds_t = (size_t) ntiles * kq_lds<TYPE, RR * NT>::FLOATS * 4;
                             if (sample) hipExtLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, ea, eb, 0, g);
                             else        hipLaunchKernelGGL((k_mmvq_kq<TYPE, NT, RR, 2>), dim3(waves), dim3(64 * ntiles), lds_t, stream, g);
@@ -960,7 +963,7 @@ static int mul_mat_multi_impl(int n_w, const pi_weight * const * ws, const void 
     // (single tokens, types without an MFMA kernel) takes the VALU mat-vec, 8 tokens per pass
     int64_t rows_all = 0;
     for (int i = 0; i < n_w; i++) rows_all += ws[i]->ne1;
-    bool mfma = !mixed && vdt == PI_Q8_K && pi_mmq_wants(w0->type, n_tok, rows_all);
+    bool mfma = !mixed && vdt == PI_Q8_K && pi_mmq_wants(w0->type, n_tok, rows_all, K);
     for (int i = 0; i < n_w; i++) mfma = mfma && ws[i]->mq != nullptr;
     size_t ofa = 0, ofb = 0, oax = 0;
     if (mfma || mixed_mfma) pi_q8_frag_layout(K, n_tok, &ofa, &ofb, &oax);

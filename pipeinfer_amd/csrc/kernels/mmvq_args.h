@@ -42,7 +42,7 @@ struct mmvq_launch { mmvq_args g; int nseg; int64_t m_total, m_min; double wbyte
 
 // mmq_mfma.hip: 1 when the MFMA kernel handles this weight type
 bool pi_mmq_supported(int type);
-bool pi_mmq_wants(int type, int n_tok, int64_t rows);
+bool pi_mmq_wants(int type, int n_tok, int64_t rows, int64_t k);      // k: row length (only Q6_K's threshold depends on it; 0: not known)
 // launches k_mmq_kq for L (segments filled in, g.frag / g.aux / g.nt set); ea / eb: optional events bracketing the kernel (sampled timing)
 int  pi_mmq_launch(int type, mmvq_launch & L, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);
 // two weight types in one matrix-core launch (k_mmq_kq2t): n_a Q4_K segments followed by segments of type_b (Q5_K / Q6_K), 3..8 tokens

@@ -115,6 +115,8 @@ def test_mul_mat_golden_blocks(gpu, t):
                                           (4096, 64, 16), (4096, 49, 9), (8192, 2064, 12), (28672, 40, 16), (2048, 16, 2), (512, 4100, 13), (4096, 80, 17), (1024, 32, 37),
                                           # ... batches of <= 8 tokens reach it from rows x tokens >= 16384 (half-size fragments); 513..768 row groups run three to a workgroup
                                           (512, 4100, 5), (1024, 2100, 8), (256, 5500, 3), (512, 9222, 5), (256, 8200, 3), (768, 12288, 16), (512, 12000, 2), (512, 7000, 6),
+                                          # ... Q6_K: rows of K >= 16384 from 3 tokens, shorter ones from 5 (round 6: the threshold depends on the row length)
+                                          (16384, 5500, 3), (16384, 4100, 4), (4096, 4100, 4), (4096, 4100, 5),
                                           # ... 17..32 tokens: two chunks of 16 over ONE weight stream (every waves-per-row-group choice; a ragged second chunk; prompts in steps of 32)
                                           (4096, 2064, 32), (2048, 9000, 24), (1024, 14000, 33), (512, 20000, 32), (768, 12288, 48), (256, 30000, 31), (8192, 130, 64), (1024, 6200, 18),
                                           # ... 33..64 tokens: four chunks over ONE weight stream, activations staged through registers (prompt passes; a ragged last chunk, 64 + 36 tokens,
