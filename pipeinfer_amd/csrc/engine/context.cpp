@@ -55,7 +55,16 @@ static size_t kv_bytes_per_cell(const llama_context * ctx) {
 // weights of the stage + K/V read over n_kv cells + K/V written for n_tok + activation hops (+ logits)
 size_t decode_alg_bytes(const llama_context * ctx, int n_tok, int n_kv) {
     const pi_hparams & hp = ctx->model->hparams;
-    size_t b = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, n_tok);
+    // stage_weight_bytes walks every tensor NAME of the stage (22 strings and map look-ups per layer): ~70 us for TinyLlama, ~250 us for an 80-layer stage — and this is
+    // called at every finish (twice for a one-token pass), i.e. on the draft's step and in the driver's reaction to a finished pass (round 6: the timeline showed 200 us
+    // between a draft step's GPU time and its host time).  It is linear in n_tok (only the embedding rows depend on it): both terms are computed once per stage.
+    static const bool uncached = getenv("PIPEINFER_ALG_BYTES_UNCACHED") != nullptr;        // (A/B: the walk at every call, as until round 6)
+    if (uncached || ctx->alg_w_key != std::make_tuple(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last)) {
+        ctx->alg_w_fixed = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, 0);
+        ctx->alg_w_per_tok = ctx->model->stage_weight_bytes(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last, 1) - ctx->alg_w_fixed;
+        ctx->alg_w_key = std::make_tuple(ctx->l0, ctx->l1, ctx->is_first, ctx->is_last);
+    }
+    size_t b = ctx->alg_w_fixed + ctx->alg_w_per_tok * (size_t) n_tok;
     b += (size_t) n_kv * kv_bytes_per_cell(ctx) + (size_t) n_tok * kv_bytes_per_cell(ctx);
     b += (size_t) 8 * hp.n_embd * n_tok;
     if (ctx->is_last) b += (size_t) 4 * hp.n_vocab * n_tok;
@@ -684,6 +693,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
     rc = -1;
     std::string err;
     if (!context_prepare(ctx, err)) { ctx->last_error = err; fprintf(stderr, "llama_decode: %s\n", err.c_str()); return nullptr; }
+    tl("start_in", ctx->stream_priority);
     const int n_tokens = batch_in.n_tokens;
     if (n_tokens <= 0) { ctx->last_error = "n_tokens == 0"; return nullptr; }
     if (n_tokens > ctx->n_batch) { ctx->last_error = "n_tokens > n_batch"; fprintf(stderr, "llama_decode: n_tokens (%d) > n_batch (%d)\n", n_tokens, ctx->n_batch); return nullptr; }
@@ -786,6 +796,7 @@ pi_run * context_start(llama_context * ctx, const llama_batch & batch_in, int & 
         return nullptr;
     }
     ctx->inflight.push_back(run);
+    tl("start_out", ctx->stream_priority, run->run_id);
     rc = 0;
     return run;
 }
@@ -1143,6 +1154,7 @@ int context_finish(llama_context * ctx, pi_run * run) {
     for (auto it = ctx->inflight.begin(); it != ctx->inflight.end(); ++it) if (*it == run) { ctx->inflight.erase(it); break; }
     run->finished = true;
     ctx->pool.push_back(run);
+    tl("finish_out", ctx->stream_priority, run->run_id);
     return 1;
 }
 

@@ -16,6 +16,7 @@
 #include <random>
 #include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../../include/llama.h"
@@ -212,6 +213,7 @@ struct llama_context {
     int64_t t_start_us = 0, t_load_us = 0, t_eval_us = 0, t_p_eval_us = 0, t_sample_us = 0;
     int32_t n_eval = 0, n_p_eval = 0, n_sample = 0;
     // roofline accounting
+    mutable size_t alg_w_fixed = 0, alg_w_per_tok = 0; mutable std::tuple<int, int, bool, bool> alg_w_key{-1, -1, false, false};   // decode_alg_bytes: the stage's weight bytes, computed once per (l0, l1, first, last)
     uint64_t stat_calls = 0; double stat_gpu_ms = 0.0; uint64_t stat_alg_bytes = 0;
     uint64_t stat_calls_1 = 0; double stat_gpu_ms_1 = 0.0; uint64_t stat_alg_bytes_1 = 0;      // single-token calls only (the decode rate)
 

@@ -85,6 +85,17 @@ def analyse(path, out=sys.stdout, verbose=True):
     if idle_hist:
         h = np.array(idle_hist)
         print("idle before a pass, ms: mean %.2f  p50 %.2f  p90 %.2f  max %.2f;  > 1 ms: %d of %d (%.1f ms in all)" % (h.mean(), np.median(h), np.percentile(h, 90), h.max(), int((h > 1).sum()), len(h), float(h[h > 1].sum())), file=out)
+    # host time of the priority (draft) context's calls by phase: start_in -> start (cells, mask) -> start_out (launch) .. finish_wait -> finish (the GPU) -> finish_out (copies, accounting); caller's own time between two calls
+    ph = collections.defaultdict(list); last = {}
+    for t, tag, a, b, c in ev:
+        if a <= 0 or tag not in ("start_in", "start", "start_out", "finish_wait", "finish", "finish_out"):
+            continue
+        prev = last.get("tag")
+        if prev and (prev[0], tag) in (("start_in", "start"), ("start", "start_out"), ("start_out", "finish_wait"), ("finish_wait", "finish"), ("finish", "finish_out"), ("finish_out", "start_in")):
+            ph[prev[0] + " -> " + tag].append(t - prev[1])
+        last["tag"] = (tag, t)
+    if ph:
+        print("draft calls, host microseconds by phase (median / mean / n):", {k: (int(np.median(v)), int(np.mean([x for x in v if x < 5000] or [0])), len(v)) for k, v in ph.items()}, file=out)
     widths = collections.Counter((p["runs"], p["tokens"]) for p in passes)
     print("passes by (runs, tokens):", dict(sorted(widths.items())), file=out)
 
